@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- OFDM symbols/s of one DCCN basic-receiver training step (fwd + bwd + Adam) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): OFDM symbols/sec fwd+bwd, DCCN QPSK N=64.  Workload (config[1]): QPSK, N=64, CP=16,
+batch = 8192 OFDM symbols = 1170 frames of 7 symbols (dev/py/ofdmreceiver_np.py:196 `batch_size//nsymbol`),
+F=nfilter=64, D=320 data cells per frame.  A "step" = R0 normalise -> R1 C-Conv -> R2 dense -> R3-R6 tail/
+loss/BER -> full backward -> R7 TF-Adam on synthetic N(0,1) IQ and random bits already resident in HBM
+(throughput is data independent).  Nothing inside the timed region is skipped or cached.
+
+Multi-GPU: the path shards by independent units (SNR-sweep points / batches: SURVEY.md section 8e) -- every
+rank runs its own full step on its own batch, no data-path collective; the only communication is the final
+RCCL all-reduce of the BER/loss table, done once inside the timed region.  scaling = "weak".
+
+One JSON line is printed by rank 0; see the task contract for the fields.  Extra objects:
+  roofline      dominant kernel of the step vs the fp32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline  the reference-equivalent CPU graph (oracle/torch_ref.py, literal TF-style conv3d) on the host
+  kernels       per-operator average launch time (HIP events on the launch stream)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # name: (frames, nbits, nfft, cp, F, D)
+    "c2": dict(frames=1170, nbits=2, nfft=64, cp=16, F=64, D=320,
+               workload="QPSK, N=64/CP=16, batch=8192 OFDM symbols (1170 frames x 7), fwd+bwd+Adam"),
+    "c3": dict(frames=1170, nbits=4, nfft=64, cp=16, F=64, D=320,
+               workload="16-QAM, N=64/CP=16, batch=8192 OFDM symbols (1170 frames x 7), fwd+bwd+Adam"),
+    "c4": dict(frames=585, nbits=2, nfft=1024, cp=72, F=1024, D=4000,
+               workload="QPSK, N=1024/CP=72, batch=4096 OFDM symbols (585 frames x 7), fwd+bwd+Adam"),
+}
+
+
+def step_flops(c):
+    """Algorithmic FLOPs of one training step (SURVEY.md section 8d / BASELINE.md section 2)."""
+    S, kin, F, D, b = 7, c["nfft"] + c["cp"], c["F"], c["D"], c["nbits"]
+    m = 2 ** b
+    L1, L2, L3, L4 = 8 * S * kin * F, 8 * S * F * D, 4 * D * m, 4 * D * (m + 2) * b
+    return c["frames"] * (2 * L1 + 3 * (L2 + L3 + L4))
+
+
+def cpu_baseline(c, budget_s=20.0):
+    """Time the literal torch-CPU restatement of the reference graph (oracle; checker only) on the host."""
+    import numpy as np
+    import torch
+    from oracle import dccn_oracle as O
+    from oracle.torch_ref import LiteralRx
+    S, kin = 7, c["nfft"] + c["cp"]
+    cfg = O.RxConfig(S=S, kin=kin, F=c["F"], D=c["D"], nbits=c["nbits"])
+    frames = c["frames"]
+    rng = np.random.RandomState(0)
+    x = rng.randn(frames, S, kin, 2).astype(np.float32)
+    bits = rng.randint(0, 2, (frames, c["D"], c["nbits"]))
+    out = {}
+    for form, literal in (("conv3d", True), ("gemm", False)):
+        model = LiteralRx(O.init_params(cfg, 1), cfg, dtype=torch.float32, literal_conv=literal)
+        model.train_step(x, bits)                      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            model.train_step(x, bits)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 50:
+                break
+        out[form] = dict(steps=n, seconds=el, sym_per_s=n * frames * S / el)
+    return dict(value=out["conv3d"]["sym_per_s"], unit="OFDM symbols/s", cores=torch.get_num_threads(),
+                kind="port",
+                sample="%d training steps of the same %d-frame batch, torch-CPU fp32 restatement of the TF1 graph "
+                       "(zero-padded conv3d form, as TensorFlow evaluates it); TF1 itself is not installable"
+                       % (out["conv3d"]["steps"], frames),
+                gemm_form_value=out["gemm"]["sym_per_s"],
+                gemm_form_sample="%d steps, same graph with the C-Conv as a centre-tap GEMM" % out["gemm"]["steps"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launch sequence instead of hipGraph replay")
+    ap.add_argument("--no-fork", action="store_true", help="single-stream graph (no concurrent dW branch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-times", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine, time_ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    c = CONFIGS[args.config]
+    S, kin = 7, c["nfft"] + c["cp"]
+    dims = RxDims(S=S, kin=kin, F=c["F"], D=c["D"], nbits=c["nbits"])
+    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1 + rank, want_prob=True, want_tx_power=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
+    eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
+    use_graph, fork = not args.no_graph, not args.no_fork
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    table = torch.zeros(6, dtype=torch.float64, device=dev)      # [c00,c01,c10,c11,ce_sum,count]
+    for _ in range(args.warmup):
+        eng.train_step(graph=use_graph, fork=fork)
+    barrier()
+    timer = HipTimer()
+    timer.start(eng._stream())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(graph=use_graph, fork=fork)
+    # final BER/loss reduction over xGMI (the only collective of the path)
+    mb = eng.metrics_buf
+    table[0:4] = mb[8:40].view(torch.int64).to(torch.float64)
+    table[4] = mb[0:8].view(torch.float64)[0]
+    table[5] = mb[40:48].view(torch.int64)[0].to(torch.float64)
+    if world > 1:
+        dist.all_reduce(table)
+    timer.stop(eng._stream())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = timer.elapsed_ms()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    sym_per_step = c["frames"] * S
+    value = world * args.steps * sym_per_step / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    result = {
+        "metric": "OFDM symbols/sec fwd+bwd, DCCN QPSK N=64" if args.config == "c2" else "OFDM symbols/sec fwd+bwd, DCCN",
+        "value": value, "unit": "OFDM symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
+                   "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
+                   "launch": ("hipGraph replay" + (" (forked dW branch)" if fork else "")) if use_graph else "eager",
+                   "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
+    }
+    if rank == 0:
+        fl = step_flops(c)
+        result["step"] = {"algorithmic_gflop": fl / 1e9, "achieved_tflops": fl / (ms_per_step * 1e-3) / 1e12,
+                          "mfma_frac": fl / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          "hip_event_ms_per_step": ev_ms / args.steps,
+                          "ber_table": [float(v) for v in table.cpu()]}
+        if not args.no_kernel_times:
+            kt = time_ops(eng, iters=200, warmup=20)
+            result["kernels"] = {k: {"us": round(v["ms"] * 1e3, 3), "tflops": round(v["tflops"], 2), "kernel": v["kernel"]}
+                                 for k, v in kt.items()}
+            gemm = {k: v for k, v in kt.items() if v["flops"] > 0 and k != "tail_fwd_bwd"}
+            dom = max(gemm, key=lambda k: gemm[k]["ms"])
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
+                except Exception:
+                    traffic = None
+            result["roofline"] = {"bound": "mfma", "kernel": kt[dom]["kernel"], "op": dom,
+                                  "achieved": kt[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": kt[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                                  "avg_launch_us": kt[dom]["ms"] * 1e3, "flops_per_launch": kt[dom]["flops"]}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(c)
+        cu, wf, hbm, arch = _lib.device_info()
+        result["device"] = {"arch": arch, "cus": cu}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

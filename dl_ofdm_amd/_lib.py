@@ -1,0 +1,132 @@
+"""ctypes binding of libdccn.so (include/dccn.h).
+
+The library is the product: every op of this package calls it, and there is NO CPU or
+PyTorch fallback -- a missing library or a missing GPU raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdccn.so")
+
+
+class DccnError(RuntimeError):
+    pass
+
+
+class Metrics(C.Structure):
+    """dccn_metrics"""
+    _fields_ = [("ce_sum", c_double), ("conf", c_longlong * 4), ("count", c_longlong),
+                ("ce_mean", c_float), ("berlin", c_float), ("log_ber", c_float), ("reserved", c_float)]
+
+
+class AdamState(C.Structure):
+    """dccn_adam_state"""
+    _fields_ = [("global_step", c_float), ("beta1_power", c_float), ("beta2_power", c_float), ("alpha", c_float)]
+
+
+class AdamHParams(C.Structure):
+    """dccn_adam_hparams (ofdmreceiver_np.py:185-189 defaults)"""
+    _fields_ = [("lr0", c_float), ("decay_steps", c_float), ("decay_rate", c_float),
+                ("beta1", c_float), ("beta2", c_float), ("eps", c_float)]
+
+    @classmethod
+    def default(cls, lr0: float = 1e-3):
+        return cls(lr0, 500.0, 0.98, 0.9, 0.999, 1e-8)
+
+
+class RxShape(C.Structure):
+    """dccn_rx_shape"""
+    _fields_ = [("batch", c_int), ("S", c_int), ("kin", c_int), ("F", c_int), ("D", c_int), ("nbits", c_int)]
+
+
+class RxBuffers(C.Structure):
+    """dccn_rx_buffers"""
+    _fields_ = [("x", c_void_p), ("bits", c_void_p), ("params", c_void_p), ("grads", c_void_p),
+                ("adam_m", c_void_p), ("adam_v", c_void_p), ("reg_coef", c_void_p), ("adam", c_void_p),
+                ("x_norm", c_void_p), ("fft_out", c_void_p), ("z", c_void_p), ("prob", c_void_p),
+                ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+METRICS_BYTES = C.sizeof(Metrics)
+ADAM_STATE_BYTES = C.sizeof(AdamState)
+
+_vp, _i, _ll, _f, _sz = c_void_p, c_int, c_longlong, c_float, c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dccn.h declares
+SIGNATURES = {
+    "dccn_strerror": (c_char_p, [_i]),
+    "dccn_version": (_i, []),
+    "dccn_last_hip_error": (_i, []),
+    "dccn_device_info": (_i, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, _i]),
+    "dccn_batch_moment_norm_workspace_size": (_sz, [_i, _i]),
+    "dccn_batch_moment_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    "dccn_clip_power_workspace_size": (_sz, [_ll]),
+    "dccn_clip_power": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _sz, _vp]),
+    "dccn_cconv_gemm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dccn_cconv_gemm_bwd_w_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_cconv_gemm_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_cconv_gemm_bwd_x": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dccn_dense_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dccn_dense_bwd_x": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dccn_dense_bwd_w_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_dense_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_tail_param_count": (_i, [_i]),
+    "dccn_demod_tail_workspace_size": (_sz, [_ll, _i]),
+    "dccn_demod_tail_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),
+    "dccn_demod_tail_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),
+    "dccn_adam_tf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, AdamHParams, _ll, _vp]),
+    "dccn_rx_param_offsets": (_i, [POINTER(RxShape), POINTER(c_longlong)]),
+    "dccn_rx_workspace_size": (_sz, [POINTER(RxShape), _i]),
+    "dccn_rx_eval_step": (_i, [POINTER(RxShape), POINTER(RxBuffers), _vp]),
+    "dccn_rx_train_step": (_i, [POINTER(RxShape), POINTER(RxBuffers), AdamHParams, _vp]),
+    "dccn_rx_graph_create": (_i, [POINTER(RxShape), POINTER(RxBuffers), _i, AdamHParams, _vp, POINTER(c_void_p)]),
+    "dccn_rx_graph_launch": (_i, [_vp, _vp]),
+    "dccn_rx_graph_destroy": (_i, [_vp]),
+    "dccn_timer_create": (_i, [POINTER(c_void_p)]),
+    "dccn_timer_start": (_i, [_vp, _vp]),
+    "dccn_timer_stop": (_i, [_vp, _vp]),
+    "dccn_timer_elapsed_ms": (_i, [_vp, POINTER(c_float)]),
+    "dccn_timer_destroy": (_i, [_vp]),
+    "dccn_stream_synchronize": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libdccn.so (built in-tree by ``__graft_entry__.build()`` / ``make -C dl_ofdm_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DccnError(
+            "libdccn.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dl_ofdm_amd/csrc`; this package has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "dccn call") -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.dccn_strerror(status).decode()
+        raise DccnError("%s failed: %s (status %d, hipError %d)" % (what, msg, status, lib.dccn_last_hip_error()))
+
+
+def device_info():
+    """(cu_count, wavefront, hbm_bytes, arch) of the current HIP device; raises without a GPU."""
+    lib = load()
+    cu, wf, hbm = c_int(0), c_int(0), c_size_t(0)
+    arch = C.create_string_buffer(64)
+    check(lib.dccn_device_info(C.byref(cu), C.byref(wf), C.byref(hbm), arch, 64), "dccn_device_info")
+    return cu.value, wf.value, hbm.value, arch.value.decode()

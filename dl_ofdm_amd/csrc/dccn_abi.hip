@@ -1,0 +1,613 @@
+// libdccn.so -- C ABI over the gfx950 kernels (see include/dccn.h for the contract and the
+// reference call site each entry point replaces).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "gemm_f32_mfma.h"
+#include "norm_adam.h"
+#include "tail.h"
+
+namespace dccn {
+thread_local int g_last_hip_error = 0;
+
+// bump allocator over a caller-provided workspace
+struct Carver {
+    char* base;
+    size_t off, cap;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), off(0), cap(n) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* r = reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap && (base != nullptr || off == 0); }
+};
+static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) + bytes; }
+
+// ---------------------------------------------------------------------------------------
+// R0
+// ---------------------------------------------------------------------------------------
+static int norm_grid_x(int cols) { return ceil_div(ceil_div(cols, 4), 64); }
+static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
+
+static size_t norm_ws_bytes(int batch, int cols) {
+    size_t o = 0;
+    o = carve_size(o, (size_t)kNormRowChunks * cols * 2 * sizeof(double));
+    o = carve_size(o, (size_t)cols * sizeof(float2));
+    o = carve_size(o, (size_t)norm_grid_x(cols) * norm_grid_y(batch) * sizeof(double));
+    return align_up(o, 256);
+}
+
+// power_out nullable -> R8 skipped
+static int norm_impl(const float* x, float* y, float* mean, float* var, float* power_out, int batch, int cols,
+                     float eps, float peak, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!x || !y || batch <= 0 || cols <= 0 || (power_out && (cols & 1))) return DCCN_ERR_INVALID_ARG;
+    if (ws_bytes < norm_ws_bytes(batch, cols) || !ws) return DCCN_ERR_WORKSPACE;
+    Carver c(ws, ws_bytes);
+    double* partial = c.take<double>((size_t)kNormRowChunks * cols * 2);
+    float2* stats = c.take<float2>(cols);
+    const int gx = norm_grid_x(cols), gy = norm_grid_y(batch);
+    double* pw = c.take<double>((size_t)gx * gy);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3(gx, kNormRowChunks), dim3(64, 4), 0, s, x, batch, cols, partial);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, s, partial, batch, cols,
+                       eps, stats, mean, var);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(normalise_kernel, dim3(gx, gy), dim3(64, 4), 0, s, x, y, stats, batch, cols, peak,
+                       power_out ? pw : nullptr);
+    DCCN_LAUNCH_CHECK();
+    if (power_out) {
+        const double denom = (double)batch * (double)(cols / 2);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, pw, gx * gy, denom, power_out);
+        DCCN_LAUNCH_CHECK();
+    }
+    return DCCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// GEMM-shaped ops
+// ---------------------------------------------------------------------------------------
+static GemmParams gp_zero() {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    return p;
+}
+static int round_k(int K) { return ceil_div(K, kBK) * kBK; }
+
+static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                          hipStream_t s) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    GemmParams p = gp_zero();
+    p.A = x; p.B = w; p.C = y; p.bias = bias;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = K; p.ldb = N; p.ldc = N;
+    p.klen = round_k(K);
+    p.vecA = (K % 4 == 0) && aligned16(x);
+    p.vecB = (N % 4 == 0) && aligned16(w);
+    return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
+}
+
+static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
+    if (!dy || !w || !dx || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    GemmParams p = gp_zero();                 // dx[M,K] = dy[M,N] . w[K,N]^T
+    p.A = dy; p.B = w; p.C = dx;
+    p.M = M; p.N = K; p.K = N;
+    p.lda = N; p.ldb = N; p.ldc = K;
+    p.klen = round_k(N);
+    p.vecA = (N % 4 == 0) && aligned16(dy);
+    p.vecB = (N % 4 == 0) && aligned16(w);
+    return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
+}
+
+static size_t splitk_ws_bytes(int Mo, int No, int Kr) {
+    const SplitPlan sp = plan_splitk(Mo, No, Kr);
+    size_t o = 0;
+    o = carve_size(o, (size_t)sp.splits * Mo * No * sizeof(float));
+    o = carve_size(o, (size_t)sp.splits * No * sizeof(float));
+    return align_up(o, 256);
+}
+
+static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
+    if (!x || !dy || !dw || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
+    const SplitPlan sp = plan_splitk(K, N, M);
+    Carver c(ws, ws_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * K * N);
+    float* cs = c.take<float>((size_t)sp.splits * N);
+    GemmParams p = gp_zero();                 // dw[K,N] = x[M,K]^T . dy[M,N]
+    p.A = x; p.B = dy;
+    p.M = K; p.N = N; p.K = M;
+    p.lda = K; p.ldb = N; p.ldc = N;
+    p.klen = sp.klen;
+    p.slab = (long long)K * N;
+    p.vecA = (K % 4 == 0) && aligned16(x);
+    p.vecB = (N % 4 == 0) && aligned16(dy);
+    if (sp.splits == 1) {
+        p.C = dw;
+        p.colsum = dbias;
+        return launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, 1, s);
+    }
+    p.C = slabs;
+    p.colsum = dbias ? cs : nullptr;
+    DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
+    const long long n = (long long)K * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(ceil_div_ll(n, 4), 256)), dim3(256), 0, s,
+                       slabs, sp.splits, n, dw, n);
+    DCCN_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(ceil_div_ll(N, 4), 256)), dim3(256), 0, s,
+                           cs, sp.splits, (long long)N, dbias, (long long)N);
+        DCCN_LAUNCH_CHECK();
+    }
+    return DCCN_OK;
+}
+
+static int cconv_fwd_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
+                          hipStream_t s) {
+    if (!x || !w || !out || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
+    GemmParams p = gp_zero();                 // out[rows,2F] = x[rows,2kin] . Weff[2kin,2F]
+    p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
+    p.M = rows; p.N = 2 * F; p.K = 2 * kin;
+    p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
+    p.klen = round_k(2 * kin);
+    p.cF = F;
+    p.vecA = (kin % 2 == 0) && aligned16(x);
+    return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
+}
+
+static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int rows, int kin, int F, hipStream_t s) {
+    if (!dout || !w || !dx || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
+    GemmParams p = gp_zero();                 // dx[rows,2kin] = dout[rows,2F] . Weff^T
+    p.A = dout; p.B = w; p.C = dx;
+    p.M = rows; p.N = 2 * kin; p.K = 2 * F;
+    p.lda = 2 * F; p.ldb = 2 * F; p.ldc = 2 * kin;
+    p.klen = round_k(2 * F);
+    p.cF = F;
+    p.vecA = (F % 2 == 0) && aligned16(dout);
+    return launch_gemm<OP_KCONTIG, OP_CCONV_WT, 0, TAG_CCONV_BWD_X>(p, 1, s);
+}
+
+static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
+                            void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < splitk_ws_bytes(2 * kin, 2 * F, rows)) return DCCN_ERR_WORKSPACE;
+    const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    Carver c(ws, ws_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * 4 * kin * F);
+    float* cs = c.take<float>((size_t)sp.splits * 2 * F);
+    GemmParams p = gp_zero();                 // dWeff[2kin,2F] = x[rows,2kin]^T . dout[rows,2F]
+    p.A = x; p.B = dout; p.C = slabs; p.colsum = cs;
+    p.M = 2 * kin; p.N = 2 * F; p.K = rows;
+    p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
+    p.klen = sp.klen;
+    p.slab = (long long)4 * kin * F;
+    p.vecA = (kin % 2 == 0) && aligned16(x);
+    p.vecB = (F % 2 == 0) && aligned16(dout);
+    DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
+    const int nthreads = kin * F + F;
+    hipLaunchKernelGGL(cconv_fold_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, s, slabs, sp.splits, p.slab,
+                       cs, dw, dbias, kin, F);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// tail
+// ---------------------------------------------------------------------------------------
+static int tail_blocks(long long cells) {
+    long long b = ceil_div_ll(cells, kTailThreads);
+    if (b > kTailBlocks) b = kTailBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+static size_t tail_ws_bytes(long long cells, int nbits) {
+    size_t o = 0;
+    o = carve_size(o, (size_t)kTailBlocks * sizeof(TailBlockMetrics));
+    o = carve_size(o, (size_t)kTailBlocks * tail_param_count(nbits) * sizeof(float));
+    (void)cells;
+    return align_up(o, 256);
+}
+
+template <int NB>
+static int tail_launch(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob, float* dz,
+                       long long cells, int nblk, TailBlockMetrics* bm, float* bg, hipStream_t s) {
+    if (bwd)
+        hipLaunchKernelGGL((demod_tail_kernel<NB, true>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
+                           dz, cells, bm, bg);
+    else
+        hipLaunchKernelGGL((demod_tail_kernel<NB, false>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
+                           dz, cells, bm, bg);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob,
+                     dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+    if (!z || !bits || !tailp || !metrics || cells <= 0 || nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
+    if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < tail_ws_bytes(cells, nbits)) return DCCN_ERR_WORKSPACE;
+    Carver c(ws, ws_bytes);
+    TailBlockMetrics* bm = c.take<TailBlockMetrics>(kTailBlocks);
+    float* bg = c.take<float>((size_t)kTailBlocks * tail_param_count(nbits));
+    const int nblk = tail_blocks(cells);
+    int st = DCCN_ERR_INVALID_ARG;
+    switch (nbits) {
+        case 1: st = tail_launch<1>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
+        case 2: st = tail_launch<2>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
+        case 3: st = tail_launch<3>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
+        case 4: st = tail_launch<4>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
+    }
+    DCCN_TRY(st);
+    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(1), dim3(256), 0, s, bm, bwd ? bg : nullptr, nblk,
+                       tail_param_count(nbits), cells * nbits, metrics, bwd ? dtailp : nullptr);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+static int adam_impl(float* param, const float* grad, float* m, float* v, const float* reg_coef,
+                     const float* reg_gate, dccn_adam_state* st, dccn_adam_hparams hp, long long n, hipStream_t s) {
+    if (!param || !grad || !m || !v || !st || n <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, st, hp);
+    DCCN_LAUNCH_CHECK();
+    long long blocks = ceil_div_ll(ceil_div_ll(n, 4), 256);
+    if (blocks > 4 * kCUs) blocks = 4 * kCUs;
+    hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, param, grad, m, v, reg_coef,
+                       reg_gate, st, hp, n);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused receiver step
+// ---------------------------------------------------------------------------------------
+static bool shape_ok(const dccn_rx_shape* sh) {
+    return sh && sh->batch > 0 && sh->S > 0 && sh->kin > 0 && sh->F > 0 && sh->D > 0 && sh->nbits >= 1 &&
+           sh->nbits <= 4;
+}
+
+struct RxLayout {
+    long long o_conv_w, o_conv_b, o_dense_w, o_dense_b, o_tail, total;
+    int rows, cols, dK, dN;
+    long long cells;
+    size_t ws_norm, ws_tail, ws_dense_bw, ws_conv_bw;
+};
+static RxLayout rx_layout(const dccn_rx_shape* sh) {
+    RxLayout L;
+    const long long F2 = 2LL * sh->F;
+    L.o_conv_w = 0;
+    L.o_conv_b = L.o_conv_w + (long long)sh->kin * F2;
+    L.o_dense_w = L.o_conv_b + F2;
+    L.o_dense_b = L.o_dense_w + (long long)sh->S * F2 * 2 * sh->D;
+    L.o_tail = L.o_dense_b + 2LL * sh->D;
+    L.total = L.o_tail + tail_param_count(sh->nbits);
+    L.rows = sh->batch * sh->S;
+    L.cols = sh->S * sh->kin * 2;
+    L.dK = sh->S * sh->F * 2;
+    L.dN = 2 * sh->D;
+    L.cells = (long long)sh->batch * sh->D;
+    L.ws_norm = norm_ws_bytes(sh->batch, L.cols);
+    L.ws_tail = tail_ws_bytes(L.cells, sh->nbits);
+    L.ws_dense_bw = splitk_ws_bytes(L.dK, L.dN, sh->batch);
+    L.ws_conv_bw = splitk_ws_bytes(2 * sh->kin, 2 * sh->F, L.rows);
+    return L;
+}
+static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
+    const RxLayout L = rx_layout(sh);
+    size_t o = 0;
+    o = carve_size(o, L.ws_norm);
+    o = carve_size(o, L.ws_tail);
+    if (train) {
+        o = carve_size(o, L.ws_dense_bw);
+        o = carve_size(o, L.ws_conv_bw);
+    }
+    return align_up(o, 256);
+}
+
+// side != nullptr: run the dense weight-gradient branch on `side` (fork/join by events),
+// concurrently with dX -> C-Conv weight gradient on the main stream.
+static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
+                        hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+    if (!shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
+    if (!b->x || !b->bits || !b->params || !b->x_norm || !b->fft_out || !b->z || !b->metrics)
+        return DCCN_ERR_INVALID_ARG;
+    if (train && (!b->grads || !b->adam_m || !b->adam_v || !b->adam || !b->dz || !b->dfft))
+        return DCCN_ERR_INVALID_ARG;
+    if (!b->workspace || b->workspace_bytes < rx_ws_bytes(sh, train ? 1 : 0)) return DCCN_ERR_WORKSPACE;
+    const RxLayout L = rx_layout(sh);
+    Carver c(b->workspace, b->workspace_bytes);
+    void* ws_norm = c.take<char>(L.ws_norm);
+    void* ws_tail = c.take<char>(L.ws_tail);
+    void* ws_dbw = train ? c.take<char>(L.ws_dense_bw) : nullptr;
+    void* ws_cbw = train ? c.take<char>(L.ws_conv_bw) : nullptr;
+    float* P = b->params;
+    float* G = b->grads;
+
+    // R0 (+R8)
+    DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power, sh->batch, L.cols, 1e-9f, 8.0f, ws_norm,
+                       L.ws_norm, s));
+    // R1
+    DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
+    // R2
+    DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
+    // R3-R6 (+ tail backward)
+    DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
+                       L.cells, sh->nbits, ws_tail, L.ws_tail, s));
+    if (!train) return DCCN_OK;
+
+    hipStream_t sw = s;
+    if (side) {
+        DCCN_HIP(hipEventRecord(ev_fork, s));
+        DCCN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        sw = side;
+    }
+    // dense dW/db  (independent of dX)
+    DCCN_TRY(dense_bwd_w_impl(b->fft_out, b->dz, G + L.o_dense_w, G + L.o_dense_b, sh->batch, L.dK, L.dN, ws_dbw,
+                              L.ws_dense_bw, sw));
+    if (side) DCCN_HIP(hipEventRecord(ev_join, side));
+    // dense dX -> C-Conv dW/db (the C-Conv input is data: no dX needed)
+    DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
+    DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
+                              L.ws_conv_bw, s));
+    if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    // R7 (+ BER-gated L2 term of R6)
+    DCCN_TRY(adam_impl(P, G, b->adam_m, b->adam_v, b->reg_coef, b->reg_coef ? &b->metrics->berlin : nullptr, b->adam,
+                       hp, L.total, s));
+    return DCCN_OK;
+}
+
+}  // namespace dccn
+
+using namespace dccn;
+
+struct dccn_rx_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+};
+
+struct dccn_timer {
+    hipEvent_t a, b;
+};
+
+extern "C" {
+
+const char* dccn_strerror(int status) {
+    switch (status) {
+        case DCCN_OK: return "ok";
+        case DCCN_ERR_INVALID_ARG: return "invalid argument";
+        case DCCN_ERR_WORKSPACE: return "workspace missing or too small";
+        case DCCN_ERR_LAUNCH: return "HIP launch/runtime error";
+        case DCCN_ERR_NO_DEVICE: return "no HIP device visible";
+        case DCCN_ERR_STATE: return "object used in the wrong state";
+        default: return "unknown status";
+    }
+}
+
+int dccn_version(void) { return 100; }
+int dccn_last_hip_error(void) { return g_last_hip_error; }
+
+int dccn_device_info(int* cu_count, int* wavefront, size_t* hbm_bytes, char* arch, int arch_len) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DCCN_ERR_NO_DEVICE;
+    int dev = 0;
+    DCCN_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    DCCN_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wavefront) *wavefront = prop.warpSize;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return DCCN_OK;
+}
+
+size_t dccn_batch_moment_norm_workspace_size(int batch, int cols) {
+    if (batch <= 0 || cols <= 0) return 0;
+    return norm_ws_bytes(batch, cols);
+}
+int dccn_batch_moment_norm_fwd(const float* x, float* y, float* mean, float* var, int batch, int cols, float eps,
+                               void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    return norm_impl(x, y, mean, var, nullptr, batch, cols, eps, 8.0f, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+size_t dccn_clip_power_workspace_size(long long n_pairs) {
+    (void)n_pairs;
+    return (size_t)4 * kCUs * sizeof(double);
+}
+int dccn_clip_power(const float* x, float* y, float* power_out, long long n_pairs, float peak, void* workspace,
+                    size_t workspace_bytes, dccn_stream_t stream) {
+    if (!x || !power_out || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_clip_power_workspace_size(n_pairs)) return DCCN_ERR_WORKSPACE;
+    long long blocks = ceil_div_ll(n_pairs, 256);
+    if (blocks > 4 * kCUs) blocks = 4 * kCUs;
+    double* partial = static_cast<double*>(workspace);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(clip_power_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n_pairs, peak, partial);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, (double)n_pairs,
+                       power_out);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+int dccn_cconv_gemm_fwd(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
+                        dccn_stream_t stream) {
+    return cconv_fwd_impl(x, w, bias, out, rows, kin, F, (hipStream_t)stream);
+}
+size_t dccn_cconv_gemm_bwd_w_workspace_size(int rows, int kin, int F) {
+    if (rows <= 0 || kin <= 0 || F <= 0) return 0;
+    return splitk_ws_bytes(2 * kin, 2 * F, rows);
+}
+int dccn_cconv_gemm_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
+                          void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    return cconv_bwd_w_impl(x, dout, dw, dbias, rows, kin, F, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int dccn_cconv_gemm_bwd_x(const float* dout, const float* w, float* dx, int rows, int kin, int F,
+                          dccn_stream_t stream) {
+    return cconv_bwd_x_impl(dout, w, dx, rows, kin, F, (hipStream_t)stream);
+}
+
+int dccn_dense_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                   dccn_stream_t stream) {
+    return dense_fwd_impl(x, w, bias, y, M, K, N, (hipStream_t)stream);
+}
+int dccn_dense_bwd_x(const float* dy, const float* w, float* dx, int M, int K, int N, dccn_stream_t stream) {
+    return dense_bwd_x_impl(dy, w, dx, M, K, N, (hipStream_t)stream);
+}
+size_t dccn_dense_bwd_w_workspace_size(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return splitk_ws_bytes(K, N, M);
+}
+int dccn_dense_bwd_w(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* workspace,
+                     size_t workspace_bytes, dccn_stream_t stream) {
+    return dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dccn_tail_param_count(int nbits) {
+    if (nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
+    return tail_param_count(nbits);
+}
+size_t dccn_demod_tail_workspace_size(long long cells, int nbits) {
+    if (cells <= 0 || nbits < 1 || nbits > 4) return 0;
+    return tail_ws_bytes(cells, nbits);
+}
+int dccn_demod_tail_loss_fwd(const float* z, const int32_t* bits, const float* tailp, float* prob,
+                             dccn_metrics* metrics, long long cells, int nbits, void* workspace,
+                             size_t workspace_bytes, dccn_stream_t stream) {
+    return tail_impl(false, z, bits, tailp, prob, metrics, nullptr, nullptr, cells, nbits, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+int dccn_demod_tail_loss_fwd_bwd(const float* z, const int32_t* bits, const float* tailp, float* prob,
+                                 dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits,
+                                 void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    return tail_impl(true, z, bits, tailp, prob, metrics, dz, dtailp, cells, nbits, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+int dccn_adam_tf_step(float* param, const float* grad, float* m, float* v, const float* reg_coef,
+                      const float* reg_gate, dccn_adam_state* state, dccn_adam_hparams hp, long long n,
+                      dccn_stream_t stream) {
+    return adam_impl(param, grad, m, v, reg_coef, reg_gate, state, hp, n, (hipStream_t)stream);
+}
+
+int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]) {
+    if (!shape_ok(shape) || !offsets) return DCCN_ERR_INVALID_ARG;
+    const RxLayout L = rx_layout(shape);
+    offsets[0] = L.o_conv_w; offsets[1] = L.o_conv_b; offsets[2] = L.o_dense_w;
+    offsets[3] = L.o_dense_b; offsets[4] = L.o_tail; offsets[5] = L.total;
+    return DCCN_OK;
+}
+size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train) {
+    if (!shape_ok(shape)) return 0;
+    return rx_ws_bytes(shape, train);
+}
+int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream) {
+    dccn_adam_hparams hp;
+    memset(&hp, 0, sizeof(hp));
+    return rx_step_impl(shape, buf, false, hp, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+int dccn_rx_train_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_adam_hparams hp,
+                       dccn_stream_t stream) {
+    return rx_step_impl(shape, buf, true, hp, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+// mode: bit0 = train, bit1 = fork the dense weight-gradient branch onto a second stream
+int dccn_rx_graph_create(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, int mode, dccn_adam_hparams hp,
+                         dccn_stream_t stream, dccn_rx_graph** out) {
+    if (!out || !shape_ok(shape) || !buf) return DCCN_ERR_INVALID_ARG;
+    const bool train = mode & 1, fork = (mode & 2) && train;
+    hipStream_t s = (hipStream_t)stream;
+    dccn_rx_graph* g = new dccn_rx_graph();
+    memset(g, 0, sizeof(*g));
+    if (fork) {
+        if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess) {
+            dccn_rx_graph_destroy(g);
+            return DCCN_ERR_LAUNCH;
+        }
+    }
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return hip_fail(e);
+    }
+    const int st = rx_step_impl(shape, buf, train, hp, s, fork ? g->side : nullptr, g->ev_fork, g->ev_join);
+    e = hipStreamEndCapture(s, &g->graph);
+    if (st != DCCN_OK || e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return st != DCCN_OK ? st : hip_fail(e);
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return hip_fail(e);
+    }
+    *out = g;
+    return DCCN_OK;
+}
+int dccn_rx_graph_launch(dccn_rx_graph* g, dccn_stream_t stream) {
+    if (!g || !g->exec) return DCCN_ERR_STATE;
+    DCCN_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return DCCN_OK;
+}
+int dccn_rx_graph_destroy(dccn_rx_graph* g) {
+    if (!g) return DCCN_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->side) (void)hipStreamDestroy(g->side);
+    delete g;
+    return DCCN_OK;
+}
+
+int dccn_timer_create(dccn_timer** out) {
+    if (!out) return DCCN_ERR_INVALID_ARG;
+    dccn_timer* t = new dccn_timer();
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) {
+        delete t;
+        return DCCN_ERR_LAUNCH;
+    }
+    *out = t;
+    return DCCN_OK;
+}
+int dccn_timer_start(dccn_timer* t, dccn_stream_t stream) {
+    if (!t) return DCCN_ERR_STATE;
+    DCCN_HIP(hipEventRecord(t->a, (hipStream_t)stream));
+    return DCCN_OK;
+}
+int dccn_timer_stop(dccn_timer* t, dccn_stream_t stream) {
+    if (!t) return DCCN_ERR_STATE;
+    DCCN_HIP(hipEventRecord(t->b, (hipStream_t)stream));
+    return DCCN_OK;
+}
+int dccn_timer_elapsed_ms(dccn_timer* t, float* ms) {
+    if (!t || !ms) return DCCN_ERR_STATE;
+    DCCN_HIP(hipEventSynchronize(t->b));
+    DCCN_HIP(hipEventElapsedTime(ms, t->a, t->b));
+    return DCCN_OK;
+}
+int dccn_timer_destroy(dccn_timer* t) {
+    if (!t) return DCCN_OK;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return DCCN_OK;
+}
+int dccn_stream_synchronize(dccn_stream_t stream) {
+    DCCN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DCCN_OK;
+}
+
+}  // extern "C"

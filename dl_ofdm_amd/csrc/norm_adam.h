@@ -1,0 +1,249 @@
+// HBM-bound pieces of the receiver step: R0 batch-moment normalisation (+ fused R8 clip
+// power), R7 TF-Adam over a flat parameter arena.  All are float4-vectorised,
+// deterministic (two-stage reductions in a fixed order, fp64 moment accumulation).
+#pragma once
+#include "common.h"
+
+namespace dccn {
+
+constexpr int kNormRowChunks = 32;      // partial-moment slabs per column
+constexpr int kNormRowsPerBlock = 32;   // rows handled by one normalise block
+
+// ---- R0 stage 1: per-column partial sum / sum of squares in fp64 ------------------------
+// grid (ceil(cols/4/64), kNormRowChunks), block (64,4).  partial[(chunk*cols + c)*2 + {0,1}]
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int batch, int cols,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[4][64][8];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c4 = (blockIdx.x * 64 + tx) * 4;
+    const int rows_per_chunk = (batch + kNormRowChunks - 1) / kNormRowChunks;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(batch, r0 + rows_per_chunk);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (c4 < cols) {
+        const bool vec = (c4 + 3 < cols) && ((cols & 3) == 0);
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const float* p = x + (size_t)r * cols + c4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c4 + e < cols) v[e] = p[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[e];
+                s[e] += d;
+                q[e] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[ty][tx][e] = s[e];
+        red[ty][tx][4 + e] = q[e];
+    }
+    __syncthreads();
+    if (ty == 0 && c4 < cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c4 + e < cols) {
+                const double ss = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
+                const double qq = red[0][tx][4 + e] + red[1][tx][4 + e] + red[2][tx][4 + e] + red[3][tx][4 + e];
+                double* o = partial + ((size_t)blockIdx.y * cols + c4 + e) * 2;
+                o[0] = ss;
+                o[1] = qq;
+            }
+        }
+    }
+}
+
+// ---- R0 stage 2: combine the slabs -> mean, inv = rsqrt(var+eps), shift = -mean*inv ------
+// stats[c] = {inv, shift}; optional mean/var outputs (tf.nn.moments values)
+__global__ __launch_bounds__(256) void moments_finalize_kernel(const double* __restrict__ partial, int batch,
+                                                               int cols, float eps, float2* __restrict__ stats,
+                                                               float* __restrict__ mean_out,
+                                                               float* __restrict__ var_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0, q = 0.0;
+    for (int z = 0; z < kNormRowChunks; ++z) {
+        const double* p = partial + ((size_t)z * cols + c) * 2;
+        s += p[0];
+        q += p[1];
+    }
+    const double mean = s / (double)batch;
+    double var = q / (double)batch - mean * mean;      // biased variance, fp64: no cancellation issue
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, varf = (float)var;
+    const float inv = 1.0f / sqrtf(varf + eps);
+    stats[c] = make_float2(inv, -meanf * inv);
+    if (mean_out) mean_out[c] = meanf;
+    if (var_out) var_out[c] = varf;
+}
+
+// ---- R0 stage 3: y = (x*inv + shift)/sqrt(2)  (+ R8: partial sums of the clipped power) --
+// grid (ceil(cols/4/64), ceil(batch/kNormRowsPerBlock)), block (64,4)
+// power_partial[blockIdx.y*gridDim.x + blockIdx.x] = sum over the block of |clip(y)|^2 (fp64)
+__global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float2* __restrict__ stats, int batch, int cols,
+                                                        float peak, double* __restrict__ power_partial) {
+    __shared__ double red[4];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c4 = (blockIdx.x * 64 + tx) * 4;
+    const int r0 = blockIdx.y * kNormRowsPerBlock;
+    const int r1 = min(batch, r0 + kNormRowsPerBlock);
+    const float rs2 = 1.41421356237309515f;            // float32(np.sqrt(2))
+    double pw = 0.0;
+    if (c4 < cols) {
+        const bool vec = (c4 + 3 < cols) && ((cols & 3) == 0);
+        float inv[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 st = (c4 + e < cols) ? stats[c4 + e] : make_float2(0.f, 0.f);
+            inv[e] = st.x;
+            sh[e] = st.y;
+        }
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const size_t off = (size_t)r * cols + c4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(x + off);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c4 + e < cols) v[e] = x[off + e];
+            }
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[e] * inv[e] + sh[e]) / rs2;
+            if (vec) {
+                *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c4 + e < cols) y[off + e] = o[e];
+            }
+            if (power_partial != nullptr) {
+                // complex_clip (dev/py/complex.py:24-26): pairs (I,Q) = (o0,o1), (o2,o3); cols is even
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    if (c4 + e + 1 < cols) {
+                        const float l2 = sqrtf(o[e] * o[e] + o[e + 1] * o[e + 1]);
+                        const float sc = peak / fmaxf(l2, peak);
+                        const float ci = o[e] * sc, cq = o[e + 1] * sc;
+                        pw += (double)(ci * ci + cq * cq);
+                    }
+                }
+            }
+        }
+    }
+    if (power_partial != nullptr) {
+        pw = wave_sum(pw);
+        const int lin = ty * 64 + tx;
+        if ((lin & 63) == 0) red[lin >> 6] = pw;
+        __syncthreads();
+        if (lin == 0) power_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// out[0] = (float)(sum(partial[0..n)) / denom)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double denom,
+                                                           float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / denom);
+}
+
+// ---- R8 standalone: clip + power over [n_pairs,2] ----------------------------------------
+__global__ __launch_bounds__(256) void clip_power_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long long n_pairs, float peak,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[4];
+    double pw = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += stride) {
+        const float2 v = *reinterpret_cast<const float2*>(x + 2 * i);
+        const float l2 = sqrtf(v.x * v.x + v.y * v.y);
+        const float sc = peak / fmaxf(l2, peak);
+        const float ci = v.x * sc, cq = v.y * sc;
+        if (y != nullptr) *reinterpret_cast<float2*>(y + 2 * i) = make_float2(ci, cq);
+        pw += (double)(ci * ci + cq * cq);
+    }
+    pw = wave_sum(pw);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- R7: TF Adam -----------------------------------------------------------------------
+// prep: alpha = lr*sqrt(1-b2p)/(1-b1p) with lr = lr0*rate^floor(step/decay_steps); then the
+// state advances (beta powers *= beta, global_step += 1) -- exactly one thread.
+__global__ void adam_prep_kernel(dccn_adam_state* __restrict__ st, dccn_adam_hparams hp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float step = st->global_step;
+        const float lr = hp.lr0 * powf(hp.decay_rate, floorf(step / hp.decay_steps));
+        const float b1p = st->beta1_power, b2p = st->beta2_power;
+        st->alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        st->beta1_power = b1p * hp.beta1;
+        st->beta2_power = b2p * hp.beta2;
+        st->global_step = step + 1.0f;
+    }
+}
+
+// m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); p -= m*alpha/(sqrt(v)+eps)   (TF ApplyAdam form)
+// g = grad + gate*reg_coef*param
+__global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ reg_coef,
+                                                         const float* __restrict__ reg_gate,
+                                                         const dccn_adam_state* __restrict__ st,
+                                                         dccn_adam_hparams hp, long long n) {
+    const float alpha = st->alpha;
+    const float gate = reg_gate ? reg_gate[0] : 1.0f;
+    const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 p4 = *reinterpret_cast<float4*>(param + i);
+            const float4 g4 = *reinterpret_cast<const float4*>(grad + i);
+            float4 m4 = *reinterpret_cast<float4*>(m + i);
+            float4 v4 = *reinterpret_cast<float4*>(v + i);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (reg_coef) c4 = *reinterpret_cast<const float4*>(reg_coef + i);
+            float* pp = reinterpret_cast<float*>(&p4);
+            const float* gg = reinterpret_cast<const float*>(&g4);
+            float* mm = reinterpret_cast<float*>(&m4);
+            float* vv = reinterpret_cast<float*>(&v4);
+            const float* cc = reinterpret_cast<const float*>(&c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = gg[e] + (gate * cc[e]) * pp[e];
+                mm[e] += (g - mm[e]) * omb1;
+                vv[e] += (g * g - vv[e]) * omb2;
+                pp[e] -= (mm[e] * alpha) / (sqrtf(vv[e]) + hp.eps);
+            }
+            *reinterpret_cast<float4*>(param + i) = p4;
+            *reinterpret_cast<float4*>(m + i) = m4;
+            *reinterpret_cast<float4*>(v + i) = v4;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const float c = reg_coef ? reg_coef[j] : 0.f;
+                const float g = grad[j] + (gate * c) * param[j];
+                float mj = m[j], vj = v[j];
+                mj += (g - mj) * omb1;
+                vj += (g * g - vj) * omb2;
+                param[j] -= (mj * alpha) / (sqrtf(vj) + hp.eps);
+                m[j] = mj;
+                v[j] = vj;
+            }
+        }
+    }
+}
+
+}  // namespace dccn

@@ -1,0 +1,193 @@
+// R3-R6 fused: the per-data-cell demodulation MLP (dev/py/model.py:1278-1291), the double
+// softmax cross-entropy, hard decision and 2x2 confusion counts
+// (dev/py/ofdmreceiver_np.py:154-169), and -- in the training variant -- the whole backward
+// of that tail in the same pass (the loss scale 1/count is known before the launch, so no
+// second sweep over the activations is needed).
+//
+// One thread owns one data cell at a time (grid-stride); the ~40-200 tail weights are read
+// through uniform (scalar-cache) loads; per-thread gradient/metric accumulators are reduced
+// wave -> block -> per-block slab, and a single-block finalize kernel sums the slabs in a
+// fixed order, so every output is deterministic.
+#pragma once
+#include "common.h"
+
+namespace dccn {
+
+constexpr float kLeaky = 0.2f;
+constexpr int kTailBlocks = 256;      // one block per CU
+constexpr int kTailThreads = 256;
+
+__host__ __device__ constexpr int tail_param_count(int nb) {
+    return 2 * (1 << nb) + (1 << nb) + ((1 << nb) + 2) * 2 * nb + 2 * nb;
+}
+
+__device__ __forceinline__ float leaky_relu(float x) { return fmaxf(kLeaky * x, x); }
+
+struct TailBlockMetrics {      // one per block in the workspace
+    double ce_sum;
+    long long conf[4];
+};
+
+template <int NB, bool BWD>
+__global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
+    const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
+    float* __restrict__ prob, float* __restrict__ dz, long long cells,
+    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
+    constexpr int M = 1 << NB;
+    constexpr int O = 2 * NB;
+    constexpr int P = tail_param_count(NB);
+    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
+    __shared__ float sred[BWD ? 4 * P : 1];
+    __shared__ double sce[4];
+    __shared__ int sconf[4][4];
+
+    const float* __restrict__ sw = tailp;   // uniform addresses -> scalar (SGPR) loads
+
+    float gacc[BWD ? P : 1];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) gacc[i] = 0.f;
+    }
+    double ce_acc = 0.0;
+    int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    const float count_f = (float)(cells * NB);
+
+    const long long stride = (long long)gridDim.x * kTailThreads;
+    for (long long cell = (long long)blockIdx.x * kTailThreads + threadIdx.x; cell < cells; cell += stride) {
+        const float2 zz = *reinterpret_cast<const float2*>(z + 2 * cell);
+        const float z0 = zz.x, z1 = zz.y;
+        float c[M + 2], pre1[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            pre1[j] = (z0 * sw[oW1 + j] + z1 * sw[oW1 + M + j]) + sw[oB1 + j];
+            c[j] = leaky_relu(pre1[j]);
+        }
+        c[M] = z0;
+        c[M + 1] = z1;
+        float pre2[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < M + 2; ++i) s += c[i] * sw[oW2 + i * O + o];
+            pre2[o] = s + sw[oB2 + o];
+        }
+        float dpre2[O];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float u0 = leaky_relu(pre2[2 * j]), u1 = leaky_relu(pre2[2 * j + 1]);
+            const float mx = fmaxf(u0, u1);
+            const float e0 = expf(u0 - mx), e1 = expf(u1 - mx);
+            const float es = e0 + e1;
+            const float p0 = e0 / es, p1 = e1 / es;
+            if (prob != nullptr)
+                *reinterpret_cast<float2*>(prob + (cell * NB + j) * 2) = make_float2(p0, p1);
+            const int label = bits[cell * NB + j];
+            // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
+            const float mx2 = fmaxf(p0, p1);
+            const float f0 = expf(p0 - mx2), f1 = expf(p1 - mx2);
+            const float fs = f0 + f1;
+            const float lse = logf(fs) + mx2;
+            ce_acc += (double)(lse - (label ? p1 : p0));
+            const int pred = (p1 > p0) ? 1 : 0;          // argmax, first index on ties
+            if (label == 0) { if (pred == 0) ++c00; else ++c01; }
+            else            { if (pred == 0) ++c10; else ++c11; }
+            if constexpr (BWD) {
+                const float q0 = f0 / fs, q1 = f1 / fs;
+                const float g0 = (q0 - (label ? 0.f : 1.f)) / count_f;
+                const float g1 = (q1 - (label ? 1.f : 0.f)) / count_f;
+                const float dot = g0 * p0 + g1 * p1;
+                const float du0 = p0 * (g0 - dot), du1 = p1 * (g1 - dot);
+                dpre2[2 * j] = du0 * (pre2[2 * j] > 0.f ? 1.f : kLeaky);
+                dpre2[2 * j + 1] = du1 * (pre2[2 * j + 1] > 0.f ? 1.f : kLeaky);
+            }
+        }
+        if constexpr (BWD) {
+            float dc[M + 2];
+#pragma unroll
+            for (int i = 0; i < M + 2; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    gacc[oW2 + i * O + o] += c[i] * dpre2[o];
+                    s += dpre2[o] * sw[oW2 + i * O + o];
+                }
+                dc[i] = s;
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o) gacc[oB2 + o] += dpre2[o];
+            float d0 = dc[M], d1 = dc[M + 1];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const float dp = dc[j] * (pre1[j] > 0.f ? 1.f : kLeaky);
+                gacc[oW1 + j] += z0 * dp;
+                gacc[oW1 + M + j] += z1 * dp;
+                gacc[oB1 + j] += dp;
+                d0 += dp * sw[oW1 + j];
+                d1 += dp * sw[oW1 + M + j];
+            }
+            *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
+        }
+    }
+
+    // ---- block reduction ------------------------------------------------------------
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    ce_acc = wave_sum(ce_acc);
+    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
+    if (lane == 0) {
+        sce[wid] = ce_acc;
+        sconf[wid][0] = c00; sconf[wid][1] = c01; sconf[wid][2] = c10; sconf[wid][3] = c11;
+    }
+    if constexpr (BWD) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float s = wave_sum(gacc[i]);
+            if (lane == 0) sred[wid * P + i] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TailBlockMetrics bm;
+        bm.ce_sum = sce[0] + sce[1] + sce[2] + sce[3];
+        for (int k = 0; k < 4; ++k)
+            bm.conf[k] = (long long)sconf[0][k] + sconf[1][k] + sconf[2][k] + sconf[3][k];
+        blk_metrics[blockIdx.x] = bm;
+    }
+    if constexpr (BWD) {
+        for (int i = threadIdx.x; i < P; i += kTailThreads)
+            blk_grads[(size_t)blockIdx.x * P + i] = (sred[i] + sred[P + i]) + (sred[2 * P + i] + sred[3 * P + i]);
+    }
+}
+
+// single block: metrics + (optional) gradient slabs -> final values, fixed order
+__global__ __launch_bounds__(256) void demod_tail_finalize_kernel(const TailBlockMetrics* __restrict__ blk_metrics,
+                                                                  const float* __restrict__ blk_grads, int nblocks,
+                                                                  int P, long long count,
+                                                                  dccn_metrics* __restrict__ metrics,
+                                                                  float* __restrict__ dtailp) {
+    if (blk_grads != nullptr && dtailp != nullptr) {
+        for (int i = threadIdx.x; i < P; i += 256) {
+            float s = 0.f;
+            for (int b = 0; b < nblocks; ++b) s += blk_grads[(size_t)b * P + i];
+            dtailp[i] = s;
+        }
+    }
+    if (threadIdx.x == 0) {
+        double ce = 0.0;
+        long long cf[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nblocks; ++b) {
+            ce += blk_metrics[b].ce_sum;
+            for (int k = 0; k < 4; ++k) cf[k] += blk_metrics[b].conf[k];
+        }
+        metrics->ce_sum = ce;
+        for (int k = 0; k < 4; ++k) metrics->conf[k] = cf[k];
+        metrics->count = count;
+        metrics->ce_mean = (float)(ce / (double)count);
+        const double ber = (double)(cf[1] + cf[2]) / (double)(cf[0] + cf[1] + cf[2] + cf[3]);
+        metrics->berlin = (float)ber;
+        metrics->log_ber = (float)log(ber);
+        metrics->reserved = 0.f;
+    }
+}
+
+}  // namespace dccn

@@ -1,0 +1,310 @@
+"""The fused basic-receiver step: one ``session.run`` of the reference as one HIP launch
+sequence (optionally a replayed hipGraph).
+
+Replaces dev/py/ofdmreceiver_np.py:121-189 (graph) + :234 (training run) + :80 (evaluation
+run).  All state -- parameters, Adam slots, ``global_step``/beta powers, activations the
+reference exposes by tensor name -- lives in flat HBM arenas owned by this object; the
+library only launches kernels into them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamHParams, AdamState, RxBuffers, RxShape, check
+from .ops import read_metrics, tail_param_count
+
+# checkpoint variable names -> (arena segment, live shape)
+PARAM_NAMES = ("fft_like/conv3d/kernel", "fft_like/conv3d/bias",
+               "demodulation/dense/kernel", "demodulation/dense/bias",
+               "demodulation/conv2d/kernel", "demodulation/conv2d/bias",
+               "demodulation/dense_1/kernel", "demodulation/dense_1/bias")
+REGULARIZED = ("demodulation/dense/kernel", "demodulation/dense/bias",
+               "demodulation/dense_1/kernel", "demodulation/dense_1/bias")
+REG_COEFF = 1e-4      # ofdmreceiver_np.py:162
+REG_L2 = 0.01         # model.py:1271-1272,1285-1286
+
+
+@dataclass(frozen=True)
+class RxDims:
+    S: int      # nsymbol
+    kin: int    # samples per symbol seen by the C-Conv
+    F: int      # nfilter
+    D: int      # frame_size
+    nbits: int
+
+    @property
+    def m(self):
+        return 2 ** self.nbits
+
+
+def param_layout(d: RxDims):
+    """name -> (offset, shape) inside the flat parameter arena (dccn_rx_param_offsets)."""
+    F2, m, b = 2 * d.F, d.m, d.nbits
+    out, o = {}, 0
+    for name, shape in (("fft_like/conv3d/kernel", (d.kin, F2)), ("fft_like/conv3d/bias", (F2,)),
+                        ("demodulation/dense/kernel", (d.S * F2, 2 * d.D)), ("demodulation/dense/bias", (2 * d.D,)),
+                        ("demodulation/conv2d/kernel", (2, m)), ("demodulation/conv2d/bias", (m,)),
+                        ("demodulation/dense_1/kernel", (m + 2, 2 * b)), ("demodulation/dense_1/bias", (2 * b,))):
+        n = int(np.prod(shape))
+        out[name] = (o, shape)
+        o += n
+    return out, o
+
+
+def glorot_init(d: RxDims, seed: int = 1) -> Dict[str, np.ndarray]:
+    """glorot-uniform kernels / zero biases with the reference's fans (the conv3d fans count
+    the K dead taps of the [1,K,1,K,2F] TF kernel -- SURVEY.md Appendix A.7)."""
+    rng = np.random.RandomState(seed)
+    fans = {"fft_like/conv3d/kernel": (d.kin * d.kin, d.kin * 2 * d.F),
+            "demodulation/dense/kernel": (2 * d.S * d.F, 2 * d.D),
+            "demodulation/conv2d/kernel": (2, d.m),
+            "demodulation/dense_1/kernel": (d.m + 2, 2 * d.nbits)}
+    lay, _ = param_layout(d)
+    p = {}
+    for name, (_, shape) in lay.items():
+        if name.endswith("bias"):
+            p[name] = np.zeros(shape, np.float32)
+        else:
+            fi, fo = fans[name]
+            lim = np.sqrt(6.0 / (fi + fo))
+            p[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    return p
+
+
+class RxEngine:
+    """Fixed-shape receiver step engine on one GPU.
+
+    train_step(x, bits) == session.run([train_op, power_tx, ce_mean, berlin], feed)
+    eval_step(x, bits)  == session.run([conf_matrix, berlin, power_tx, ce_mean, ...], feed)
+    """
+
+    def __init__(self, dims: RxDims, batch: int, device="cuda", train: bool = True, seed: int = 1,
+                 params: Optional[Dict[str, np.ndarray]] = None, lr0: float = 1e-3, want_prob: bool = True,
+                 want_tx_power: bool = True):
+        self.lib = _lib.load()
+        self.dims, self.batch, self.train = dims, int(batch), bool(train)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DccnError("RxEngine needs a CUDA (ROCm) device; there is no CPU fallback")
+        self.shape = RxShape(self.batch, dims.S, dims.kin, dims.F, dims.D, dims.nbits)
+        offs = (C.c_longlong * 6)()
+        check(self.lib.dccn_rx_param_offsets(C.byref(self.shape), offs), "dccn_rx_param_offsets")
+        self.layout, total = param_layout(dims)
+        assert total == offs[5] and self.layout["demodulation/conv2d/kernel"][0] == offs[4]
+        self.n_params = total
+        f32 = dict(dtype=torch.float32, device=self.device)
+        B, d = self.batch, dims
+        self.params = torch.zeros(total, **f32)
+        self.x = torch.zeros(B, d.S, d.kin, 2, **f32)
+        self.bits = torch.zeros(B, d.D, d.nbits, dtype=torch.int32, device=self.device)
+        self.x_norm = torch.empty(B, d.S, d.kin, 2, **f32)
+        self.fft_out = torch.empty(B, d.S, d.F, 2, **f32)
+        self.z = torch.empty(B, 2 * d.D, **f32)
+        self.prob = torch.empty(B, d.D, d.nbits, 2, **f32) if want_prob else None
+        self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=self.device)
+        self.tx_power = torch.zeros(1, **f32) if want_tx_power else None
+        if train:
+            self.grads = torch.zeros(total, **f32)
+            self.adam_m = torch.zeros(total, **f32)
+            self.adam_v = torch.zeros(total, **f32)
+            self.reg_coef = torch.zeros(total, **f32)
+            for n in REGULARIZED:
+                o, shp = self.layout[n]
+                self.reg_coef[o:o + int(np.prod(shp))] = REG_COEFF * 2.0 * REG_L2
+            self.adam_state = torch.tensor([0.0, 0.9, 0.999, 0.0], **f32)     # dccn_adam_state
+            self.dz = torch.empty(B, 2 * d.D, **f32)
+            self.dfft = torch.empty(B, d.S, d.F, 2, **f32)
+        else:
+            self.grads = self.adam_m = self.adam_v = self.reg_coef = self.adam_state = self.dz = self.dfft = None
+        nws = self.lib.dccn_rx_workspace_size(C.byref(self.shape), 1 if train else 0)
+        self.ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
+        self.hp = AdamHParams.default(lr0)
+        self._graph = None
+        self._graph_mode = None
+        p = lambda t: 0 if t is None else t.data_ptr()   # noqa: E731
+        self.buffers = RxBuffers(p(self.x), p(self.bits), p(self.params), p(self.grads), p(self.adam_m),
+                                 p(self.adam_v), p(self.reg_coef), p(self.adam_state), p(self.x_norm),
+                                 p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
+                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws)
+        self.load_params(params if params is not None else glorot_init(dims, seed))
+
+    # ---- parameters ----------------------------------------------------------------------
+    def view(self, name: str, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
+        o, shp = self.layout[name]
+        a = self.params if arena is None else arena
+        return a[o:o + int(np.prod(shp))].view(*shp)
+
+    def load_params(self, params: Dict[str, np.ndarray]):
+        for n in PARAM_NAMES:
+            self.view(n).copy_(torch.as_tensor(np.asarray(params[n], dtype=np.float32)).reshape(self.layout[n][1]))
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return {n: self.view(n).detach().cpu().numpy().copy() for n in PARAM_NAMES}
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        return {n: self.view(n, self.grads).detach().cpu().numpy().copy() for n in PARAM_NAMES}
+
+    # ---- steps ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_batch(self, x, bits):
+        """Stage a batch into the engine's resident input buffers (device copy or H2D)."""
+        self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        self.bits.copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
+
+    def train_step(self, x=None, bits=None, graph: bool = False, fork: bool = True):
+        if not self.train:
+            raise _lib.DccnError("engine built with train=False")
+        if x is not None:
+            self.set_batch(x, bits)
+        if graph:
+            self._launch_graph(1 | (2 if fork else 0))
+        else:
+            check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(self.buffers), self.hp, self._stream()),
+                  "dccn_rx_train_step")
+
+    def eval_step(self, x=None, bits=None, graph: bool = False):
+        if x is not None:
+            self.set_batch(x, bits)
+        if graph:
+            self._launch_graph(0)
+        else:
+            check(self.lib.dccn_rx_eval_step(C.byref(self.shape), C.byref(self.buffers), self._stream()),
+                  "dccn_rx_eval_step")
+
+    def _launch_graph(self, mode: int):
+        if self._graph is None or self._graph_mode != mode:
+            self.close_graph()
+            g = C.c_void_p(0)
+            torch.cuda.synchronize(self.device)
+            check(self.lib.dccn_rx_graph_create(C.byref(self.shape), C.byref(self.buffers), mode, self.hp,
+                                                self._stream(), C.byref(g)), "dccn_rx_graph_create")
+            self._graph, self._graph_mode = g, mode
+        check(self.lib.dccn_rx_graph_launch(self._graph, self._stream()), "dccn_rx_graph_launch")
+
+    def close_graph(self):
+        if self._graph is not None:
+            self.lib.dccn_rx_graph_destroy(self._graph)
+            self._graph = None
+
+    def __del__(self):
+        try:
+            self.close_graph()
+        except Exception:
+            pass
+
+    # ---- fetches (synchronise) -----------------------------------------------------------
+    def metrics(self) -> dict:
+        """ce_mean / conf_matrix / linear_ber / log_ber (+ cost, tx_power) of the last step."""
+        m = read_metrics(self.metrics_buf)
+        if self.tx_power is not None:
+            m["tx_power"] = float(self.tx_power.item())
+        return m
+
+    def adam(self) -> dict:
+        s = self.adam_state.cpu().numpy()
+        return dict(global_step=float(s[0]), beta1_power=float(s[1]), beta2_power=float(s[2]), alpha=float(s[3]))
+
+    def cost(self, m: Optional[dict] = None) -> float:
+        """`cost:0` = ce_mean + berlin*REG_COEFF*sum(reg) + log(berlin) (ofdmreceiver_np.py:171)."""
+        m = m or self.metrics()
+        reg = sum(REG_L2 * float((self.view(n) ** 2).sum().item()) for n in REGULARIZED)
+        return m["ce_mean"] + m["berlin"] * REG_COEFF * reg + m["log_ber"]
+
+
+# ---- measurement helpers --------------------------------------------------------------------
+class HipTimer:
+    """HIP events recorded on the stream the kernels are launched on (dccn_timer_*)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.h = C.c_void_p(0)
+        check(self.lib.dccn_timer_create(C.byref(self.h)), "dccn_timer_create")
+
+    def start(self, stream):
+        check(self.lib.dccn_timer_start(self.h, stream), "dccn_timer_start")
+
+    def stop(self, stream):
+        check(self.lib.dccn_timer_stop(self.h, stream), "dccn_timer_stop")
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        check(self.lib.dccn_timer_elapsed_ms(self.h, C.byref(ms)), "dccn_timer_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self.lib.dccn_timer_destroy(self.h)
+        except Exception:
+            pass
+
+
+def op_launchers(eng: RxEngine):
+    """name -> (callable launching that operator once on the current stream into the engine's
+    buffers, algorithmic FLOPs per launch, kernel symbol stem).  Used by bench.py to time the
+    individual kernels of the step with HIP events."""
+    lib, d, B = eng.lib, eng.dims, eng.batch
+    rows, dK, dN, cells = B * d.S, d.S * d.F * 2, 2 * d.D, B * d.D
+    P, G = eng.params, eng.grads
+    lay = eng.layout
+
+    def seg(arena, name):
+        return arena.data_ptr() + 4 * lay[name][0]
+
+    from .ops import workspace
+    nws = max(lib.dccn_dense_bwd_w_workspace_size(B, dK, dN), lib.dccn_cconv_gemm_bwd_w_workspace_size(rows, d.kin, d.F),
+              lib.dccn_demod_tail_workspace_size(cells, d.nbits),
+              lib.dccn_batch_moment_norm_workspace_size(B, d.S * d.kin * 2))
+    ws = workspace(nws, eng.device, "bench")
+    s = eng._stream
+    ops = {
+        "batch_moment_norm": (lambda: lib.dccn_batch_moment_norm_fwd(
+            eng.x.data_ptr(), eng.x_norm.data_ptr(), None, None, B, d.S * d.kin * 2, 1e-9, ws.data_ptr(), nws, s()),
+            0.0, "moments/normalise"),
+        "cconv_fwd": (lambda: lib.dccn_cconv_gemm_fwd(
+            eng.x_norm.data_ptr(), seg(P, "fft_like/conv3d/kernel"), seg(P, "fft_like/conv3d/bias"),
+            eng.fft_out.data_ptr(), rows, d.kin, d.F, s()), 8.0 * rows * d.kin * d.F, "gemm<cconv_fwd>"),
+        "dense_fwd": (lambda: lib.dccn_dense_fwd(
+            eng.fft_out.data_ptr(), seg(P, "demodulation/dense/kernel"), seg(P, "demodulation/dense/bias"),
+            eng.z.data_ptr(), B, dK, dN, s()), 2.0 * B * dK * dN, "gemm<dense_fwd>"),
+        "tail_fwd_bwd": (lambda: lib.dccn_demod_tail_loss_fwd_bwd(
+            eng.z.data_ptr(), eng.bits.data_ptr(), seg(P, "demodulation/conv2d/kernel"),
+            None if eng.prob is None else eng.prob.data_ptr(), eng.metrics_buf.data_ptr(), eng.dz.data_ptr(),
+            seg(G, "demodulation/conv2d/kernel"), cells, d.nbits, ws.data_ptr(), nws, s()),
+            3.0 * cells * (4.0 * d.m + 4.0 * (d.m + 2) * d.nbits), "demod_tail"),
+        "dense_bwd_x": (lambda: lib.dccn_dense_bwd_x(
+            eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(), B, dK, dN, s()),
+            2.0 * B * dK * dN, "gemm<dense_bwd_x>"),
+        "dense_bwd_w": (lambda: lib.dccn_dense_bwd_w(
+            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(G, "demodulation/dense/kernel"),
+            seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
+            2.0 * B * dK * dN, "gemm<dense_bwd_w>+reduce"),
+        "cconv_bwd_w": (lambda: lib.dccn_cconv_gemm_bwd_w(
+            eng.x_norm.data_ptr(), eng.dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
+            seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),
+            8.0 * rows * d.kin * d.F, "gemm<cconv_bwd_w>+fold"),
+    }
+    return ops
+
+
+def time_ops(eng: RxEngine, iters: int = 200, warmup: int = 20) -> Dict[str, dict]:
+    """Average per-launch duration of each operator (HIP events on the launch stream)."""
+    out = {}
+    timer = HipTimer()
+    for name, (fn, flops, sym) in op_launchers(eng).items():
+        for _ in range(warmup):
+            check(fn(), name)
+        timer.start(eng._stream())
+        for _ in range(iters):
+            fn()
+        timer.stop(eng._stream())
+        ms = timer.elapsed_ms() / iters
+        out[name] = dict(ms=ms, flops=flops, tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0, kernel=sym)
+    return out

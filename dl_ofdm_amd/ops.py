@@ -1,0 +1,272 @@
+"""Tensor-level operators over libdccn.so: raw calls + ``torch.autograd.Function`` wrappers.
+
+torch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic
+happens in the HIP kernels.  Every op raises if its input is not a CUDA float32 tensor --
+there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Metrics, check
+
+__all__ = ["batch_moment_norm", "clip_power", "cconv_gemm", "dense", "demod_tail_loss",
+           "demod_tail_eval", "read_metrics", "tail_param_count", "pack_tail_params",
+           "unpack_tail_params", "workspace"]
+
+
+# ---- plumbing -----------------------------------------------------------------------------
+def _need_cuda(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DccnError("dl_ofdm_amd ops need CUDA (ROCm) tensors; got a %s tensor -- there is no "
+                                 "CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise _lib.DccnError("dl_ofdm_amd ops need contiguous tensors")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("expected float32, got %s" % t.dtype)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, key: str = "default") -> torch.Tensor:
+    """Grow-only per-(device,key) scratch buffer (stream-ordered reuse on the current stream)."""
+    k = (str(device), key)
+    t = _ws_cache.get(k)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[k] = t
+    return t
+
+
+def tail_param_count(nbits: int) -> int:
+    m = 2 ** nbits
+    return 2 * m + m + (m + 2) * 2 * nbits + 2 * nbits
+
+
+def pack_tail_params(w1, b1, w2, b2) -> torch.Tensor:
+    """[2,m] | [m] | [m+2,2b] | [2b] -> flat (dccn.h tail packing)."""
+    return torch.cat([w1.reshape(-1), b1.reshape(-1), w2.reshape(-1), b2.reshape(-1)]).contiguous()
+
+
+def unpack_tail_params(flat: torch.Tensor, nbits: int):
+    m = 2 ** nbits
+    o = 0
+    w1 = flat[o:o + 2 * m].view(2, m); o += 2 * m
+    b1 = flat[o:o + m]; o += m
+    w2 = flat[o:o + (m + 2) * 2 * nbits].view(m + 2, 2 * nbits); o += (m + 2) * 2 * nbits
+    b2 = flat[o:o + 2 * nbits]
+    return w1, b1, w2, b2
+
+
+# ---- R0 / R8 ------------------------------------------------------------------------------
+def batch_moment_norm(x: torch.Tensor, eps: float = 1e-9, return_moments: bool = False):
+    """ofdmreceiver_np.py:128-129: moments over axis 0 + batch_normalization / sqrt(2)."""
+    _need_cuda(x); _f32(x)
+    lib = _lib.load()
+    batch = x.shape[0]
+    cols = x.numel() // batch
+    y = torch.empty_like(x)
+    mean = torch.empty(cols, dtype=torch.float32, device=x.device) if return_moments else None
+    var = torch.empty(cols, dtype=torch.float32, device=x.device) if return_moments else None
+    nws = lib.dccn_batch_moment_norm_workspace_size(batch, cols)
+    ws = workspace(nws, x.device)
+    check(lib.dccn_batch_moment_norm_fwd(_p(x), _p(y), _p(mean), _p(var), batch, cols, eps, _p(ws), nws, _stream()),
+          "dccn_batch_moment_norm_fwd")
+    if return_moments:
+        return y, mean.view(x.shape[1:]), var.view(x.shape[1:])
+    return y
+
+
+def clip_power(x: torch.Tensor, peak: float = 1.0, want_clipped: bool = True):
+    """complex.py:21-27 ``complex_clip``: (clip_by_norm over IQ, mean clipped power)."""
+    _need_cuda(x); _f32(x)
+    if x.shape[-1] != 2:
+        raise AssertionError("last axis must be IQ (2)")
+    lib = _lib.load()
+    n_pairs = x.numel() // 2
+    y = torch.empty_like(x) if want_clipped else None
+    power = torch.empty(1, dtype=torch.float32, device=x.device)
+    nws = lib.dccn_clip_power_workspace_size(n_pairs)
+    ws = workspace(nws, x.device)
+    check(lib.dccn_clip_power(_p(x), _p(y), _p(power), n_pairs, peak, _p(ws), nws, _stream()), "dccn_clip_power")
+    return y, power[0]
+
+
+# ---- R1 -----------------------------------------------------------------------------------
+class _CConvGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _need_cuda(x, w, bias); _f32(x, w, bias)
+        lib = _lib.load()
+        rows, kin, _ = x.shape
+        F = w.shape[1] // 2
+        out = torch.empty(rows, F, 2, dtype=torch.float32, device=x.device)
+        check(lib.dccn_cconv_gemm_fwd(_p(x), _p(w), _p(bias), _p(out), rows, kin, F, _stream()),
+              "dccn_cconv_gemm_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        lib = _lib.load()
+        dout = dout.contiguous()
+        rows, kin, _ = x.shape
+        F = w.shape[1] // 2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.dccn_cconv_gemm_bwd_x(_p(dout), _p(w), _p(dx), rows, kin, F, _stream()),
+                  "dccn_cconv_gemm_bwd_x")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(2 * F, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_cconv_gemm_bwd_w_workspace_size(rows, kin, F)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_cconv_gemm_bwd_w(_p(x), _p(dout), _p(dw), _p(db), rows, kin, F, _p(ws), nws, _stream()),
+                  "dccn_cconv_gemm_bwd_w")
+        return dx, dw, db
+
+
+def cconv_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """Complex convolution in GEMM form (complex.py:140-196 after im2col).
+
+    x [rows, kin, 2], w [kin, 2F] = [Wa|Wb], bias [2F] = [ba|bb] -> [rows, F, 2] with
+    re = I.Wa - Q.Wb + (ba-bb), im = I.Wb - Q.Wa + (bb-ba)."""
+    if x.dim() != 3 or x.shape[2] != 2 or w.dim() != 2 or w.shape[0] != x.shape[1] or w.shape[1] % 2:
+        raise TypeError("cconv_gemm: x [rows,kin,2], w [kin,2F]")
+    return _CConvGemm.apply(x.contiguous(), w.contiguous(), None if bias is None else bias.contiguous())
+
+
+# ---- R2 -----------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _need_cuda(x, w, bias); _f32(x, w, bias)
+        lib = _lib.load()
+        M, K = x.shape
+        N = w.shape[1]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        check(lib.dccn_dense_fwd(_p(x), _p(w), _p(bias), _p(y), M, K, N, _stream()), "dccn_dense_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.dccn_dense_bwd_x(_p(dy), _p(w), _p(dx), M, K, N, _stream()), "dccn_dense_bwd_x")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_dense_bwd_w_workspace_size(M, K, N)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_dense_bwd_w(_p(x), _p(dy), _p(dw), _p(db), M, K, N, _p(ws), nws, _stream()),
+                  "dccn_dense_bwd_w")
+        return dx, dw, db
+
+
+def dense(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """tf.layers.dense on the last axis (model.py:1268-1275): x[..., K] . w[K,N] + bias."""
+    lead = x.shape[:-1]
+    y = _Dense.apply(x.reshape(-1, x.shape[-1]).contiguous(), w.contiguous(),
+                     None if bias is None else bias.contiguous())
+    return y.view(*lead, w.shape[1])
+
+
+# ---- R3-R6 --------------------------------------------------------------------------------
+def _new_metrics(device) -> torch.Tensor:
+    return torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=device)
+
+
+def read_metrics(buf: torch.Tensor) -> dict:
+    """Device dccn_metrics -> dict(ce_mean, conf[2][2], berlin, log_ber, ce_sum, count).  Synchronises."""
+    raw = buf.cpu().numpy().tobytes()
+    m = Metrics.from_buffer_copy(raw)
+    return dict(ce_sum=m.ce_sum, conf=[[m.conf[0], m.conf[1]], [m.conf[2], m.conf[3]]], count=m.count,
+                ce_mean=m.ce_mean, berlin=m.berlin, log_ber=m.log_ber)
+
+
+class _TailLoss(torch.autograd.Function):
+    """ce_mean of the demodulation tail; forward already produces dz / dtailp (fused kernel)."""
+
+    @staticmethod
+    def forward(ctx, z, tailp, bits, nbits, prob_out, metrics_buf):
+        _need_cuda(z, tailp, bits); _f32(z, tailp)
+        lib = _lib.load()
+        cells = z.numel() // 2
+        nws = lib.dccn_demod_tail_workspace_size(cells, nbits)
+        ws = workspace(nws, z.device)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if need:
+            dz = torch.empty_like(z)
+            dt = torch.empty_like(tailp)
+            check(lib.dccn_demod_tail_loss_fwd_bwd(_p(z), _p(bits), _p(tailp), _p(prob_out), _p(metrics_buf), _p(dz),
+                                                   _p(dt), cells, nbits, _p(ws), nws, _stream()),
+                  "dccn_demod_tail_loss_fwd_bwd")
+            ctx.save_for_backward(dz, dt)
+        else:
+            check(lib.dccn_demod_tail_loss_fwd(_p(z), _p(bits), _p(tailp), _p(prob_out), _p(metrics_buf), cells,
+                                               nbits, _p(ws), nws, _stream()), "dccn_demod_tail_loss_fwd")
+        # ce_mean lives at a fixed offset inside dccn_metrics (after ce_sum, conf[4], count)
+        ce = metrics_buf[48:52].view(torch.float32).clone().reshape(())
+        return ce
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, dt = ctx.saved_tensors
+        return dz * g, dt * g, None, None, None, None
+
+
+def demod_tail_loss(z: torch.Tensor, tailp: torch.Tensor, bits: torch.Tensor, nbits: int,
+                    want_prob: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
+    """model.py:1278-1291 + ofdmreceiver_np.py:154-169.
+
+    z [..., D, 2] (dense output per data cell), tailp packed tail weights, bits int32
+    [..., D, nbits].  Returns (ce_mean scalar tensor with grad, prob [...,D,nbits,2] or None,
+    metrics buffer -> :func:`read_metrics`)."""
+    if bits.dtype != torch.int32:
+        raise TypeError("bits must be int32")
+    if nbits < 1 or nbits > 4:
+        raise ValueError("nbits must be in 1..4")
+    cells = z.numel() // 2
+    if bits.numel() != cells * nbits or tailp.numel() != tail_param_count(nbits):
+        raise ValueError("shape mismatch between z, bits and tail params")
+    z = z.contiguous()
+    prob = torch.empty(*z.shape[:-1], nbits, 2, dtype=torch.float32, device=z.device) if want_prob else None
+    mbuf = _new_metrics(z.device)
+    ce = _TailLoss.apply(z, tailp.contiguous(), bits.contiguous(), nbits, prob, mbuf)
+    return ce, prob, mbuf
+
+
+def demod_tail_eval(z, tailp, bits, nbits, want_prob=True):
+    with torch.no_grad():
+        return demod_tail_loss(z, tailp, bits, nbits, want_prob)

@@ -1,0 +1,219 @@
+/*
+ * dccn.h -- C ABI of libdccn.so, the MI355X (gfx950) implementation of the DCCN OFDM
+ * receiver hot path.
+ *
+ * The reference (zhongyuanzhao/dl_ofdm) has no FFI: its boundary is the Python layer
+ * API of dev/py/complex.py + dev/py/model.py sitting on TensorFlow library ops.  Each
+ * entry point below replaces the TF ops behind one of those call sites (cited per
+ * function as dev/py/<file>:<lines>).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (16-byte aligned), unless
+ *     the parameter comment says "host";
+ *   - all tensors are dense row-major float32; complex values carry a trailing
+ *     {I,Q} axis of size 2 (dev/py/ofdm.py:375-377);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
+ *     stream-ordered, allocates nothing, and is re-entrant given distinct workspaces;
+ *   - the return value is 0 (DCCN_OK) or a negative dccn_status; no C++ exception
+ *     crosses the ABI.  dccn_strerror() turns a status into text;
+ *   - `*_workspace_size()` return the scratch bytes the matching call needs.
+ */
+#ifndef DCCN_H_
+#define DCCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dccn_stream_t;
+
+typedef enum dccn_status {
+    DCCN_OK = 0,
+    DCCN_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported nbits */
+    DCCN_ERR_WORKSPACE = -2,     /* workspace too small */
+    DCCN_ERR_LAUNCH = -3,        /* hipLaunch / runtime error (see dccn_last_hip_error) */
+    DCCN_ERR_NO_DEVICE = -4,     /* no gfx950 device visible */
+    DCCN_ERR_STATE = -5          /* plan used in the wrong state */
+} dccn_status;
+
+const char* dccn_strerror(int status);
+int dccn_version(void);                              /* 100*major + minor */
+int dccn_last_hip_error(void);                       /* hipError_t of the last failure */
+/* host out-params; returns DCCN_ERR_NO_DEVICE when no GPU is visible */
+int dccn_device_info(int* cu_count, int* wavefront, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- R0: input normalisation ------------------------------------------------------
+ * dev/py/ofdmreceiver_np.py:128-129  tf.nn.moments(x,[0]) + batch_normalization/sqrt(2).
+ * x,y [batch, cols]; mean,var [cols] (nullable).  y = (x*inv + (-mean*inv)) / sqrt(2),
+ * inv = rsqrt(var + eps), biased variance over the batch axis. */
+size_t dccn_batch_moment_norm_workspace_size(int batch, int cols);
+int dccn_batch_moment_norm_fwd(const float* x, float* y, float* mean, float* var,
+                               int batch, int cols, float eps,
+                               void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
+/* ---- R8: complex_clip --------------------------------------------------------------
+ * dev/py/complex.py:21-27  clip_by_norm over the IQ axis + mean clipped power.
+ * x,y [n_pairs,2] (y nullable: power only); power_out: device float[1]. */
+size_t dccn_clip_power_workspace_size(long long n_pairs);
+int dccn_clip_power(const float* x, float* y, float* power_out, long long n_pairs, float peak,
+                    void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
+/* ---- R1 / R1': complex convolution as one fused real GEMM ---------------------------
+ * dev/py/complex.py:140-196 (layers_conv2d_complex) and :51-92 (layers_conv1d_complex):
+ * conv3d/conv2d with 2F filters + 4-way combine.  GEMM form over an (im2col) patch axis:
+ *   x    [rows, kin, 2]      rows = output positions, kin = taps*channels per position
+ *   w    [kin, 2F]           [Wa | Wb] (the live taps of the TF kernel)
+ *   bias [2F]                [ba | bb], nullable
+ *   out  [rows, F, 2]        re = I.Wa - Q.Wb + (ba-bb),  im = I.Wb - Q.Wa + (bb-ba)
+ * The four real products run as ONE MFMA GEMM [rows,2kin] x [2kin,2F] whose B tile is
+ * expanded from w while it is staged into LDS.  Forward is bitwise deterministic. */
+int dccn_cconv_gemm_fwd(const float* x, const float* w, const float* bias, float* out,
+                        int rows, int kin, int F, dccn_stream_t stream);
+size_t dccn_cconv_gemm_bwd_w_workspace_size(int rows, int kin, int F);
+/* dw [kin,2F], dbias [2F] (nullable) from x and dout [rows,F,2] */
+int dccn_cconv_gemm_bwd_w(const float* x, const float* dout, float* dw, float* dbias,
+                          int rows, int kin, int F,
+                          void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+/* dx [rows,kin,2] from dout and w */
+int dccn_cconv_gemm_bwd_x(const float* dout, const float* w, float* dx,
+                          int rows, int kin, int F, dccn_stream_t stream);
+
+/* ---- R2: dense layer ---------------------------------------------------------------
+ * dev/py/model.py:1268-1275  tf.layers.dense: y[M,N] = x[M,K] . w[K,N] + bias[N]. */
+int dccn_dense_fwd(const float* x, const float* w, const float* bias, float* y,
+                   int M, int K, int N, dccn_stream_t stream);
+int dccn_dense_bwd_x(const float* dy, const float* w, float* dx,
+                     int M, int K, int N, dccn_stream_t stream);
+size_t dccn_dense_bwd_w_workspace_size(int M, int K, int N);
+int dccn_dense_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
+                     int M, int K, int N,
+                     void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
+/* ---- R3-R6: demodulation tail + loss + BER ----------------------------------------
+ * dev/py/model.py:1278-1291 (1x1 conv2d 2->m, leaky-ReLU 0.2, concat, dense (m+2)->2b,
+ * leaky-ReLU, softmax over bit pairs), dev/py/ofdmreceiver_np.py:154-169 (one_hot,
+ * softmax_cross_entropy_with_logits on the softmax OUTPUT, argmax, confusion matrix),
+ * dev/py/util.py:44-48 (ber_tensor).  m = 2^nbits, nbits in 1..4.
+ *   z      [cells, 2]         dense output viewed per data cell
+ *   bits   [cells, nbits]     int32 labels
+ *   tailp  [dccn_tail_param_count(nbits)]  packed: w1[2,m] | b1[m] | w2[m+2,2b] | b2[2b]
+ *   prob   [cells, nbits, 2]  (nullable)
+ *   metrics: device dccn_metrics, written by the call (deterministic two-stage reduce)
+ * _fwd_bwd additionally emits dz [cells,2] and dtailp (same packing), the gradient of
+ * ce_mean = mean over cells*nbits of the cross entropy. */
+typedef struct dccn_metrics {
+    double ce_sum;             /* sum of per-bit cross entropies */
+    long long conf[4];         /* confusion matrix, row = label, col = decision */
+    long long count;           /* cells * nbits */
+    float ce_mean;             /* ce_sum / count */
+    float berlin;              /* (conf[1]+conf[2]) / count, f64 division cast to f32 */
+    float log_ber;             /* logf(berlin) (-inf when error free) */
+    float reserved;
+} dccn_metrics;
+
+int dccn_tail_param_count(int nbits);
+size_t dccn_demod_tail_workspace_size(long long cells, int nbits);
+int dccn_demod_tail_loss_fwd(const float* z, const int32_t* bits, const float* tailp,
+                             float* prob, dccn_metrics* metrics, long long cells, int nbits,
+                             void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+int dccn_demod_tail_loss_fwd_bwd(const float* z, const int32_t* bits, const float* tailp,
+                                 float* prob, dccn_metrics* metrics, float* dz, float* dtailp,
+                                 long long cells, int nbits,
+                                 void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
+/* ---- R7: optimizer -----------------------------------------------------------------
+ * dev/py/ofdmreceiver_np.py:185-189  exponential_decay(1e-3, step, 500, 0.98, staircase)
+ * + tf.train.AdamOptimizer (TF 1.15 ApplyAdam kernel form).  All state lives on the
+ * device so a captured step can be replayed without host-side parameter changes.
+ *   state: device dccn_adam_state (global_step, beta powers; advanced by the call)
+ *   param/grad/m/v [n]: flat arenas
+ *   reg_coef [n] (nullable): per-element L2 coefficient c; the gradient used is
+ *       g + (*reg_gate) * c * param    (reg_gate: device float*, nullable -> 1.0).
+ *       The receiver passes c = REG_COEFF*2*0.01 on regularised tensors and
+ *       reg_gate = &metrics->berlin  (ofdmreceiver_np.py:171). */
+typedef struct dccn_adam_state {
+    float global_step;         /* float32 variable, ofdmreceiver_np.py:185 */
+    float beta1_power;
+    float beta2_power;
+    float alpha;               /* lr_t used by the most recent step (output) */
+} dccn_adam_state;
+
+typedef struct dccn_adam_hparams {   /* host struct, passed by value */
+    float lr0, decay_steps, decay_rate;    /* 1e-3, 500, 0.98 */
+    float beta1, beta2, eps;               /* 0.9, 0.999, 1e-8 */
+} dccn_adam_hparams;
+
+int dccn_adam_tf_step(float* param, const float* grad, float* m, float* v,
+                      const float* reg_coef, const float* reg_gate,
+                      dccn_adam_state* state, dccn_adam_hparams hp, long long n,
+                      dccn_stream_t stream);
+
+/* ---- the fused receiver step -------------------------------------------------------
+ * dev/py/ofdmreceiver_np.py:234 (session.run(train_op...)) and :80 (evaluation run):
+ * R0 -> R1 -> R2 -> R3..R6 [-> backward -> R7] as one stream-ordered launch sequence
+ * (optionally captured into a hipGraph and replayed).
+ *
+ * Parameter arena layout (floats), F2 = 2F, m = 2^nbits:
+ *   conv_w [kin,F2] | conv_b [F2] | dense_w [S*F2, 2D] | dense_b [2D] | tailp
+ * dccn_rx_param_offsets() fills offsets[6] = {conv_w, conv_b, dense_w, dense_b, tail, total}. */
+typedef struct dccn_rx_shape {
+    int batch;     /* frames (Bf) */
+    int S;         /* OFDM symbols per frame (7) */
+    int kin;       /* samples per symbol seen by the C-Conv (N+CP, or N when cp=False) */
+    int F;         /* nfilter */
+    int D;         /* data cells per frame (frame_size) */
+    int nbits;     /* 1..4 */
+} dccn_rx_shape;
+
+typedef struct dccn_rx_buffers {
+    const float* x;            /* [batch, S, kin, 2] raw input (tx_ofdm) */
+    const int32_t* bits;       /* [batch, D, nbits] labels (bits_in) */
+    float* params;             /* parameter arena */
+    float* grads;              /* gradient arena (train only) */
+    float* adam_m;             /* train only */
+    float* adam_v;             /* train only */
+    float* reg_coef;           /* [total] per-element L2 coefficient (train only) */
+    dccn_adam_state* adam;     /* train only */
+    float* x_norm;             /* [batch, S, kin, 2]  `input:0` */
+    float* fft_out;            /* [batch, S, F, 2]    `receiver/fft_like/fft_out:0` */
+    float* z;                  /* [batch, 2D] */
+    float* prob;               /* [batch, D, nbits, 2] `output:0` (nullable) */
+    float* dz;                 /* [batch, 2D] train only */
+    float* dfft;               /* [batch, S, F, 2] train only */
+    dccn_metrics* metrics;     /* ce_mean / conf_matrix / linear_ber / log_ber */
+    float* tx_power;           /* device float[1] `tx_power:0` (nullable: skip R8) */
+    void* workspace;
+    size_t workspace_bytes;
+} dccn_rx_buffers;
+
+int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
+size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train);
+/* eager launch sequences */
+int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream);
+int dccn_rx_train_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
+                       dccn_adam_hparams hp, dccn_stream_t stream);
+/* hipGraph-captured replay of the same sequences */
+typedef struct dccn_rx_graph dccn_rx_graph;
+/* mode: bit0 = train (else eval), bit1 = run the dense weight-gradient branch on a forked stream */
+int dccn_rx_graph_create(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, int mode,
+                         dccn_adam_hparams hp, dccn_stream_t stream, dccn_rx_graph** out);
+int dccn_rx_graph_launch(dccn_rx_graph* g, dccn_stream_t stream);
+int dccn_rx_graph_destroy(dccn_rx_graph* g);
+
+/* ---- measurement helpers (HIP events on the caller's stream) ------------------------ */
+typedef struct dccn_timer dccn_timer;
+int dccn_timer_create(dccn_timer** out);
+int dccn_timer_start(dccn_timer* t, dccn_stream_t stream);
+int dccn_timer_stop(dccn_timer* t, dccn_stream_t stream);
+int dccn_timer_elapsed_ms(dccn_timer* t, float* ms);     /* synchronises on the stop event */
+int dccn_timer_destroy(dccn_timer* t);
+int dccn_stream_synchronize(dccn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCCN_H_ */

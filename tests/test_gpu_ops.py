@@ -1,0 +1,251 @@
+"""GPU parity of every C-ABI operator against the CPU oracle (``-m gpu``).
+
+Tolerance (north_star): 1e-5 relative fp32, measured as max|gpu - ref64| / max|ref64| where
+ref64 is the oracle evaluated in float64 on the same float32 inputs.  Integer results
+(confusion counts, decisions outside the stated margin) must be exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def relerr(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    return float(np.abs(got - ref).max()) / scale
+
+
+def assert_close(got, ref, what, tol=RTOL):
+    e = relerr(got, ref)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dl_ofdm_amd import ops as _ops
+    from dl_ofdm_amd import _lib
+    cu, wf, hbm, arch = _lib.device_info()
+    assert wf == 64 and arch.startswith("gfx950"), (cu, wf, arch)
+    return _ops
+
+
+# ---- R0 -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(36, 7, 80, 2), (1170, 7, 80, 2), (5, 3, 5, 2), (64, 7, 64, 2), (2, 1, 3, 2)])
+def test_batch_moment_norm(ops, shape):
+    rng = np.random.RandomState(1)
+    x = (rng.randn(*shape) * rng.uniform(0.1, 3.0, size=shape[1:]) + rng.randn(*shape[1:])).astype(np.float32)
+    y, mean, var = ops.batch_moment_norm(dev(x), return_moments=True)
+    x2 = x.reshape(shape[0], -1).astype(np.float64)
+    yr, mr, vr = O.batch_moment_norm(x2)
+    assert_close(mean.cpu().numpy().reshape(-1), mr, "mean")
+    assert_close(var.cpu().numpy().reshape(-1), vr, "var")
+    assert_close(y.cpu().numpy().reshape(shape[0], -1), yr, "normalised x")
+
+
+def test_batch_moment_norm_batch1_degenerate(ops):
+    # batch 1 -> var 0 -> output exactly 0 * rsqrt(1e-9) = 0
+    x = np.random.RandomState(2).randn(1, 7, 80, 2).astype(np.float32)
+    y = ops.batch_moment_norm(dev(x))
+    assert float(y.abs().max()) <= 1e-3
+
+
+# ---- R8 -------------------------------------------------------------------------------------
+def test_clip_power(ops):
+    rng = np.random.RandomState(3)
+    x = (rng.randn(50, 7, 80, 2) * 4.0).astype(np.float32)      # plenty of samples above the peak
+    y, pw = ops.clip_power(dev(x), peak=8.0)
+    yr, pr = O.complex_clip(x.astype(np.float64), 8.0)
+    assert_close(y.cpu().numpy(), yr, "clipped")
+    assert abs(float(pw) - float(pr)) <= 1e-5 * float(pr)
+    assert float(np.abs(np.linalg.norm(y.cpu().numpy(), axis=-1)).max()) <= 8.0 * (1 + 1e-6)
+
+
+# ---- R1 -------------------------------------------------------------------------------------
+CCONV_SHAPES = [(252, 80, 64), (8190, 80, 64), (37, 5, 3), (100, 64, 64), (129, 33, 17), (70, 1096, 256)]
+
+
+@pytest.mark.parametrize("rows,kin,F", CCONV_SHAPES)
+def test_cconv_gemm_fwd_bwd(ops, rows, kin, F):
+    rng = np.random.RandomState(rows + kin + F)
+    x = rng.randn(rows, kin, 2).astype(np.float32)
+    w = (rng.randn(kin, 2 * F) / np.sqrt(kin)).astype(np.float32)
+    b = rng.randn(2 * F).astype(np.float32)
+    dout = rng.randn(rows, F, 2).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+    out = ops.cconv_gemm(xt, wt, bt)
+    out.backward(dev(dout))
+    ref = O.cconv_gemm_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    dx, dw, db = O.cconv_gemm_bwd(x.astype(np.float64), w.astype(np.float64), dout.astype(np.float64))
+    assert_close(out.detach().cpu().numpy(), ref, "cconv fwd")
+    assert_close(xt.grad.cpu().numpy(), dx, "cconv dx")
+    assert_close(wt.grad.cpu().numpy(), dw, "cconv dw")
+    assert_close(bt.grad.cpu().numpy(), db, "cconv dbias")
+
+
+def test_cconv_gemm_no_bias_and_determinism(ops):
+    rng = np.random.RandomState(9)
+    x, w = rng.randn(500, 80, 2).astype(np.float32), rng.randn(80, 128).astype(np.float32)
+    a = ops.cconv_gemm(dev(x), dev(w), None)
+    b = ops.cconv_gemm(dev(x), dev(w), None)
+    assert torch.equal(a, b)
+    assert_close(a.cpu().numpy(), O.cconv_gemm_fwd(x.astype(np.float64), w.astype(np.float64), None), "no-bias fwd")
+
+
+def test_cconv_known_answer_dft(ops):
+    """Wa=cos_k, Wb=-sin_k gives re = Re{X_k}, im = -Im{X_{N-k}}."""
+    N = 64
+    n = np.arange(N)[:, None]
+    k = np.arange(N)[None, :]
+    wa, wb = np.cos(2 * np.pi * n * k / N), -np.sin(2 * np.pi * n * k / N)
+    w = np.concatenate([wa, wb], axis=1).astype(np.float32)
+    rng = np.random.RandomState(4)
+    xc = rng.randn(33, N) + 1j * rng.randn(33, N)
+    x = np.stack([xc.real, xc.imag], axis=-1).astype(np.float32)
+    out = ops.cconv_gemm(dev(x), dev(w), None).cpu().numpy()
+    X = np.fft.fft(xc, axis=1)
+    assert_close(out[..., 0], X.real, "Re X_k", tol=2e-5)
+    assert_close(out[..., 1], -X[:, (-np.arange(N)) % N].imag, "-Im X_{N-k}", tol=2e-5)
+
+
+# ---- R2 -------------------------------------------------------------------------------------
+DENSE_SHAPES = [(36, 896, 640), (1170, 896, 640), (7, 13, 5), (300, 2048, 1024), (65, 130, 67), (1, 896, 640)]
+
+
+@pytest.mark.parametrize("M,K,N", DENSE_SHAPES)
+def test_dense_fwd_bwd(ops, M, K, N):
+    rng = np.random.RandomState(M + K + N)
+    x = rng.randn(M, K).astype(np.float32)
+    w = (rng.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32)
+    dy = rng.randn(M, N).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+    y = ops.dense(xt, wt, bt)
+    y.backward(dev(dy))
+    x6, w6, b6, d6 = (a.astype(np.float64) for a in (x, w, b, dy))
+    assert_close(y.detach().cpu().numpy(), x6 @ w6 + b6, "dense fwd")
+    assert_close(xt.grad.cpu().numpy(), d6 @ w6.T, "dense dx")
+    assert_close(wt.grad.cpu().numpy(), x6.T @ d6, "dense dw")
+    assert_close(bt.grad.cpu().numpy(), d6.sum(0), "dense dbias")
+
+
+def test_dense_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    K = N = 96
+    bmat = (np.arange(K)[:, None] * 1.0 + 0.001 * np.arange(N)[None, :] ** 2).astype(np.float32)
+    y = ops.dense(dev(np.eye(K, dtype=np.float32)), dev(bmat), None).cpu().numpy()
+    assert np.array_equal(y, bmat)
+
+
+# ---- R3-R6 ----------------------------------------------------------------------------------
+def _tail_params(nbits, rng, dtype=np.float64):
+    m = 2 ** nbits
+    return dict(w1=rng.uniform(-1, 1, (2, m)).astype(dtype), b1=rng.uniform(-.3, .3, m).astype(dtype),
+                w2=rng.uniform(-1, 1, (m + 2, 2 * nbits)).astype(dtype),
+                b2=rng.uniform(-.3, .3, 2 * nbits).astype(dtype))
+
+
+def _tail_oracle(z, bits, tp, nbits):
+    """oracle tail fwd+bwd in float64 via the full-model backward restricted to the tail."""
+    m = 2 ** nbits
+    cells = z.shape[0]
+    pre1 = z @ tp["w1"] + tp["b1"]
+    h1 = O.leaky(pre1)
+    c = np.concatenate([h1, z], -1)
+    pre2 = c @ tp["w2"] + tp["b2"]
+    u = O.leaky(pre2)
+    prob = O.softmax_pairs(u.reshape(cells, nbits, 2))
+    lb = O.loss_ber(prob, bits)
+    pr = prob.reshape(-1, 2)
+    y = bits.reshape(-1)
+    g = O.softmax_pairs(pr)
+    g[np.arange(pr.shape[0]), y] -= 1.0
+    g /= pr.shape[0]
+    du = (pr * (g - (g * pr).sum(-1, keepdims=True))).reshape(cells, 2 * nbits)
+    dpre2 = du * np.where(pre2 > 0, 1.0, 0.2)
+    dc = dpre2 @ tp["w2"].T
+    dpre1 = dc[:, :m] * np.where(pre1 > 0, 1.0, 0.2)
+    grads = dict(w1=z.T @ dpre1, b1=dpre1.sum(0), w2=c.T @ dpre2, b2=dpre2.sum(0))
+    dz = dpre1 @ tp["w1"].T + dc[:, m:]
+    return prob, lb, dz, grads
+
+
+@pytest.mark.parametrize("nbits,cells", [(1, 36 * 320), (2, 36 * 320), (3, 36 * 320), (4, 36 * 320),
+                                         (2, 1170 * 320), (4, 1170 * 320), (2, 1), (3, 77)])
+def test_demod_tail_loss(ops, nbits, cells):
+    rng = np.random.RandomState(10 * nbits + cells % 7)
+    tp = _tail_params(nbits, rng)
+    z = (rng.randn(cells, 2) * 2.0).astype(np.float32)
+    bits = rng.randint(0, 2, (cells, nbits)).astype(np.int32)
+    flat = np.concatenate([tp[k].reshape(-1) for k in ("w1", "b1", "w2", "b2")]).astype(np.float32)
+    tp32 = {k: v.astype(np.float32).astype(np.float64) for k, v in tp.items()}
+    prob_r, lb, dz_r, gr = _tail_oracle(z.astype(np.float64), bits, tp32, nbits)
+
+    zt, ft = dev(z).requires_grad_(), dev(flat).requires_grad_()
+    ce, prob, mbuf = ops.demod_tail_loss(zt, ft, dev(bits, torch.int32), nbits)
+    ce.backward()
+    m = ops.read_metrics(mbuf)
+    assert_close(prob.cpu().numpy(), prob_r, "prob")
+    assert abs(m["ce_mean"] - lb["ce_mean"]) <= 1e-5 * abs(lb["ce_mean"])
+    assert abs(float(ce) - lb["ce_mean"]) <= 1e-5 * abs(lb["ce_mean"])
+    # decisions: exact wherever the float64 margin is not at rounding level
+    pg = prob.cpu().numpy().reshape(-1, 2)
+    pr = prob_r.reshape(-1, 2)
+    safe = np.abs(pr[:, 1] - pr[:, 0]) > 1e-5
+    dec_g, dec_r = (pg[:, 1] > pg[:, 0]), (pr[:, 1] > pr[:, 0])
+    assert np.array_equal(dec_g[safe], dec_r[safe])
+    n_unsafe = int((~safe).sum())
+    conf = np.array(m["conf"])
+    assert conf.sum() == cells * nbits == m["count"]
+    assert np.abs(conf - lb["conf"]).sum() <= 2 * n_unsafe
+    assert_close(zt.grad.cpu().numpy(), dz_r, "dz")
+    g = ft.grad.cpu().numpy()
+    gref = np.concatenate([gr[k].reshape(-1) for k in ("w1", "b1", "w2", "b2")])
+    assert_close(g, gref, "tail param grads")
+    # inference variant agrees bitwise on prob/metrics
+    ce2, prob2, mbuf2 = ops.demod_tail_eval(dev(z), dev(flat), dev(bits, torch.int32), nbits)
+    assert torch.equal(prob2, prob)
+    assert ops.read_metrics(mbuf2)["conf"] == m["conf"]
+
+
+# ---- R7 -------------------------------------------------------------------------------------
+def test_adam_tf_steps(ops):
+    import ctypes as C
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    n = 10007
+    p0 = rng.randn(n).astype(np.float32)
+    reg = np.zeros(n, np.float32)
+    reg[1000:6000] = 2e-6
+    p = {"w": p0.copy()}
+    st = O.adam_init(p)
+    pt, mt, vt = dev(p0), dev(np.zeros(n, np.float32)), dev(np.zeros(n, np.float32))
+    state = dev(np.array([0.0, 0.9, 0.999, 0.0], np.float32))
+    gate = dev(np.array([0.25], np.float32))
+    hp = _lib.AdamHParams.default()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for it in range(7):
+        g = (rng.randn(n) * 0.1).astype(np.float32)
+        geff = g + (np.float32(0.25) * reg) * p["w"]
+        O.adam_tf_step(p, {"w": geff}, st)
+        gt = dev(g)
+        _lib.check(lib.dccn_adam_tf_step(pt.data_ptr(), gt.data_ptr(), mt.data_ptr(), vt.data_ptr(),
+                                         dev(reg).data_ptr(), gate.data_ptr(), state.data_ptr(), hp, n, s))
+        torch.cuda.synchronize()
+    assert_close(pt.cpu().numpy(), p["w"], "adam params", tol=2e-6)
+    assert_close(mt.cpu().numpy(), st.m["w"], "adam m", tol=2e-6)
+    assert_close(vt.cpu().numpy(), st.v["w"], "adam v", tol=2e-6)
+    sv = state.cpu().numpy()
+    assert sv[0] == 7.0 and abs(sv[1] - st.beta1_power) < 1e-7 and abs(sv[2] - st.beta2_power) < 1e-7
