@@ -368,6 +368,7 @@ using namespace dccn;
 struct dccn_rx_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
+    hipStream_t cap;     // capture happens on a private stream: the caller's may be the (uncapturable) null stream
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
 };
@@ -526,9 +527,14 @@ int dccn_rx_graph_create(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
                          dccn_stream_t stream, dccn_rx_graph** out) {
     if (!out || !shape_ok(shape) || !buf) return DCCN_ERR_INVALID_ARG;
     const bool train = mode & 1, fork = (mode & 2) && train;
-    hipStream_t s = (hipStream_t)stream;
+    (void)stream;
     dccn_rx_graph* g = new dccn_rx_graph();
     memset(g, 0, sizeof(*g));
+    if (hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking) != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return DCCN_ERR_LAUNCH;
+    }
+    hipStream_t s = g->cap;
     if (fork) {
         if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -568,6 +574,7 @@ int dccn_rx_graph_destroy(dccn_rx_graph* g) {
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     if (g->side) (void)hipStreamDestroy(g->side);
+    if (g->cap) (void)hipStreamDestroy(g->cap);
     delete g;
     return DCCN_OK;
 }

@@ -339,6 +339,43 @@ def total_loss(p, lb):
             + np.float32(BER_COEFF) * np.float32(lb["log_ber"]))
 
 
+def tail_forward_backward(z: np.ndarray, bits: np.ndarray, w1, b1, w2, b2, nbits: int):
+    """Demodulation tail + loss on its own (model.py:1278-1291, ofdmreceiver_np.py:154-169) with
+    the hand-derived backward of ce_mean.
+
+    z [cells,2], bits [cells,nbits].  Returns dict(prob, loss_ber fields, dz, grads{w1,b1,w2,b2},
+    pre1, pre2) -- pre1/pre2 let tests locate cells sitting on the leaky-ReLU kink."""
+    dt = z.dtype
+    m = 2 ** nbits
+    cells = z.shape[0]
+    pre1 = z @ w1 + b1
+    h1 = leaky(pre1)
+    c = np.concatenate([h1, z], axis=-1)
+    pre2 = c @ w2 + b2
+    u = leaky(pre2)
+    prob = softmax_pairs(u.reshape(cells, nbits, 2))
+    lb = loss_ber(prob, bits)
+    pr = prob.reshape(-1, 2)
+    ncls = pr.shape[0]
+    y = bits.reshape(-1).astype(np.int64)
+    g = softmax_pairs(pr)                       # d ce / d p = softmax(p) - onehot
+    g[np.arange(ncls), y] -= 1.0
+    g = g / dt.type(ncls)                       # mean
+    du = pr * (g - (g * pr).sum(axis=-1, keepdims=True))          # through the first softmax
+    du = du.reshape(cells, 2 * nbits)
+    dpre2 = du * np.where(pre2 > 0, dt.type(1.0), dt.type(LEAKY_ALPHA))
+    gW2 = c.T @ dpre2
+    gb2 = dpre2.sum(axis=0)
+    dc = dpre2 @ w2.T
+    dpre1 = dc[:, :m] * np.where(pre1 > 0, dt.type(1.0), dt.type(LEAKY_ALPHA))
+    gW1 = z.T @ dpre1
+    gb1 = dpre1.sum(axis=0)
+    dz = dpre1 @ w1.T + dc[:, m:]
+    out = dict(lb)
+    out.update(prob=prob, dz=dz, grads=dict(w1=gW1, b1=gb1, w2=gW2, b2=gb2), pre1=pre1, pre2=pre2)
+    return out
+
+
 def rx_forward_backward(p: Dict[str, np.ndarray], x_norm: np.ndarray, bits: np.ndarray,
                         cfg: RxConfig, need_dx: bool = False):
     """Forward + hand-derived backward of ce_mean + berlin*REG_COEFF*sum(reg)
@@ -348,30 +385,11 @@ def rx_forward_backward(p: Dict[str, np.ndarray], x_norm: np.ndarray, bits: np.n
     dt = x_norm.dtype
     Bf = x_norm.shape[0]
     prob4, t = rx_forward(p, x_norm, cfg, keep=True)
-    lb = loss_ber(prob4, bits)
-    pr = t["prob"].reshape(-1, 2)
-    ncls = pr.shape[0]
-    y = bits.reshape(-1).astype(np.int64)
-    # d ce / d p = softmax(p) - onehot, then / ncls for the mean
-    sp = softmax_pairs(pr)
-    g = sp.copy()
-    g[np.arange(ncls), y] -= 1.0
-    g = g / dt.type(ncls)
-    # through the first softmax
-    du = pr * (g - (g * pr).sum(axis=-1, keepdims=True))
-    du = du.reshape(Bf * cfg.D, 2 * cfg.nbits)
-    dpre2 = du * np.where(t["pre2"] > 0, dt.type(1.0), dt.type(LEAKY_ALPHA))
-    W2 = p["demodulation/dense_1/kernel"]
-    gW2 = t["c"].T @ dpre2
-    gb2 = dpre2.sum(axis=0)
-    dc = dpre2 @ W2.T
-    dh1 = dc[:, :cfg.m]
-    dpre1 = dh1 * np.where(t["pre1"] > 0, dt.type(1.0), dt.type(LEAKY_ALPHA))
-    W1 = p["demodulation/conv2d/kernel"]
-    gW1 = t["iq"].T @ dpre1
-    gb1 = dpre1.sum(axis=0)
-    diq = dpre1 @ W1.T + dc[:, cfg.m:]
-    dz = diq.reshape(Bf, 2 * cfg.D)
+    tl = tail_forward_backward(t["iq"], bits.reshape(Bf * cfg.D, cfg.nbits),
+                               p["demodulation/conv2d/kernel"], p["demodulation/conv2d/bias"],
+                               p["demodulation/dense_1/kernel"], p["demodulation/dense_1/bias"], cfg.nbits)
+    lb = {k: tl[k] for k in ("ce_mean", "conf", "berlin", "log_ber", "ce")}
+    dz = tl["dz"].reshape(Bf, 2 * cfg.D)
     Wd = p["demodulation/dense/kernel"]
     gWd = t["a"].T @ dz
     gbd = dz.sum(axis=0)
@@ -381,8 +399,8 @@ def rx_forward_backward(p: Dict[str, np.ndarray], x_norm: np.ndarray, bits: np.n
     grads = {
         "fft_like/conv3d/kernel": gWc, "fft_like/conv3d/bias": gbc,
         "demodulation/dense/kernel": gWd, "demodulation/dense/bias": gbd,
-        "demodulation/conv2d/kernel": gW1, "demodulation/conv2d/bias": gb1,
-        "demodulation/dense_1/kernel": gW2, "demodulation/dense_1/bias": gb2,
+        "demodulation/conv2d/kernel": tl["grads"]["w1"], "demodulation/conv2d/bias": tl["grads"]["b1"],
+        "demodulation/dense_1/kernel": tl["grads"]["w2"], "demodulation/dense_1/bias": tl["grads"]["b2"],
     }
     # + berlin * REG_COEFF * d/dw (0.01 * sum w^2)
     rs = lb["berlin"].astype(dt) * dt.type(REG_COEFF) * dt.type(2.0 * REG_L2)
@@ -395,6 +413,7 @@ def rx_forward_backward(p: Dict[str, np.ndarray], x_norm: np.ndarray, bits: np.n
     info["dz"] = dz
     info["dfft"] = dfft
     info["saved"] = t
+    info["pre1"], info["pre2"] = tl["pre1"], tl["pre2"]
     if need_dx:
         return grads, info, dx.reshape(x_norm.shape)
     return grads, info

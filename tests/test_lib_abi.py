@@ -1,0 +1,73 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/dccn.h declares
+(no compute calls here); host-side argument validation that needs no device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dl_ofdm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dccn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dccn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from dl_ofdm_amd import _lib
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libdccn.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_struct_sizes_match_header(lib):
+    from dl_ofdm_amd import _lib
+    assert C.sizeof(_lib.Metrics) == 64
+    assert C.sizeof(_lib.AdamState) == 16
+    assert C.sizeof(_lib.AdamHParams) == 24
+    assert C.sizeof(_lib.RxShape) == 24
+    assert C.sizeof(_lib.RxBuffers) == 18 * 8
+
+
+def test_host_side_queries(lib):
+    from dl_ofdm_amd import _lib
+    assert lib.dccn_version() >= 100
+    assert lib.dccn_strerror(0) == b"ok" and b"workspace" in lib.dccn_strerror(-2)
+    assert [lib.dccn_tail_param_count(b) for b in (1, 2, 3, 4)] == [16, 40, 90, 200]
+    assert lib.dccn_tail_param_count(5) < 0
+    sh = _lib.RxShape(1170, 7, 80, 64, 320, 2)
+    offs = (C.c_longlong * 6)()
+    assert lib.dccn_rx_param_offsets(C.byref(sh), offs) == 0
+    assert list(offs) == [0, 10240, 10368, 583808, 584448, 584488]        # 584 488 live params
+    assert lib.dccn_rx_workspace_size(C.byref(sh), 1) > lib.dccn_rx_workspace_size(C.byref(sh), 0) > 0
+    bad = _lib.RxShape(1170, 7, 80, 64, 320, 5)
+    assert lib.dccn_rx_param_offsets(C.byref(bad), offs) == -1
+    assert lib.dccn_rx_workspace_size(C.byref(bad), 1) == 0
+    # argument validation happens before any device work
+    assert lib.dccn_dense_fwd(None, None, None, None, 4, 4, 4, None) == -1
+    assert lib.dccn_cconv_gemm_fwd(None, None, None, None, 0, 80, 64, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from dl_ofdm_amd import _lib, ops
+    with pytest.raises(_lib.DccnError):
+        ops.batch_moment_norm(torch.zeros(4, 7, 80, 2))
+    with pytest.raises(_lib.DccnError):
+        ops.dense(torch.zeros(4, 8), torch.zeros(8, 8), None)
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    with pytest.raises(_lib.DccnError):
+        RxEngine(RxDims(7, 80, 64, 320, 2), 4, device="cpu")
