@@ -39,12 +39,90 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 
-// ---- wave / block reductions (wave64) -------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
+// ---- wave reductions (wave64) on the DPP crossbar: no LDS round trips ------------------------
+// quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror sums each 16-lane row
+// (fixed order => deterministic), then the four row sums are combined through v_readlane.
+// The result is returned in every lane.
+__device__ __forceinline__ int dpp_mov_i32(int v, const int ctrl_sel) {
+    switch (ctrl_sel) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;   // valid in lane 0
+    for (int s = 0; s < 4; ++s) v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), s));
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v += dpp_mov_i32(v, s);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = dpp_mov_i32((int)(b & 0xffffffffLL), s), hi = dpp_mov_i32((int)(b >> 32), s);
+        v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    }
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 16 * q);
+        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 16 * q);
+        r[q] = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int lo = dpp_mov_i32((int)(v & 0xffffffffLL), s), hi = dpp_mov_i32((int)(v >> 32), s);
+        v += ((long long)hi << 32) | (unsigned)lo;
+    }
+    long long r = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), 16 * q);
+        const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 16 * q);
+        r += ((long long)hi << 32) | (unsigned)lo;
+    }
+    return r;
+}
+
+// ---- "last block finalizes" hand-off (guide section 6, Guideline 16, counter form) -----------
+// Every block publishes its partial results with plain stores, then calls this.  Exactly one
+// block -- the last to arrive -- gets `true`, with every other block's stores visible to it
+// (agent-scope release on the producers, agent-scope acquire on the consumer; placement
+// independent).  The counter must be zero at kernel start (the launch sequence memsets its
+// counter words); the last block re-zeroes it, so back-to-back replays stay consistent.
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned expected) {
+    __shared__ int s_is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left the CU
+    __syncthreads();
+    const bool leader = (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0);
+    if (leader) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (prev == expected - 1u);
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_is_last = last;
+    }
+    __syncthreads();
+    return s_is_last != 0;
 }
 
 }  // namespace dccn

@@ -37,33 +37,36 @@ static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
 static size_t norm_ws_bytes(int batch, int cols) {
     size_t o = 0;
     o = carve_size(o, (size_t)kNormRowChunks * cols * 2 * sizeof(double));
-    o = carve_size(o, (size_t)cols * sizeof(float2));
     o = carve_size(o, (size_t)norm_grid_x(cols) * norm_grid_y(batch) * sizeof(double));
     return align_up(o, 256);
 }
 
-// power_out nullable -> R8 skipped
-static int norm_impl(const float* x, float* y, float* mean, float* var, float* power_out, int batch, int cols,
-                     float eps, float peak, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!x || !y || batch <= 0 || cols <= 0 || (power_out && (cols & 1))) return DCCN_ERR_INVALID_ARG;
+struct PowerPartials {      // where normalise left the R8 partial sums (finished by a later kernel)
+    const double* partial;
+    int n;
+    double denom;
+};
+
+// want_power: also emit the per-block partial sums of the clipped power (R8); adam != nullptr: the
+// optimizer bookkeeping of the fused training step rides on the first kernel
+static int norm_impl(const float* x, float* y, float* mean, float* var, bool want_power, PowerPartials* pp, int batch,
+                     int cols, float eps, float peak, dccn_adam_state* adam, dccn_adam_hparams hp, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+    if (!x || !y || batch <= 0 || cols <= 0 || (want_power && (cols & 1))) return DCCN_ERR_INVALID_ARG;
     if (ws_bytes < norm_ws_bytes(batch, cols) || !ws) return DCCN_ERR_WORKSPACE;
     Carver c(ws, ws_bytes);
     double* partial = c.take<double>((size_t)kNormRowChunks * cols * 2);
-    float2* stats = c.take<float2>(cols);
     const int gx = norm_grid_x(cols), gy = norm_grid_y(batch);
     double* pw = c.take<double>((size_t)gx * gy);
-    hipLaunchKernelGGL(moments_partial_kernel, dim3(gx, kNormRowChunks), dim3(64, 4), 0, s, x, batch, cols, partial);
+    hipLaunchKernelGGL(moments_kernel, dim3(gx, kNormRowChunks), dim3(64, 4), 0, s, x, batch, cols, partial, adam, hp);
     DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, s, partial, batch, cols,
-                       eps, stats, mean, var);
+    hipLaunchKernelGGL(normalise_kernel, dim3(gx, gy), dim3(64, 4), 0, s, x, y, partial, batch, cols, eps, peak,
+                       want_power ? pw : nullptr, mean, var);
     DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(normalise_kernel, dim3(gx, gy), dim3(64, 4), 0, s, x, y, stats, batch, cols, peak,
-                       power_out ? pw : nullptr);
-    DCCN_LAUNCH_CHECK();
-    if (power_out) {
-        const double denom = (double)batch * (double)(cols / 2);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, pw, gx * gy, denom, power_out);
-        DCCN_LAUNCH_CHECK();
+    if (pp) {
+        pp->partial = pw;
+        pp->n = gx * gy;
+        pp->denom = (double)batch * (double)(cols / 2);
     }
     return DCCN_OK;
 }
@@ -76,7 +79,7 @@ static GemmParams gp_zero() {
     memset(&p, 0, sizeof(p));
     return p;
 }
-static int round_k(int K) { return ceil_div(K, kBK) * kBK; }
+static int round_k(int K) { return ceil_div(K, 64) * 64; }
 
 static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                           hipStream_t s) {
@@ -86,8 +89,8 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.M = M; p.N = N; p.K = K;
     p.lda = K; p.ldb = N; p.ldc = N;
     p.klen = round_k(K);
-    p.vecA = (K % 4 == 0) && aligned16(x);
-    p.vecB = (N % 4 == 0) && aligned16(w);
+    p.vecA = (K % 4 == 0) && aligned16(x);                 // KCONTIG: ld = K, k extent K
+    p.vecB = (N % 4 == 0) && aligned16(w);                 // ICONTIG: ld = N, i extent N
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 
@@ -111,8 +114,14 @@ static size_t splitk_ws_bytes(int Mo, int No, int Kr) {
     return align_up(o, 256);
 }
 
+// defer != nullptr: leave the split-K slabs un-reduced (the fused Adam kernel sums them) and report them
+struct DeferredSlabs {
+    const float* dw_slabs;
+    const float* db_slabs;
+    int splits;
+};
 static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
-                            size_t ws_bytes, hipStream_t s) {
+                            size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr) {
     if (!x || !dy || !dw || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
     const SplitPlan sp = plan_splitk(K, N, M);
@@ -127,6 +136,7 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     p.slab = (long long)K * N;
     p.vecA = (K % 4 == 0) && aligned16(x);
     p.vecB = (N % 4 == 0) && aligned16(dy);
+    if (defer) { defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1; }
     if (sp.splits == 1) {
         p.C = dw;
         p.colsum = dbias;
@@ -135,15 +145,15 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     p.C = slabs;
     p.colsum = dbias ? cs : nullptr;
     DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
-    const long long n = (long long)K * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(ceil_div_ll(n, 4), 256)), dim3(256), 0, s,
-                       slabs, sp.splits, n, dw, n);
-    DCCN_LAUNCH_CHECK();
-    if (dbias) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div_ll(ceil_div_ll(N, 4), 256)), dim3(256), 0, s,
-                           cs, sp.splits, (long long)N, dbias, (long long)N);
-        DCCN_LAUNCH_CHECK();
+    if (defer) {
+        defer->dw_slabs = slabs;
+        defer->db_slabs = dbias ? cs : nullptr;
+        defer->splits = sp.splits;
+        return DCCN_OK;
     }
+    const long long n = (long long)K * N;
+    DCCN_TRY(launch_splitk_reduce(slabs, sp.splits, n, dw, n, s));
+    if (dbias) DCCN_TRY(launch_splitk_reduce(cs, sp.splits, (long long)N, dbias, (long long)N, s));
     return DCCN_OK;
 }
 
@@ -190,7 +200,7 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     p.vecB = (F % 2 == 0) && aligned16(dout);
     DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     const int nthreads = kin * F + F;
-    hipLaunchKernelGGL(cconv_fold_kernel, dim3(ceil_div(nthreads, 256)), dim3(256), 0, s, slabs, sp.splits, p.slab,
+    hipLaunchKernelGGL(cconv_fold_kernel, dim3(ceil_div(nthreads, kRedLanes)), dim3(256), 0, s, slabs, sp.splits, p.slab,
                        cs, dw, dbias, kin, F);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -213,6 +223,7 @@ static size_t tail_ws_bytes(long long cells, int nbits) {
     return align_up(o, 256);
 }
 
+
 template <int NB>
 static int tail_launch(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob, float* dz,
                        long long cells, int nblk, TailBlockMetrics* bm, float* bg, hipStream_t s) {
@@ -226,9 +237,10 @@ static int tail_launch(bool bwd, const float* z, const int32_t* bits, const floa
     return DCCN_OK;
 }
 
+// pp/power_out: optional R8 finish riding on the slab-reduction kernel (fused receiver step)
 static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob,
-                     dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits, void* ws,
-                     size_t ws_bytes, hipStream_t s) {
+                     dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits,
+                     const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!z || !bits || !tailp || !metrics || cells <= 0 || nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < tail_ws_bytes(cells, nbits)) return DCCN_ERR_WORKSPACE;
@@ -244,8 +256,11 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
         case 4: st = tail_launch<4>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
     }
     DCCN_TRY(st);
-    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(1), dim3(256), 0, s, bm, bwd ? bg : nullptr, nblk,
-                       tail_param_count(nbits), cells * nbits, metrics, bwd ? dtailp : nullptr);
+    const int P = bwd ? tail_param_count(nbits) : 0;
+    const bool pw = pp != nullptr && power_out != nullptr;
+    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(ceil_div(P + 2, 4)), dim3(256), 0, s, bm, bwd ? bg : nullptr,
+                       nblk, P, cells * nbits, metrics, bwd ? dtailp : nullptr, pw ? pp->partial : nullptr,
+                       pw ? pp->n : 0, pw ? pp->denom : 1.0, pw ? power_out : nullptr);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -328,16 +343,17 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     float* P = b->params;
     float* G = b->grads;
 
-    // R0 (+R8)
-    DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power, sh->batch, L.cols, 1e-9f, 8.0f, ws_norm,
-                       L.ws_norm, s));
+    // R0 (+R8 partial sums; + the optimizer's per-step bookkeeping when training)
+    PowerPartials pp;
+    DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, sh->batch, L.cols, 1e-9f, 8.0f,
+                       train ? b->adam : nullptr, hp, ws_norm, L.ws_norm, s));
     // R1
     DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     // R2
     DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
     // R3-R6 (+ tail backward)
     DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
-                       L.cells, sh->nbits, ws_tail, L.ws_tail, s));
+                       L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s));
     if (!train) return DCCN_OK;
 
     hipStream_t sw = s;
@@ -347,17 +363,31 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         sw = side;
     }
     // dense dW/db  (independent of dX)
+    DeferredSlabs ds;
     DCCN_TRY(dense_bwd_w_impl(b->fft_out, b->dz, G + L.o_dense_w, G + L.o_dense_b, sh->batch, L.dK, L.dN, ws_dbw,
-                              L.ws_dense_bw, sw));
+                              L.ws_dense_bw, sw, &ds));
     if (side) DCCN_HIP(hipEventRecord(ev_join, side));
     // dense dX -> C-Conv dW/db (the C-Conv input is data: no dX needed)
     DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
     DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                               L.ws_conv_bw, s));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    // R7 (+ BER-gated L2 term of R6)
-    DCCN_TRY(adam_impl(P, G, b->adam_m, b->adam_v, b->reg_coef, b->reg_coef ? &b->metrics->berlin : nullptr, b->adam,
-                       hp, L.total, s));
+    // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
+    AdamRxArgs aa;
+    aa.param = P; aa.grad = G; aa.m = b->adam_m; aa.v = b->adam_v;
+    aa.reg_coef = b->reg_coef; aa.reg_gate = b->reg_coef ? &b->metrics->berlin : nullptr;
+    aa.state = b->adam; aa.n = L.total;
+    aa.dw_slabs = ds.dw_slabs; aa.db_slabs = ds.db_slabs; aa.splits = ds.splits;
+    aa.o_dw = L.o_dense_w; aa.n_dw = (long long)L.dK * L.dN; aa.o_db = L.o_dense_b; aa.n_db = L.dN;
+    long long blocks = ceil_div_ll(ceil_div_ll(L.total, 4), 256);
+    if (blocks > 8 * kCUs) blocks = 8 * kCUs;
+    switch (ds.splits) {
+        case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+        case 3: hipLaunchKernelGGL(adam_rx_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+        case 4: hipLaunchKernelGGL(adam_rx_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+        default: hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+    }
+    DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 
@@ -417,7 +447,9 @@ size_t dccn_batch_moment_norm_workspace_size(int batch, int cols) {
 }
 int dccn_batch_moment_norm_fwd(const float* x, float* y, float* mean, float* var, int batch, int cols, float eps,
                                void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    return norm_impl(x, y, mean, var, nullptr, batch, cols, eps, 8.0f, workspace, workspace_bytes,
+    dccn_adam_hparams hp;
+    memset(&hp, 0, sizeof(hp));
+    return norm_impl(x, y, mean, var, false, nullptr, batch, cols, eps, 8.0f, nullptr, hp, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }
 
@@ -485,14 +517,14 @@ size_t dccn_demod_tail_workspace_size(long long cells, int nbits) {
 int dccn_demod_tail_loss_fwd(const float* z, const int32_t* bits, const float* tailp, float* prob,
                              dccn_metrics* metrics, long long cells, int nbits, void* workspace,
                              size_t workspace_bytes, dccn_stream_t stream) {
-    return tail_impl(false, z, bits, tailp, prob, metrics, nullptr, nullptr, cells, nbits, workspace, workspace_bytes,
-                     (hipStream_t)stream);
+    return tail_impl(false, z, bits, tailp, prob, metrics, nullptr, nullptr, cells, nbits, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream);
 }
 int dccn_demod_tail_loss_fwd_bwd(const float* z, const int32_t* bits, const float* tailp, float* prob,
                                  dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits,
                                  void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    return tail_impl(true, z, bits, tailp, prob, metrics, dz, dtailp, cells, nbits, workspace, workspace_bytes,
-                     (hipStream_t)stream);
+    return tail_impl(true, z, bits, tailp, prob, metrics, dz, dtailp, cells, nbits, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream);
 }
 
 int dccn_adam_tf_step(float* param, const float* grad, float* m, float* v, const float* reg_coef,

@@ -9,12 +9,27 @@ namespace dccn {
 constexpr int kNormRowChunks = 32;      // partial-moment slabs per column
 constexpr int kNormRowsPerBlock = 32;   // rows handled by one normalise block
 
+__device__ __forceinline__ float adam_alpha(const dccn_adam_state* st, const dccn_adam_hparams& hp) {
+    const float lr = hp.lr0 * powf(hp.decay_rate, floorf(st->global_step / hp.decay_steps));
+    return lr * sqrtf(1.0f - st->beta2_power) / (1.0f - st->beta1_power);
+}
+
 // ---- R0 stage 1: per-column partial sum / sum of squares in fp64 ------------------------
 // grid (ceil(cols/4/64), kNormRowChunks), block (64,4).  partial[(chunk*cols + c)*2 + {0,1}]
-__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int batch, int cols,
-                                                              double* __restrict__ partial) {
+// In the fused training step the first thread of the first block also does the optimizer's
+// per-step bookkeeping (it runs long before the Adam kernel of this step and after the one of the
+// previous step): alpha for THIS step from the current global_step / beta powers, then advance them.
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int batch, int cols,
+                                                      double* __restrict__ partial,
+                                                      dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp) {
     __shared__ double red[4][64][8];
     const int tx = threadIdx.x, ty = threadIdx.y;
+    if (adam != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tx == 0 && ty == 0) {
+        adam->alpha = adam_alpha(adam, hp);
+        adam->beta1_power = adam->beta1_power * hp.beta1;
+        adam->beta2_power = adam->beta2_power * hp.beta2;
+        adam->global_step = adam->global_step + 1.0f;
+    }
     const int c4 = (blockIdx.x * 64 + tx) * 4;
     const int rows_per_chunk = (batch + kNormRowChunks - 1) / kNormRowChunks;
     const int r0 = blockIdx.y * rows_per_chunk;
@@ -22,6 +37,7 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (c4 < cols) {
         const bool vec = (c4 + 3 < cols) && ((cols & 3) == 0);
+#pragma unroll 4
         for (int r = r0 + ty; r < r1; r += 4) {
             const float* p = x + (size_t)r * cols + c4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -50,8 +66,8 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (c4 + e < cols) {
-                const double ss = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
-                const double qq = red[0][tx][4 + e] + red[1][tx][4 + e] + red[2][tx][4 + e] + red[3][tx][4 + e];
+                const double ss = (red[0][tx][e] + red[1][tx][e]) + (red[2][tx][e] + red[3][tx][e]);
+                const double qq = (red[0][tx][4 + e] + red[1][tx][4 + e]) + (red[2][tx][4 + e] + red[3][tx][4 + e]);
                 double* o = partial + ((size_t)blockIdx.y * cols + c4 + e) * 2;
                 o[0] = ss;
                 o[1] = qq;
@@ -60,38 +76,43 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
     }
 }
 
-// ---- R0 stage 2: combine the slabs -> mean, inv = rsqrt(var+eps), shift = -mean*inv ------
-// stats[c] = {inv, shift}; optional mean/var outputs (tf.nn.moments values)
-__global__ __launch_bounds__(256) void moments_finalize_kernel(const double* __restrict__ partial, int batch,
-                                                               int cols, float eps, float2* __restrict__ stats,
-                                                               float* __restrict__ mean_out,
-                                                               float* __restrict__ var_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    double s = 0.0, q = 0.0;
-    for (int z = 0; z < kNormRowChunks; ++z) {
-        const double* p = partial + ((size_t)z * cols + c) * 2;
-        s += p[0];
-        q += p[1];
-    }
-    const double mean = s / (double)batch;
-    double var = q / (double)batch - mean * mean;      // biased variance, fp64: no cancellation issue
-    if (var < 0.0) var = 0.0;
-    const float meanf = (float)mean, varf = (float)var;
-    const float inv = 1.0f / sqrtf(varf + eps);
-    stats[c] = make_float2(inv, -meanf * inv);
-    if (mean_out) mean_out[c] = meanf;
-    if (var_out) var_out[c] = varf;
-}
-
-// ---- R0 stage 3: y = (x*inv + shift)/sqrt(2)  (+ R8: partial sums of the clipped power) --
+// ---- R0 stage 2+3: combine the slabs (each block for its own 256 columns: mean, inv = rsqrt(var+eps),
+// shift = -mean*inv), then y = (x*inv + shift)/sqrt(2)   (+ R8: per-block partial sums of the clipped power)
 // grid (ceil(cols/4/64), ceil(batch/kNormRowsPerBlock)), block (64,4)
 // power_partial[blockIdx.y*gridDim.x + blockIdx.x] = sum over the block of |clip(y)|^2 (fp64)
 __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                        const float2* __restrict__ stats, int batch, int cols,
-                                                        float peak, double* __restrict__ power_partial) {
+                                                        const double* __restrict__ partial, int batch, int cols,
+                                                        float eps, float peak, double* __restrict__ power_partial,
+                                                        float* __restrict__ mean_out, float* __restrict__ var_out) {
+    __shared__ float2 sstat[256];
     __shared__ double red[4];
     const int tx = threadIdx.x, ty = threadIdx.y;
+    const int lin = ty * 64 + tx;
+    {
+        const int c = blockIdx.x * 256 + lin;
+        float2 st = make_float2(0.f, 0.f);
+        if (c < cols) {
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int z = 0; z < kNormRowChunks; ++z) {
+                const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)z * cols + c) * 2);
+                sm += v.x;
+                sq += v.y;
+            }
+            const double mean = sm / (double)batch;
+            double var = sq / (double)batch - mean * mean;    // biased variance; fp64, so no cancellation issue
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)mean, varf = (float)var;
+            const float inv = 1.0f / sqrtf(varf + eps);
+            st = make_float2(inv, -meanf * inv);
+            if (blockIdx.y == 0) {
+                if (mean_out) mean_out[c] = meanf;
+                if (var_out) var_out[c] = varf;
+            }
+        }
+        sstat[lin] = st;
+    }
+    __syncthreads();
     const int c4 = (blockIdx.x * 64 + tx) * 4;
     const int r0 = blockIdx.y * kNormRowsPerBlock;
     const int r1 = min(batch, r0 + kNormRowsPerBlock);
@@ -102,10 +123,11 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
         float inv[4], sh[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float2 st = (c4 + e < cols) ? stats[c4 + e] : make_float2(0.f, 0.f);
+            const float2 st = sstat[tx * 4 + e];
             inv[e] = st.x;
             sh[e] = st.y;
         }
+#pragma unroll 8
         for (int r = r0 + ty; r < r1; r += 4) {
             const size_t off = (size_t)r * cols + c4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -141,10 +163,9 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
     }
     if (power_partial != nullptr) {
         pw = wave_sum(pw);
-        const int lin = ty * 64 + tx;
         if ((lin & 63) == 0) red[lin >> 6] = pw;
         __syncthreads();
-        if (lin == 0) power_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (lin == 0) power_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -242,6 +263,103 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ par
                 m[j] = mj;
                 v[j] = vj;
             }
+        }
+    }
+}
+
+
+// ---- R7 fused into the receiver step: one launch does the split-K reduction of the dense weight
+// gradient and the Adam update over the whole arena.  alpha comes from the optimizer state, which the
+// first kernel of the step (moments_kernel) has already advanced. ----
+struct AdamRxArgs {
+    float* param; float* grad; float* m; float* v;
+    const float* reg_coef; const float* reg_gate;
+    const dccn_adam_state* state;
+    long long n;
+    // dense kernel / bias gradient still in split-K slabs (splits > 1), else nullptr
+    const float* dw_slabs; const float* db_slabs;
+    int splits;
+    long long o_dw, n_dw, o_db, n_db;      // arena segments of dense kernel / bias
+};
+
+template <int SPLITS>     // 0: runtime count
+__global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const dccn_adam_hparams hp) {
+    const float alpha = a.state->alpha;
+    const float gate = a.reg_gate ? a.reg_gate[0] : 1.0f;
+    const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
+    const bool seg4 = ((a.o_dw | a.n_dw | a.o_db | a.n_db) & 3) == 0;
+    const int splits = SPLITS > 0 ? SPLITS : a.splits;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < a.n; i += stride) {
+        const int cnt = (int)((a.n - i) < 4 ? (a.n - i) : 4);
+        float g[4] = {0.f, 0.f, 0.f, 0.f}, p[4], mm[4], vv[4], cc[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = cnt == 4;
+        // everything this element needs is requested up front (independent loads), summed afterwards
+        float4 p4, m4, v4, c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (full) {
+            p4 = *reinterpret_cast<const float4*>(a.param + i);
+            m4 = *reinterpret_cast<const float4*>(a.m + i);
+            v4 = *reinterpret_cast<const float4*>(a.v + i);
+            if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + i);
+        }
+        // ---- gradient: plain arena, or the fixed-order sum of the split-K slabs ----
+        if (full && seg4 && a.dw_slabs && i >= a.o_dw && i < a.o_dw + a.n_dw) {
+            const float* q = a.dw_slabs + (i - a.o_dw);
+            float4 s = *reinterpret_cast<const float4*>(q);
+#pragma unroll
+            for (int z = 1; z < splits; ++z) {
+                const float4 t = *reinterpret_cast<const float4*>(q + (size_t)z * a.n_dw);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            g[0] = s.x; g[1] = s.y; g[2] = s.z; g[3] = s.w;
+            *reinterpret_cast<float4*>(a.grad + i) = s;
+        } else if (full && !(a.dw_slabs && i < a.o_dw + a.n_dw && i + 4 > a.o_dw) &&
+                   !(a.db_slabs && i < a.o_db + a.n_db && i + 4 > a.o_db)) {
+            const float4 s = *reinterpret_cast<const float4*>(a.grad + i);
+            g[0] = s.x; g[1] = s.y; g[2] = s.z; g[3] = s.w;
+        } else {
+            for (int e = 0; e < cnt; ++e) {
+                const long long j = i + e;
+                float t;
+                if (a.dw_slabs && j >= a.o_dw && j < a.o_dw + a.n_dw) {
+                    t = 0.f;
+                    for (int z = 0; z < splits; ++z) t += a.dw_slabs[(size_t)z * a.n_dw + (j - a.o_dw)];
+                    a.grad[j] = t;
+                } else if (a.db_slabs && j >= a.o_db && j < a.o_db + a.n_db) {
+                    t = 0.f;
+                    for (int z = 0; z < splits; ++z) t += a.db_slabs[(size_t)z * a.n_db + (j - a.o_db)];
+                    a.grad[j] = t;
+                } else {
+                    t = a.grad[j];
+                }
+                g[e] = t;
+            }
+        }
+        if (full) {
+            p[0] = p4.x; p[1] = p4.y; p[2] = p4.z; p[3] = p4.w;
+            mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+            cc[0] = c4.x; cc[1] = c4.y; cc[2] = c4.z; cc[3] = c4.w;
+        } else {
+            for (int e = 0; e < 4; ++e) {
+                const bool in = e < cnt;
+                p[e] = in ? a.param[i + e] : 0.f; mm[e] = in ? a.m[i + e] : 0.f; vv[e] = in ? a.v[i + e] : 0.f;
+                cc[e] = (in && a.reg_coef) ? a.reg_coef[i + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = g[e] + (gate * cc[e]) * p[e];
+            mm[e] += (ge - mm[e]) * omb1;
+            vv[e] += (ge * ge - vv[e]) * omb2;
+            p[e] -= (mm[e] * alpha) / (sqrtf(vv[e]) + hp.eps);
+        }
+        if (full) {
+            *reinterpret_cast<float4*>(a.param + i) = make_float4(p[0], p[1], p[2], p[3]);
+            *reinterpret_cast<float4*>(a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            for (int e = 0; e < cnt; ++e) { a.param[i + e] = p[e]; a.m[i + e] = mm[e]; a.v[i + e] = vv[e]; }
         }
     }
 }

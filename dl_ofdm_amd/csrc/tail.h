@@ -4,10 +4,11 @@
 // of that tail in the same pass (the loss scale 1/count is known before the launch, so no
 // second sweep over the activations is needed).
 //
-// One thread owns one data cell at a time (grid-stride); the ~40-200 tail weights are read
-// through uniform (scalar-cache) loads; per-thread gradient/metric accumulators are reduced
-// wave -> block -> per-block slab, and a single-block finalize kernel sums the slabs in a
-// fixed order, so every output is deterministic.
+// One block per CU; a thread walks its cells with a grid stride, prefetching the next cell's
+// inputs before it evaluates the current one (one wave per SIMD has no other latency hiding).
+// The ~40-200 tail weights are read through uniform (scalar-cache) loads.  Per-thread gradient /
+// metric accumulators are reduced wave (DPP) -> block (LDS) -> per-block slab; a small second
+// kernel sums the slabs with one wave per output in a fixed order, so everything is deterministic.
 #pragma once
 #include "common.h"
 
@@ -27,6 +28,23 @@ struct TailBlockMetrics {      // one per block in the workspace
     double ce_sum;
     long long conf[4];
 };
+
+template <int NB>
+struct TailCellIn {
+    float2 z;
+    int lab[NB];
+};
+
+template <int NB>
+__device__ __forceinline__ TailCellIn<NB> tail_load_cell(const float* __restrict__ z, const int32_t* __restrict__ bits,
+                                                         long long cell, long long cells) {
+    TailCellIn<NB> c;
+    const long long cc = cell < cells ? cell : cells - 1;        // clamped: the load is always legal
+    c.z = *reinterpret_cast<const float2*>(z + 2 * cc);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) c.lab[j] = bits[cc * NB + j];
+    return c;
+}
 
 template <int NB, bool BWD>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
@@ -50,12 +68,14 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     }
     double ce_acc = 0.0;
     int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-    const float count_f = (float)(cells * NB);
+    const float inv_count = 1.0f / (float)(cells * NB);
 
     const long long stride = (long long)gridDim.x * kTailThreads;
-    for (long long cell = (long long)blockIdx.x * kTailThreads + threadIdx.x; cell < cells; cell += stride) {
-        const float2 zz = *reinterpret_cast<const float2*>(z + 2 * cell);
-        const float z0 = zz.x, z1 = zz.y;
+    long long cell = (long long)blockIdx.x * kTailThreads + threadIdx.x;
+    TailCellIn<NB> cur = tail_load_cell<NB>(z, bits, cell, cells);
+    while (cell < cells) {
+        const TailCellIn<NB> nxt = tail_load_cell<NB>(z, bits, cell + stride, cells);     // prefetch
+        const float z0 = cur.z.x, z1 = cur.z.y;
         float c[M + 2], pre1[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -82,7 +102,7 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
             const float p0 = e0 / es, p1 = e1 / es;
             if (prob != nullptr)
                 *reinterpret_cast<float2*>(prob + (cell * NB + j) * 2) = make_float2(p0, p1);
-            const int label = bits[cell * NB + j];
+            const int label = cur.lab[j];
             // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
             const float mx2 = fmaxf(p0, p1);
             const float f0 = expf(p0 - mx2), f1 = expf(p1 - mx2);
@@ -93,9 +113,10 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
             if (label == 0) { if (pred == 0) ++c00; else ++c01; }
             else            { if (pred == 0) ++c10; else ++c11; }
             if constexpr (BWD) {
-                const float q0 = f0 / fs, q1 = f1 / fs;
-                const float g0 = (q0 - (label ? 0.f : 1.f)) / count_f;
-                const float g1 = (q1 - (label ? 1.f : 0.f)) / count_f;
+                const float rfs = 1.0f / fs;
+                const float q0 = f0 * rfs, q1 = f1 * rfs;
+                const float g0 = (q0 - (label ? 0.f : 1.f)) * inv_count;
+                const float g1 = (q1 - (label ? 1.f : 0.f)) * inv_count;
                 const float dot = g0 * p0 + g1 * p1;
                 const float du0 = p0 * (g0 - dot), du1 = p1 * (g1 - dot);
                 dpre2[2 * j] = du0 * (pre2[2 * j] > 0.f ? 1.f : kLeaky);
@@ -128,9 +149,11 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
             }
             *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
         }
+        cur = nxt;
+        cell += stride;
     }
 
-    // ---- block reduction ------------------------------------------------------------
+    // ---- block reduction: DPP within the wave, LDS across the four waves ----------------------
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     ce_acc = wave_sum(ce_acc);
     c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         TailBlockMetrics bm;
-        bm.ce_sum = sce[0] + sce[1] + sce[2] + sce[3];
+        bm.ce_sum = (sce[0] + sce[1]) + (sce[2] + sce[3]);
         for (int k = 0; k < 4; ++k)
             bm.conf[k] = (long long)sconf[0][k] + sconf[1][k] + sconf[2][k] + sconf[3][k];
         blk_metrics[blockIdx.x] = bm;
@@ -159,34 +182,59 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     }
 }
 
-// single block: metrics + (optional) gradient slabs -> final values, fixed order
+// Slab reduction: wave g < P sums gradient column g over the per-block slabs (lane l owns slabs
+// l, l+64, l+128, l+192), wave g == P builds the metrics record, wave g == P+1 (fused receiver step
+// only) finishes the mean clipped power of R8 from the normalise kernel's per-block partial sums.
+// grid = ceil((P+2)/4) blocks.
 __global__ __launch_bounds__(256) void demod_tail_finalize_kernel(const TailBlockMetrics* __restrict__ blk_metrics,
                                                                   const float* __restrict__ blk_grads, int nblocks,
                                                                   int P, long long count,
                                                                   dccn_metrics* __restrict__ metrics,
-                                                                  float* __restrict__ dtailp) {
-    if (blk_grads != nullptr && dtailp != nullptr) {
-        for (int i = threadIdx.x; i < P; i += 256) {
-            float s = 0.f;
-            for (int b = 0; b < nblocks; ++b) s += blk_grads[(size_t)b * P + i];
-            dtailp[i] = s;
+                                                                  float* __restrict__ dtailp,
+                                                                  const double* __restrict__ power_partial,
+                                                                  int n_power, double power_denom,
+                                                                  float* __restrict__ power_out) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g < P) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = lane + 64 * q;
+            v[q] = (b < nblocks) ? blk_grads[(size_t)b * P + g] : 0.f;
         }
-    }
-    if (threadIdx.x == 0) {
+        const float s = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+        if (lane == 0) dtailp[g] = s;
+    } else if (g == P) {
         double ce = 0.0;
         long long cf[4] = {0, 0, 0, 0};
-        for (int b = 0; b < nblocks; ++b) {
-            ce += blk_metrics[b].ce_sum;
-            for (int k = 0; k < 4; ++k) cf[k] += blk_metrics[b].conf[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = lane + 64 * q;
+            if (b < nblocks) {
+                ce += blk_metrics[b].ce_sum;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cf[k] += blk_metrics[b].conf[k];
+            }
         }
-        metrics->ce_sum = ce;
-        for (int k = 0; k < 4; ++k) metrics->conf[k] = cf[k];
-        metrics->count = count;
-        metrics->ce_mean = (float)(ce / (double)count);
-        const double ber = (double)(cf[1] + cf[2]) / (double)(cf[0] + cf[1] + cf[2] + cf[3]);
-        metrics->berlin = (float)ber;
-        metrics->log_ber = (float)log(ber);
-        metrics->reserved = 0.f;
+        ce = wave_sum(ce);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cf[k] = wave_sum(cf[k]);
+        if (lane == 0) {
+            metrics->ce_sum = ce;
+            for (int k = 0; k < 4; ++k) metrics->conf[k] = cf[k];
+            metrics->count = count;
+            metrics->ce_mean = (float)(ce / (double)count);
+            const double ber = (double)(cf[1] + cf[2]) / (double)(cf[0] + cf[1] + cf[2] + cf[3]);
+            metrics->berlin = (float)ber;
+            metrics->log_ber = (float)log(ber);
+            metrics->reserved = 0.f;
+        }
+    } else if (g == P + 1 && power_out != nullptr) {
+        double s = 0.0;
+        for (int i = lane; i < n_power; i += 64) s += power_partial[i];
+        s = wave_sum(s);
+        if (lane == 0) power_out[0] = (float)(s / power_denom);
     }
 }
 

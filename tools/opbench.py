@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Launch one operator of the receiver step repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
+
+    python tools/opbench.py dense_fwd --iters 50 [--config c2]
+Prints the HIP-event average per launch."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import bench
+    from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine, op_launchers
+    ap = argparse.ArgumentParser()
+    ap.add_argument("ops", nargs="+")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--config", default="c2")
+    args = ap.parse_args()
+    c = bench.CONFIGS[args.config]
+    dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
+    eng = RxEngine(dims, c["frames"], train=True)
+    eng.x.normal_()
+    eng.bits.random_(0, 2)
+    eng.train_step()
+    torch.cuda.synchronize()
+    ops = op_launchers(eng)
+    t = HipTimer()
+    for name in args.ops:
+        fn = ops[name][0]
+        for _ in range(5):
+            fn()
+        t.start(eng._stream())
+        for _ in range(args.iters):
+            fn()
+        t.stop(eng._stream())
+        print("%s: %.2f us/launch" % (name, t.elapsed_ms() * 1e3 / args.iters))
+
+
+if __name__ == "__main__":
+    main()
