@@ -1,0 +1,138 @@
+"""DCCN model topology -- host-side mirror of dev/py/model.py for the hot path.
+
+``ofdm_dense_rx`` (model.py:1222-1292) keeps the reference's signature; variables live in a
+:class:`~dl_ofdm_amd.complex.VariableStore` under the reference's checkpoint names
+(``fft_like/conv3d/{kernel,bias}``, ``demodulation/dense/...``, ``demodulation/conv2d/...``,
+``demodulation/dense_1/...``).  This composable (autograd) path and the fused
+:class:`~dl_ofdm_amd.engine.RxEngine` run the same kernels; the engine merely launches them as one
+pre-planned sequence over flat arenas.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .complex import VariableStore, complex_clip, layers_conv2d_complex
+from .engine import PARAM_NAMES, RxDims
+
+# graph tensor names the reference's loaders fetch (model.py:58-71) -> what provides them here
+TENSOR_NAMES = ("bits_in:0", "tx_ofdm:0", "SNR:0", "input:0", "output:0", "cost:0", "ce_mean:0", "log_ber:0",
+                "linear_ber:0", "conf_matrix:0", "tx_signal:0", "tx_power:0", "noise_power:0", "iq_rx:0", "iq_tx:0",
+                "receiver/fft_like/fft_out:0")
+
+
+def layers_dense(inputs: torch.Tensor, units: int, *, scope: VariableStore) -> torch.Tensor:
+    """tf.layers.dense (no activation): glorot-uniform kernel [in, units], zero bias."""
+    name = scope.layer_name("dense")
+    k_in = inputs.shape[-1]
+    w = scope.get(name + "/kernel", (k_in, units), fan_in=k_in, fan_out=units)
+    b = scope.get(name + "/bias", (units,), zeros=True)
+    return ops.dense(inputs, w, b)
+
+
+def ofdm_dense_rx(inputs: torch.Tensor, FLAGS, ofdmobj, outshape=None, *, scope: VariableStore,
+                  bits: Optional[torch.Tensor] = None):
+    """Basic DCCN receiver (model.py:1222-1292): C-Conv "fft_like" -> dense -> per-cell 1x1 conv ->
+    leaky-ReLU -> concat -> dense -> leaky-ReLU -> softmax over bit pairs.
+
+    inputs [batch, n_sym, n_sc, 2] (already normalised, `input:0`); outshape [-1, frame_size, nbits, 2].
+    Returns the probabilities [batch, frame_size, nbits, 2] -- and, when ``bits`` (int32
+    [batch, frame_size, nbits]) is given, ``(prob, ce_mean, metrics_buf, fft_out)`` with ``ce_mean``
+    differentiable (the tail, its loss and its backward are one fused kernel)."""
+    _, n_sym, n_sc, m_iq = inputs.shape
+    n_filters = FLAGS.nfilter
+    CP = ofdmobj.CP
+    out = inputs
+    if not FLAGS.cp:                                           # remove the cyclic prefix (:1236-1240)
+        K = ofdmobj.K
+        out = out[:, :, CP:CP + K, :]
+    else:
+        K = n_sc
+    _, data_ofdm, nbits, nllr = outshape
+    data_ofdm, nbits, nllr = int(data_ofdm), int(nbits), int(nllr)
+    assert nllr == 2 and m_iq == 2
+
+    with scope.scope("fft_like"):                               # layer 1: learned DFT replacement (:1246-1264)
+        conv = out.reshape(-1, n_sym, 1, K, m_iq)
+        out = layers_conv2d_complex(conv, n_filters, (1, K), strides=1, padding="same", scope=scope)
+        fft_out = out.reshape(-1, n_sym, n_filters, m_iq)
+
+    with scope.scope("demodulation"):                           # layer 2: data IQ extraction (:1266-1288)
+        flat = fft_out.reshape(-1, n_sym * n_filters * m_iq)
+        z = layers_dense(flat, data_ofdm * m_iq, scope=scope)
+        m = 2 ** nbits
+        c2 = scope.layer_name("conv2d")
+        w1 = scope.get(c2 + "/kernel", (2, m), fan_in=2, fan_out=m, meta=dict(tf_shape=(1, 1, 2, m)))
+        b1 = scope.get(c2 + "/bias", (m,), zeros=True)
+        d1 = scope.layer_name("dense")
+        w2 = scope.get(d1 + "/kernel", (m + 2, nbits * nllr), fan_in=m + 2, fan_out=nbits * nllr)
+        b2 = scope.get(d1 + "/bias", (nbits * nllr,), zeros=True)
+        tailp = ops.pack_tail_params(w1, b1, w2, b2)
+
+    zc = z.view(-1, data_ofdm, 2)
+    if bits is None:
+        dummy = torch.zeros(zc.shape[0], data_ofdm, nbits, dtype=torch.int32, device=z.device)
+        _, prob, _ = ops.demod_tail_eval(zc, tailp, dummy, nbits)
+        return prob
+    ce, prob, mbuf = ops.demod_tail_loss(zc, tailp, bits, nbits)
+    return prob, ce, mbuf, fft_out
+
+
+class OfdmDenseRx(torch.nn.Module):
+    """The basic-receiver graph of dev/py/ofdmreceiver_np.py:121-171 as a module over the layer API:
+    batch-moment normalisation -> complex_clip monitor -> ofdm_dense_rx -> loss / BER."""
+
+    def __init__(self, FLAGS, ofdmobj, seed: int = 1, device="cuda"):
+        super().__init__()
+        self.FLAGS, self.ofdmobj = FLAGS, ofdmobj
+        self.store = VariableStore(seed=seed, device=device)
+        self.outshape = [-1, ofdmobj.frame_size, FLAGS.nbits, 2]
+        self._create_variables()
+
+    def _create_variables(self):
+        """Create every variable up front, in the order (and with the fans) the first forward pass would."""
+        d, st = self.dims(), self.store
+        m, b = 2 ** d.nbits, d.nbits
+        st.get("fft_like/conv3d/kernel", (1, 1, d.kin, 2 * d.F), fan_in=d.kin * d.kin, fan_out=d.kin * 2 * d.F,
+               meta=dict(tf_shape=(1, d.kin, 1, d.kin, 2 * d.F), live_taps=((0,), ((d.kin - 1) // 2,))))
+        st.get("fft_like/conv3d/bias", (2 * d.F,), zeros=True)
+        st.get("demodulation/dense/kernel", (2 * d.S * d.F, 2 * d.D), fan_in=2 * d.S * d.F, fan_out=2 * d.D)
+        st.get("demodulation/dense/bias", (2 * d.D,), zeros=True)
+        st.get("demodulation/conv2d/kernel", (2, m), fan_in=2, fan_out=m, meta=dict(tf_shape=(1, 1, 2, m)))
+        st.get("demodulation/conv2d/bias", (m,), zeros=True)
+        st.get("demodulation/dense_1/kernel", (m + 2, 2 * b), fan_in=m + 2, fan_out=2 * b)
+        st.get("demodulation/dense_1/bias", (2 * b,), zeros=True)
+
+    def forward(self, tx_ofdm: torch.Tensor, bits_in: Optional[torch.Tensor] = None):
+        self.store.begin()
+        x_norm = ops.batch_moment_norm(tx_ofdm)                         # transmitter scope (:128-129)
+        if bits_in is None:
+            return ofdm_dense_rx(x_norm, self.FLAGS, self.ofdmobj, self.outshape, scope=self.store)
+        _, tx_power = complex_clip(x_norm, peak=8.0)                    # :131 (monitor only)
+        prob, ce, mbuf, fft_out = ofdm_dense_rx(x_norm, self.FLAGS, self.ofdmobj, self.outshape,
+                                                scope=self.store, bits=bits_in)
+        return dict(output=prob, ce_mean=ce, metrics=mbuf, tx_power=tx_power, input=x_norm, fft_out=fft_out)
+
+    # ---- parameter exchange with the fused engine / checkpoints -------------------------------
+    def dims(self) -> RxDims:
+        F, o = self.FLAGS, self.ofdmobj
+        kin = (o.K + o.CP) if F.cp else o.K
+        return RxDims(S=F.nsymbol, kin=kin, F=F.nfilter, D=o.frame_size, nbits=F.nbits)
+
+    def export_params(self) -> Dict[str, np.ndarray]:
+        """name -> live array in the engine's layout (conv3d kernel as [kin, 2F])."""
+        d = self.dims()
+        out = {}
+        for n in PARAM_NAMES:
+            a = self.store.tensor(n).detach().cpu().numpy()
+            if n == "fft_like/conv3d/kernel":
+                a = a.reshape(d.kin, 2 * d.F)
+            out[n] = a.copy()
+        return out
+
+    def import_params(self, params: Dict[str, np.ndarray]):
+        for n in PARAM_NAMES:
+            self.store.set(n, params[n])

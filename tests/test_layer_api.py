@@ -1,0 +1,174 @@
+"""Layer / model API mirror of dev/py/complex.py + model.py.
+
+CPU part: TF-style variable naming, shapes, error behaviour (no compute).
+GPU part (-m gpu): every layer against the oracle's literal restatement; the composable model against
+the fused engine."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccn_oracle as O
+
+
+def flags(**kw):
+    base = dict(nsymbol=7, nfft=64, longcp=True, pilot="lte", npilot=8, nguard=8, nbits=2, channel="EPA", cp=True,
+                nfilter=64)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def relerr(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+
+
+# ---- CPU ---------------------------------------------------------------------------------------
+def test_variable_names_match_reference_checkpoint_names():
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.engine import PARAM_NAMES
+    from dl_ofdm_amd.model import OfdmDenseRx
+    for nbits, cp in ((1, True), (2, True), (4, False)):
+        F = flags(nbits=nbits, cp=cp)
+        m = OfdmDenseRx(F, ofdm.ofdm_tx(F), device="cpu")
+        assert tuple(m.store.names()) == PARAM_NAMES
+        kin = 80 if cp else 64
+        assert m.store.meta["fft_like/conv3d/kernel"]["tf_shape"] == (1, kin, 1, kin, 128)
+        assert m.store.meta["fft_like/conv3d/kernel"]["live_taps"] == ((0,), ((kin - 1) // 2,))
+        assert m.store.meta["demodulation/dense/kernel"]["shape"] == (896, 640)
+        assert m.store.meta["demodulation/dense_1/kernel"]["shape"] == (2 ** nbits + 2, 2 * nbits)
+        lim = np.sqrt(6.0 / (kin * kin + kin * 128))               # glorot over the FULL conv3d kernel (A.7)
+        w = m.store.tensor("fft_like/conv3d/kernel").detach().numpy()
+        assert np.abs(w).max() <= lim and np.abs(w).max() > 0.9 * lim
+        assert float(m.store.tensor("demodulation/dense/bias").abs().max()) == 0.0
+
+
+def test_scope_auto_naming_like_tf_layers():
+    from dl_ofdm_amd.complex import VariableStore
+    st = VariableStore(device="cpu")
+    with st.scope("Equalizer"):
+        assert [st.layer_name("dense"), st.layer_name("conv3d"), st.layer_name("dense"), st.layer_name("conv3d")] == \
+            ["Equalizer/dense", "Equalizer/conv3d", "Equalizer/dense_1", "Equalizer/conv3d_1"]
+    st.begin()
+    with st.scope("Equalizer"):
+        assert st.layer_name("dense") == "Equalizer/dense"
+
+
+def test_layer_argument_errors():
+    from dl_ofdm_amd.complex import VariableStore, layers_conv1d_complex, layers_conv2d_complex
+    st = VariableStore(device="cpu")
+    with pytest.raises(TypeError):
+        layers_conv2d_complex(torch.zeros(2, 7, 1, 80), 4, (1, 80), scope=st)        # real rank-4: not complex64
+    with pytest.raises(NameError):
+        layers_conv2d_complex(torch.zeros(2, 7, 1, 80, 2), 4, [1, 80], scope=st)     # kernel must be int or tuple
+    with pytest.raises(NameError):
+        layers_conv1d_complex(torch.zeros(2, 7, 80, 3), 4, 3, scope=st)
+    with pytest.raises(AssertionError):
+        layers_conv1d_complex(torch.zeros(2, 7, 80, 2), 4, (3,), scope=st)
+
+
+def test_live_taps():
+    from dl_ofdm_amd.complex import _live_taps, tf_padding
+    out, p0, _ = tf_padding(1, 80, 1, "same")
+    assert (out, p0) == (1, 39) and _live_taps(1, 80, 1, out, p0) == [39]
+    out, p0, _ = tf_padding(1, 64, 1, "same")
+    assert _live_taps(1, 64, 1, out, p0) == [31]
+    out, p0, _ = tf_padding(7, 7, 1, "same")
+    assert _live_taps(7, 7, 1, out, p0) == list(range(7))
+    out, p0, _ = tf_padding(64, 64, 1, "valid")
+    assert out == 1 and _live_taps(64, 64, 1, out, p0) == list(range(64))
+
+
+# ---- GPU ---------------------------------------------------------------------------------------
+def _full_kernel(store, name, rng):
+    """Embed the stored live taps into a TF-shaped kernel whose dead taps hold random values."""
+    meta = store.meta[name + "/kernel"]
+    tl, tw = meta["live_taps"]
+    full = rng.randn(*meta["tf_shape"])
+    live = store.tensor(name + "/kernel").detach().cpu().numpy().astype(np.float64)
+    for ia, a in enumerate(tl):
+        for ib, b in enumerate(tw):
+            full[a, b, 0] = live[ia, ib]
+    return full
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,F,kernal,strides,padding", [
+    ((3, 7, 1, 80, 2), 64, (1, 80), 1, "same"),         # receiver fft_like
+    ((3, 7, 64, 1, 2), 64, (1, 64), 1, "valid"),        # equalizer frequency-domain conversion
+    ((2, 7, 64, 1, 2), 1, (7, 64), (1, 1), "same"),     # equalizer 2-D smoothing, F = 1
+    ((2, 9, 10, 3, 2), 5, (3, 2), (2, 1), "valid"),
+    ((2, 9, 10, 3, 2), 5, 3, 1, "same"),
+])
+def test_layers_conv2d_complex_vs_literal(shape, F, kernal, strides, padding):
+    from dl_ofdm_amd.complex import VariableStore, layers_conv2d_complex
+    rng = np.random.RandomState(0)
+    x = rng.randn(*shape).astype(np.float32)
+    st = VariableStore(seed=3)
+    xt = torch.as_tensor(x).cuda().requires_grad_()
+    y = layers_conv2d_complex(xt, F, kernal, strides=strides, padding=padding, scope=st)
+    st.set("conv3d/bias", rng.randn(2 * F))
+    st.begin()
+    y = layers_conv2d_complex(xt, F, kernal, strides=strides, padding=padding, scope=st)
+    full = _full_kernel(st, "conv3d", rng)
+    stt = (strides, strides) if isinstance(strides, int) else strides
+    ref = O.layers_conv2d_complex_literal(x.astype(np.float64), full, st.tensor("conv3d/bias").detach().cpu().numpy().astype(np.float64), stt, padding)
+    assert relerr(y.detach().cpu().numpy(), ref) <= 1e-5
+    y.sum().backward()                                                      # gradients reach inputs and variables
+    assert xt.grad is not None and st.tensor("conv3d/kernel").grad is not None
+    # complex64 input -> complex64 output
+    xc = torch.complex(xt.detach()[..., 0], xt.detach()[..., 1])
+    st.begin()
+    yc = layers_conv2d_complex(xc, F, kernal, strides=strides, padding=padding, scope=st)
+    assert yc.dtype == torch.complex64 and torch.equal(torch.view_as_real(yc), y.detach())
+
+
+@pytest.mark.gpu
+def test_conv1d_layers_vs_literal():
+    from dl_ofdm_amd.complex import VariableStore, layers_conv1d_complex, nn_conv1d_complex
+    rng = np.random.RandomState(1)
+    x = rng.randn(4, 11, 6, 2).astype(np.float32)
+    st = VariableStore(seed=5)
+    y = layers_conv1d_complex(torch.as_tensor(x).cuda(), 7, 3, strides=1, padding="same", scope=st)
+    k = st.tensor("conv2d/kernel").detach().cpu().numpy().astype(np.float64).reshape(3, 1, 6, 14)
+    b = st.tensor("conv2d/bias").detach().cpu().numpy().astype(np.float64)
+    assert relerr(y.cpu().numpy(), O.layers_conv1d_complex_literal(x.astype(np.float64), k, b, 1, "same")) <= 1e-5
+    f = rng.randn(3, 6, 1, 2).astype(np.float32)
+    z = nn_conv1d_complex(torch.as_tensor(x).cuda(), torch.as_tensor(f).cuda())
+    assert relerr(z.cpu().numpy(), O.nn_conv1d_complex(x.astype(np.float64), f.astype(np.float64))) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_composable_model_equals_fused_engine():
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.engine import RxEngine
+    from dl_ofdm_amd.model import OfdmDenseRx
+    from dl_ofdm_amd.ops import read_metrics
+    F = flags(nbits=2)
+    o = ofdm.ofdm_tx(F)
+    model = OfdmDenseRx(F, o, seed=4)
+    rng = np.random.RandomState(2)
+    for n in ("fft_like/conv3d/bias", "demodulation/dense/bias", "demodulation/conv2d/bias"):
+        model.store.set(n, rng.uniform(-.05, .05, model.store.tensor(n).shape))
+    batch = 200
+    x = torch.as_tensor(rng.randn(batch, 7, 80, 2).astype(np.float32)).cuda()
+    bits = torch.as_tensor(rng.randint(0, 2, (batch, 320, 2)).astype(np.int32)).cuda()
+    out = model(x, bits)
+    out["ce_mean"].backward()
+    eng = RxEngine(model.dims(), batch, params=model.export_params(), train=True)
+    eng.train_step(x, bits)
+    torch.cuda.synchronize()
+    assert torch.equal(out["input"], eng.x_norm) and torch.equal(out["fft_out"], eng.fft_out)
+    assert torch.equal(out["output"], eng.prob)
+    m1, m2 = read_metrics(out["metrics"]), eng.metrics()
+    assert m1["conf"] == m2["conf"] and m1["ce_mean"] == m2["ce_mean"]
+    assert abs(float(out["tx_power"]) - m2["tx_power"]) <= 1e-6 * m2["tx_power"]
+    g = eng.get_grads()
+    for n in g:
+        ga = model.store.tensor(n).grad.cpu().numpy().reshape(g[n].shape)
+        assert relerr(ga, g[n]) <= 2e-6, n
+    # inference call: probabilities only, same values
+    with torch.no_grad():
+        assert torch.equal(model(x), eng.prob)
