@@ -91,6 +91,7 @@ def test_short_training_run_learns_and_sweeps(tmp_path):
     assert h[-1]["train_loss"] < h[0]["train_loss"] - 0.02, (h[0], h[-1])
     assert h[-1]["test_ber"] < 0.35 and h[0]["test_ber"] > h[-1]["test_ber"]
     snrs, ber, loss, csvfile = res["sweep"]
+    csvfile = os.path.join(str(tmp_path), os.path.basename(csvfile))
     assert os.path.basename(csvfile) == "Test_DCCN_OFDM_t_AWGN.csv" and os.path.isfile(csvfile)
     lines = open(csvfile).read().splitlines()
     assert lines[0] == "SNR,BER,Loss" and len(lines) == 8

@@ -134,10 +134,10 @@ def test_conv1d_layers_vs_literal():
     y = layers_conv1d_complex(torch.as_tensor(x).cuda(), 7, 3, strides=1, padding="same", scope=st)
     k = st.tensor("conv2d/kernel").detach().cpu().numpy().astype(np.float64).reshape(3, 1, 6, 14)
     b = st.tensor("conv2d/bias").detach().cpu().numpy().astype(np.float64)
-    assert relerr(y.cpu().numpy(), O.layers_conv1d_complex_literal(x.astype(np.float64), k, b, 1, "same")) <= 1e-5
+    assert relerr(y.detach().cpu().numpy(), O.layers_conv1d_complex_literal(x.astype(np.float64), k, b, 1, "same")) <= 1e-5
     f = rng.randn(3, 6, 1, 2).astype(np.float32)
     z = nn_conv1d_complex(torch.as_tensor(x).cuda(), torch.as_tensor(f).cuda())
-    assert relerr(z.cpu().numpy(), O.nn_conv1d_complex(x.astype(np.float64), f.astype(np.float64))) <= 1e-5
+    assert relerr(z.detach().cpu().numpy(), O.nn_conv1d_complex(x.astype(np.float64), f.astype(np.float64))) <= 1e-5
 
 
 @pytest.mark.gpu
