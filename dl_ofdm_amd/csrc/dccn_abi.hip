@@ -80,6 +80,8 @@ static GemmParams gp_zero() {
     return p;
 }
 static int round_k(int K) { return ceil_div(K, 64) * 64; }
+// the fast GEMM loaders use 32-bit byte offsets from a uniform base: operand must be < 2 GiB
+static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < (1LL << 31); }
 
 static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                           hipStream_t s) {
@@ -89,8 +91,8 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.M = M; p.N = N; p.K = K;
     p.lda = K; p.ldb = N; p.ldc = N;
     p.klen = round_k(K);
-    p.vecA = (K % 4 == 0) && aligned16(x);                 // KCONTIG: ld = K, k extent K
-    p.vecB = (N % 4 == 0) && aligned16(w);                 // ICONTIG: ld = N, i extent N
+    p.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);     // KCONTIG: ld = K, k extent K
+    p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 
@@ -101,8 +103,8 @@ static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, i
     p.M = M; p.N = K; p.K = N;
     p.lda = N; p.ldb = N; p.ldc = K;
     p.klen = round_k(N);
-    p.vecA = (N % 4 == 0) && aligned16(dy);
-    p.vecB = (N % 4 == 0) && aligned16(w);
+    p.vecA = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
+    p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);
     return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
 }
 
@@ -134,8 +136,8 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     p.lda = K; p.ldb = N; p.ldc = N;
     p.klen = sp.klen;
     p.slab = (long long)K * N;
-    p.vecA = (K % 4 == 0) && aligned16(x);
-    p.vecB = (N % 4 == 0) && aligned16(dy);
+    p.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
+    p.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     if (defer) { defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1; }
     if (sp.splits == 1) {
         p.C = dw;
@@ -166,7 +168,8 @@ static int cconv_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
     p.klen = round_k(2 * kin);
     p.cF = F;
-    p.vecA = (kin % 2 == 0) && aligned16(x);
+    p.vecA = (kin % 2 == 0) && aligned16(x) && small_enough(rows, 2LL * kin);
+    p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);      // float2 loads of [Wa|Wb] rows
     return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
 }
 
@@ -178,7 +181,8 @@ static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int ro
     p.lda = 2 * F; p.ldb = 2 * F; p.ldc = 2 * kin;
     p.klen = round_k(2 * F);
     p.cF = F;
-    p.vecA = (F % 2 == 0) && aligned16(dout);
+    p.vecA = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);
+    p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);
     return launch_gemm<OP_KCONTIG, OP_CCONV_WT, 0, TAG_CCONV_BWD_X>(p, 1, s);
 }
 
@@ -196,8 +200,8 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
     p.klen = sp.klen;
     p.slab = (long long)4 * kin * F;
-    p.vecA = (kin % 2 == 0) && aligned16(x);
-    p.vecB = (F % 2 == 0) && aligned16(dout);
+    p.vecA = (kin % 2 == 0) && aligned16(x) && small_enough(rows, 2LL * kin);
+    p.vecB = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);
     DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     const int nthreads = kin * F + F;
     hipLaunchKernelGGL(cconv_fold_kernel, dim3(ceil_div(nthreads, kRedLanes)), dim3(256), 0, s, slabs, sp.splits, p.slab,

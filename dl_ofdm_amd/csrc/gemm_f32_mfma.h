@@ -1,14 +1,19 @@
-// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32): exact f32 products and a
-// k-ascending fmaf accumulation chain per output element, so a launch without split-K is
-// bitwise deterministic and bitwise reproducible by `for k: acc = fmaf(a,b,acc)`.
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32): exact f32 products, f32 accumulation
+// in a fixed order => every launch is bitwise deterministic.
 //
-// C[M,N] = A[M,K] . B[K,N]  with both operands staged through LDS as [k][i] tiles
-// (k-major, i contiguous), so one MFMA operand fetch is a conflict-free ds_read_b32 of 32
-// consecutive floats per half-wave.  How a tile gets from HBM into that layout is the
-// operand "kind":
-//   OP_ICONTIG   element (k,i) at p[k*ld+i]  -> float4 along i, ds_write_b128
-//   OP_KCONTIG   element (k,i) at p[i*ld+k]  -> float4 along k, 4 transposed ds_write_b32
-//                (LDS row stride BI+1 makes those writes conflict-free)
+// C[M,N] = A[M,K] . B[K,N].  Both operands are staged in LDS as [i][k] tiles (k contiguous, row
+// stride BK+4 floats): one ds_read_b128 hands a lane FOUR consecutive k of its row, i.e. the operand
+// of four consecutive MFMAs.  (The MFMA pairs the k supplied by lanes 0-31 with the k supplied by
+// lanes 32-63; inside every group of 8 k the order is permuted to {0,4},{1,5},{2,6},{3,7} -- the
+// same permutation for A and B, so the sum is unchanged.)  With the +4 pad every LDS access of the
+// kernel is bank-conflict free: 16-lane read groups land on 16 distinct 16-byte slots, writes are
+// 128 contiguous bytes per 8-lane group.
+//
+// How a tile gets from HBM into that layout is the operand "kind":
+//   OP_KCONTIG   element (k,i) at p[i*ld+k]  -> float4 along k, ds_write_b128
+//   OP_ICONTIG   element (k,i) at p[k*ld+i]  -> a thread loads a 4(k) x 4(i) block as four float4
+//                rows, transposes it in registers and writes four ds_write_b128 (lane -> block map
+//                chosen so that both the global rows and the LDS writes stay conflict free)
 //   OP_CCONV_W   virtual expanded complex-conv weights Weff[2kin,2F] built on the fly from
 //                w[kin,2F] = [Wa|Wb] (dev/py/complex.py:185-188):
 //                    Weff[2n  ,2f] =  Wa[n,f]   Weff[2n  ,2f+1] =  Wb[n,f]
@@ -17,8 +22,7 @@
 //                sub-convolutions of the C-Conv are ONE GEMM with interleaved IQ in/out.
 //   OP_CCONV_WT  Weff transposed (for dX = dOut . Weff^T)
 //
-// Block = 256 threads = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) made of 32x32 MFMA
-// tiles; BK = 32; register-staged double buffering with one barrier per k-tile.
+// Block = 256 threads = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) made of 32x32 MFMA tiles.
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -39,14 +43,14 @@ struct GemmParams {
     float* colsum;       // [splits][N] partial column sums of the B rows, nullable
     int M, N, K;
     int lda, ldb, ldc;
-    int klen;            // K range per split (multiple of 32)
+    int klen;            // K range per split (multiple of 64)
     long long slab;      // elements between the split slabs of C
     int cF;              // F of the cconv operand kinds
     int vecA, vecB;      // vector (16 B) global loads legal for the operand
     int cbias;           // 1: bias is the C-Conv [ba|bb] pair -> col 2f: ba-bb, col 2f+1: bb-ba
 };
 
-constexpr int kBKmin = 32;      // K ranges (klen) are multiples of this
+constexpr int kGemmThreads = 256;
 
 __device__ __forceinline__ float cconv_weff(const float* __restrict__ w, int F, int row, int col) {
     const int n = row >> 1, q = row & 1, f = col >> 1, c = col & 1;
@@ -54,65 +58,138 @@ __device__ __forceinline__ float cconv_weff(const float* __restrict__ w, int F, 
     return q ? -v : v;
 }
 
-template <int KIND, int BI, int BK, int THREADS>
-struct Tile {
-    static constexpr int NV = BK * BI / 4 / THREADS;   // 4-element pieces per thread per k-tile
-    static constexpr bool KV = (KIND == OP_KCONTIG || KIND == OP_CCONV_WT);
-    static constexpr int LD = KV ? BI + 1 : BI;
-    float4 r[NV];
-    unsigned okmask;     // bit v: piece v lies inside the k range (applied when it is written to LDS,
-                         // so the global load itself has no consumer until then and stays in flight)
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
+// One operand tile: BI rows (the M or N index) x BK columns (k).  A "piece" is one 16-byte unit of
+// LDS traffic per thread (4 consecutive k of one row); NV pieces per thread per k-tile.
+//
+// Two load paths:
+//   fast   (VEC builds, k-tiles that lie completely inside the K range): every per-thread address is
+//          `uniform tile base + constant 32-bit byte offset`; the offsets (with the row clamp folded in) are
+//          computed once before the k-loop, the tile base advances on the scalar unit.  No masks, no
+//          selects: fp32 MFMAs execute on the SIMD's own FMA lanes, so every VALU instruction in the loop
+//          is time taken from the matrix chain -- the steady-state body is kept down to loads, LDS ops, MFMAs.
+//   masked (ragged last k-tile, unaligned / odd-sized operands): clamped addresses + zero-fill selects.
+template <int KIND, int BI, int BK>
+struct Tile {
+    static constexpr int NV = BK * BI / 4 / kGemmThreads;
+    static constexpr int LD = BK + 4;
+    static constexpr bool IC = (KIND == OP_ICONTIG);
+    static constexpr bool CC = (KIND == OP_CCONV_W || KIND == OP_CCONV_WT);
+    static constexpr int NOFF = CC ? 2 * NV : NV;
+    static_assert(NV >= 1 && (!IC || NV % 4 == 0), "tile too small for the thread block");
+    float4 r[NV];
+    unsigned okmask;        // masked path: bit v = piece v lies inside the k range (applied at LDS-write time)
+    unsigned voff[NOFF];    // fast path: byte offsets from the uniform tile base
+    unsigned negmask;       // CCONV_WT fast path: bit v = piece v's Weff row is odd (negated)
+
+    // ICONTIG: piece v = row e = v%4 of 4x4 block v/4.  Lanes of an 8-lane group cover 2 adjacent i4
+    // x 4 consecutive k4 (conflict-free transposed ds_write_b128); the 8 groups of a wave cover 16
+    // adjacent i4, so each global row segment a wave touches is 256 contiguous bytes.
+    static __device__ __forceinline__ void block_coords(int bidx, int& i4, int& k4) {
+        const int sub = bidx & 7, rest = bidx >> 3;
+        constexpr int pairs = BI / 8;
+        i4 = 2 * (rest % pairs) + (sub & 1);
+        k4 = 4 * (rest / pairs) + (sub >> 1);
+    }
+
+    // ---- fast path ------------------------------------------------------------------------
+    __device__ __forceinline__ void init_fast(int ld, int i0, int I, int cF, int tid) {
+        negmask = 0u;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if constexpr (IC) {
+                int i4, k4;
+                block_coords(tid + (v >> 2) * kGemmThreads, i4, k4);
+                voff[v] = (unsigned)(((4 * k4 + (v & 3)) * ld + min(i0 + 4 * i4, I - 4)) * 4);
+            } else {
+                const int idx = tid + v * kGemmThreads;
+                const int ic = min(i0 + idx / (BK / 4), I - 1);
+                const int k = (idx % (BK / 4)) * 4;                 // k offset inside the tile (multiple of 4)
+                if constexpr (KIND == OP_KCONTIG) {
+                    voff[v] = (unsigned)((ic * ld + k) * 4);
+                } else if constexpr (KIND == OP_CCONV_W) {        // element (k,i) = Weff[k][i], i = ic fixed
+                    const int f = ic >> 1, c = ic & 1, n0 = k >> 1;
+                    voff[2 * v] = (unsigned)((n0 * 2 * cF + f + (c ? cF : 0)) * 4);       // q = 0, 2 (rows n0, n0+1), +
+                    voff[2 * v + 1] = (unsigned)((n0 * 2 * cF + f + (c ? 0 : cF)) * 4);   // q = 1, 3, negated
+                } else {                                          // element (k,i) = Weff[i][k], row i = ic fixed
+                    const int n = ic >> 1, qb = ic & 1, f0 = k >> 1;
+                    voff[2 * v] = (unsigned)((n * 2 * cF + (qb ? cF : 0) + f0) * 4);      // columns c = 0
+                    voff[2 * v + 1] = (unsigned)((n * 2 * cF + (qb ? 0 : cF) + f0) * 4);  // columns c = 1
+                    negmask |= (unsigned)qb << v;
+                }
+            }
+        }
+    }
+    // wave-uniform base of the k-tile starting at k0
+    static __device__ __forceinline__ const char* tile_base(const float* p, int ld, int k0, int cF) {
+        if constexpr (KIND == OP_ICONTIG) return reinterpret_cast<const char*>(p + (size_t)k0 * ld);
+        else if constexpr (KIND == OP_KCONTIG) return reinterpret_cast<const char*>(p + k0);
+        else if constexpr (KIND == OP_CCONV_W) return reinterpret_cast<const char*>(p + (size_t)(k0 >> 1) * 2 * cF);
+        else return reinterpret_cast<const char*>(p + (k0 >> 1));
+    }
+    __device__ __forceinline__ void load_fast(int v, const char* __restrict__ base, int cF) {
+        if constexpr (KIND == OP_ICONTIG || KIND == OP_KCONTIG) {
+            r[v] = *reinterpret_cast<const float4*>(base + voff[v]);
+        } else if constexpr (KIND == OP_CCONV_W) {
+            const unsigned row = (unsigned)(2 * cF * 4);
+            const float a0 = *reinterpret_cast<const float*>(base + voff[2 * v]);
+            const float b0 = *reinterpret_cast<const float*>(base + voff[2 * v + 1]);
+            const float a1 = *reinterpret_cast<const float*>(base + voff[2 * v] + row);
+            const float b1 = *reinterpret_cast<const float*>(base + voff[2 * v + 1] + row);
+            r[v] = make_float4(a0, -b0, a1, -b1);
+        } else {
+            const float2 a = *reinterpret_cast<const float2*>(base + voff[2 * v]);
+            const float2 b = *reinterpret_cast<const float2*>(base + voff[2 * v + 1]);
+            const float sgn = ((negmask >> v) & 1u) ? -1.f : 1.f;
+            r[v] = make_float4(sgn * a.x, sgn * b.x, sgn * a.y, sgn * b.y);
+        }
+    }
+
+    // ---- masked path ------------------------------------------------------------------------
     // Piece v of the (k0..kend) x (i0..I) window.  Out-of-range k must read as 0 (it enters the sums);
     // out-of-range i only feeds outputs that are never stored.  Every access is issued unconditionally
-    // from a clamped in-range address (no divergent control flow).  `vec` (block-uniform, decided on
-    // the host, a template parameter so the loop stays straight-line) selects one 16-byte load per piece: it needs ld % 4 == 0, a 16-byte aligned base and
-    // (ICONTIG) I % 4 == 0 / (KCONTIG) K % 4 == 0.
+    // from a clamped in-range address (no divergent control flow).
     template <bool VEC>
-    __device__ __forceinline__ void load_piece(int v, const float* __restrict__ p, int ld, int k0, int kend, int K,
-                                               int i0, int I, int cF, int tid) {
-        const int idx = tid + v * THREADS;
-        if constexpr (!KV) {
-            const int k = k0 + idx / (BI / 4);
-            const int i = i0 + (idx % (BI / 4)) * 4;
+    __device__ __forceinline__ void load_masked(int v, const float* __restrict__ p, int ld, int k0, int kend, int K,
+                                                int i0, int I, int cF, int tid) {
+        if constexpr (IC) {
+            int i4, k4;
+            block_coords(tid + (v >> 2) * kGemmThreads, i4, k4);
+            const int k = k0 + 4 * k4 + (v & 3);
+            const int i = i0 + 4 * i4;
             const int kc = min(k, K - 1);
-            bool vdone = false;
-            if constexpr (KIND == OP_ICONTIG && VEC) {
+            if constexpr (VEC) {
                 r[v] = *reinterpret_cast<const float4*>(p + (size_t)kc * ld + min(i, I - 4));
-                vdone = true;
-            }
-            if (!vdone) {
+                okmask = (okmask & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
+            } else {
                 float e[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ic = min(i + q, I - 1);
-                    float t;
-                    if constexpr (KIND == OP_ICONTIG) t = p[(size_t)kc * ld + ic];
-                    else t = cconv_weff(p, cF, kc, ic);
-                    e[q] = (i + q < I) ? t : 0.f;
+                    const float t = p[(size_t)kc * ld + min(i + q, I - 1)];
+                    e[q] = (k < kend && i + q < I) ? t : 0.f;
                 }
                 r[v] = make_float4(e[0], e[1], e[2], e[3]);
+                okmask |= 1u << v;
             }
-            okmask = (okmask & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
         } else {
+            const int idx = tid + v * kGemmThreads;
             const int i = i0 + idx / (BK / 4);
             const int k = k0 + (idx % (BK / 4)) * 4;
             const int ic = min(i, I - 1);
-            bool vdone = false;
             if constexpr (KIND == OP_KCONTIG && VEC) {
                 r[v] = *reinterpret_cast<const float4*>(p + (size_t)ic * ld + min(k, K - 4));
                 okmask = (okmask & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
-                vdone = true;
-            }
-            if (!vdone) {
+            } else {
                 float e[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int kc = min(k + q, K - 1);
                     float t;
                     if constexpr (KIND == OP_KCONTIG) t = p[(size_t)ic * ld + kc];
-                    else t = cconv_weff(p, cF, ic, kc);
-                    e[q] = (k + q < kend) ? t : 0.f;
+                    else if constexpr (KIND == OP_CCONV_W) t = cconv_weff(p, cF, kc, ic);      // element (k,i) = Weff[k][i]
+                    else t = cconv_weff(p, cF, ic, kc);                                          // element (k,i) = Weff[i][k]
+                    e[q] = (k + q < kend && i < I) ? t : 0.f;
                 }
                 r[v] = make_float4(e[0], e[1], e[2], e[3]);
                 okmask |= 1u << v;
@@ -120,52 +197,55 @@ struct Tile {
         }
     }
 
+    // v must be a compile-time constant after unrolling (static register / component selection)
+    template <bool MASKED>
     __device__ __forceinline__ void store_piece(int v, float* __restrict__ lds, int tid) const {
-        const int idx = tid + v * THREADS;
-        const bool ok = (okmask >> v) & 1u;
-        const float4 val = make_float4(ok ? r[v].x : 0.f, ok ? r[v].y : 0.f, ok ? r[v].z : 0.f, ok ? r[v].w : 0.f);
-        if constexpr (!KV) {
-            const int k = idx / (BI / 4);
-            const int i = (idx % (BI / 4)) * 4;
-            *reinterpret_cast<float4*>(lds + k * LD + i) = val;
+        if constexpr (IC) {
+            int i4, k4;
+            block_coords(tid + (v >> 2) * kGemmThreads, i4, k4);
+            const int b = v & ~3, q = v & 3;               // row i = 4*i4 + q of the transposed block
+            float4 val = make_float4(f4c(r[b + 0], q), f4c(r[b + 1], q), f4c(r[b + 2], q), f4c(r[b + 3], q));
+            if constexpr (MASKED) {
+                val.x = ((okmask >> (b + 0)) & 1u) ? val.x : 0.f;
+                val.y = ((okmask >> (b + 1)) & 1u) ? val.y : 0.f;
+                val.z = ((okmask >> (b + 2)) & 1u) ? val.z : 0.f;
+                val.w = ((okmask >> (b + 3)) & 1u) ? val.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(lds + (4 * i4 + q) * LD + 4 * k4) = val;
         } else {
-            const int i = idx / (BK / 4);
-            const int k = (idx % (BK / 4)) * 4;
-            lds[(k + 0) * LD + i] = val.x;
-            lds[(k + 1) * LD + i] = val.y;
-            lds[(k + 2) * LD + i] = val.z;
-            lds[(k + 3) * LD + i] = val.w;
+            const int idx = tid + v * kGemmThreads;
+            float4 val = r[v];
+            if constexpr (MASKED) {
+                const bool ok = (okmask >> v) & 1u;
+                val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
+            }
+            *reinterpret_cast<float4*>(lds + (idx / (BK / 4)) * LD + (idx % (BK / 4)) * 4) = val;
         }
     }
 };
 
 template <int KA, int KB, int BM, int BN, int BK>
 constexpr size_t gemm_smem_bytes() {
-    return (size_t)(2 * BK * Tile<KA, BM, BK, 256>::LD + 2 * BK * Tile<KB, BN, BK, 256>::LD) * sizeof(float);
+    return (size_t)(2 * BM * Tile<KA, BM, BK>::LD + 2 * BN * Tile<KB, BN, BK>::LD) * sizeof(float);
 }
 
+enum PrefetchMode : int { PF_NONE = 0, PF_FAST = 1, PF_MASKED = 2 };
+
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator
-// THREADS = 256: four waves, one per SIMD.  THREADS = 512: a second group of four waves shares the
-// same LDS tiles and takes the other half of every k-tile (in-block split-K, summed through LDS at the
-// end): each SIMD then holds two independent MFMA chains, so one wave's barrier / LDS / global-load
-// waits are covered by the other's matrix work.
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int THREADS>
-__global__ __launch_bounds__(THREADS) void gemm_f32_mfma_kernel(const GemmParams p) {
-    constexpr int kBK = BK;
-    constexpr int KG = THREADS / 256;
-    using TA = Tile<KA, BM, BK, THREADS>;
-    using TB = Tile<KB, BN, BK, THREADS>;
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
+__global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
+    using TA = Tile<KA, BM, BK>;
+    using TB = Tile<KB, BN, BK>;
     constexpr int LDA = TA::LD, LDB = TB::LD;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                       // [2][kBK][LDA]
-    float* sB = smem + 2 * kBK * LDA;       // [2][kBK][LDB]   (2*32*LDA is a multiple of 4)
+    float* sA = smem;                       // [2][BM][LDA]
+    float* sB = smem + 2 * BM * LDA;        // [2][BN][LDB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int kg = wid >> 2;                               // k-group of this wave (0 when THREADS == 256)
-    const int wm0 = ((wid & 3) >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (speed only, never
     // correctness); give each XCD a contiguous run of row-major tiles so its private L2 holds one
     // slice of A rows plus the B panel instead of everything.
@@ -179,7 +259,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_mfma_kernel(const GemmParams
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int kbeg = blockIdx.z * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
-    const int ntiles = (kend - kbeg + kBK - 1) / kBK;
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int nfull = VEC ? (kend - kbeg) / BK : 0;     // k-tiles the fast loader may fetch
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -196,102 +277,110 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_mfma_kernel(const GemmParams
     TB tb;
     ta.okmask = 0u;
     tb.okmask = 0u;
-    constexpr int PA = TA::NV, PB = TB::NV, NK = kBK / 2 / KG;      // MFMA steps per wave per k-tile
-    static_assert(PA >= 1 && PB >= 1 && NK >= 2 * (PA + PB), "k-tile too shallow for the load/store slots");
-    const int kofs = kg * NK;                                       // first k-step of this wave's group
+    if constexpr (VEC) {
+        ta.init_fast(p.lda, m0, p.M, p.cF, tid);
+        tb.init_fast(p.ldb, n0, p.N, p.cF, tid);
+    }
+    constexpr int PA = TA::NV, PB = TB::NV;
+    constexpr int NG = BK / 8;                           // groups of 8 k per k-tile
+    constexpr int NSTEP = NG * 4;                        // MFMA steps (of TM*TN MFMAs) per k-tile
+    static_assert(NSTEP >= 2 * (PA + PB), "k-tile too shallow for the load/store slots");
+
+    auto load_a = [&](auto mode_tag, int v, int k0) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if constexpr (MODE == PF_FAST) ta.load_fast(v, TA::tile_base(p.A, p.lda, k0, p.cF), p.cF);
+        else ta.template load_masked<VEC>(v, p.A, p.lda, k0, kend, p.K, m0, p.M, p.cF, tid);
+    };
+    auto load_b = [&](auto mode_tag, int v, int k0) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if constexpr (MODE == PF_FAST) tb.load_fast(v, TB::tile_base(p.B, p.ldb, k0, p.cF), p.cF);
+        else tb.template load_masked<VEC>(v, p.B, p.ldb, k0, kend, p.K, n0, p.N, p.cF, tid);
+    };
+    auto stage_first = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+        for (int v = 0; v < PA; ++v) load_a(mode_tag, v, kbeg);
+#pragma unroll
+        for (int v = 0; v < PB; ++v) load_b(mode_tag, v, kbeg);
+#pragma unroll
+        for (int v = 0; v < PA; ++v) ta.template store_piece<MODE == PF_MASKED>(v, sA, tid);
+#pragma unroll
+        for (int v = 0; v < PB; ++v) tb.template store_piece<MODE == PF_MASKED>(v, sB, tid);
+    };
     if (ntiles > 0) {
-#pragma unroll
-        for (int v = 0; v < PA; ++v) ta.template load_piece<VEC>(v, p.A, p.lda, kbeg, kend, p.K, m0, p.M, p.cF, tid);
-#pragma unroll
-        for (int v = 0; v < PB; ++v) tb.template load_piece<VEC>(v, p.B, p.ldb, kbeg, kend, p.K, n0, p.N, p.cF, tid);
-#pragma unroll
-        for (int v = 0; v < PA; ++v) ta.store_piece(v, sA, tid);
-#pragma unroll
-        for (int v = 0; v < PB; ++v) tb.store_piece(v, sB, tid);
+        if (nfull > 0) stage_first(std::integral_constant<int, PF_FAST>{});
+        else stage_first(std::integral_constant<int, PF_MASKED>{});
     }
     __syncthreads();
 
-    // One k-tile = NK dependent MFMA steps (64 cycles each per accumulator).  Everything else the wave
-    // has to do for the pipeline is issued INSIDE that chain, in the shadow of the matrix pipe:
-    //   - operand fragments are read from LDS two steps ahead (3-slot register ring),
+    // One k-tile = NSTEP dependent MFMA steps (64 cycles each per accumulator).  Everything else the wave
+    // has to do for the pipeline is issued INSIDE that chain:
+    //   - the operand fragments of the next group of 8 k are read (one ds_read_b128 per 32x32 operand
+    //     tile) while the 4 MFMA steps of the current group run,
     //   - the global loads of the next k-tile go out during the first PA+PB steps,
-    //   - their LDS writes (other buffer) happen during the last PA+PB steps, ~NK*64 cycles later.
-    // Only the barrier and the first two fragment reads of a tile are exposed.
-    // (MORE = false for the last k-tile: no prefetch work, so the steady-state body has no branches and the
-    // compiler keeps counted vmcnt/lgkmcnt waits instead of draining at control-flow joins.)
+    //   - their LDS writes (other buffer) happen during the last PA+PB steps, ~NSTEP*64 cycles later.
+    // The prefetch mode is a template parameter (fast / masked / none), so the steady-state body is
+    // straight-line and the compiler keeps counted vmcnt/lgkmcnt waits instead of draining at joins.
     int t = 0;
-    auto ktile = [&](auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    auto ktile = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         const int cur = t & 1;
-        const int k0n = kbeg + (t + 1) * kBK;
-        const float* As = sA + cur * kBK * LDA + wm0 + l31;
-        const float* Bs = sB + cur * kBK * LDB + wn0 + l31;
-        float* An = sA + (cur ^ 1) * kBK * LDA;
-        float* Bn = sB + (cur ^ 1) * kBK * LDB;
-        float fa[3][TM], fb[3][TN];
+        const int k0n = kbeg + (t + 1) * BK;
+        const float* As = sA + cur * BM * LDA + (wm0 + l31) * LDA + 4 * h;
+        const float* Bs = sB + cur * BN * LDB + (wn0 + l31) * LDB + 4 * h;
+        float* An = sA + (cur ^ 1) * BM * LDA;
+        float* Bn = sB + (cur ^ 1) * BN * LDB;
+        float4 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int pre = 0; pre < 2; ++pre) {
+        for (int a = 0; a < TM; ++a) fa[0][a] = *reinterpret_cast<const float4*>(As + a * 32 * LDA);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[pre][a] = As[(2 * (kofs + pre) + h) * LDA + a * 32];
+        for (int b = 0; b < TN; ++b) fb[0][b] = *reinterpret_cast<const float4*>(Bs + b * 32 * LDB);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[pre][b] = Bs[(2 * (kofs + pre) + h) * LDB + b * 32];
-        }
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            if (kk + 2 < NK) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a) fa[(kk + 2) % 3][a] = As[(2 * (kofs + kk + 2) + h) * LDA + a * 32];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[(kk + 2) % 3][b] = Bs[(2 * (kofs + kk + 2) + h) * LDB + b * 32];
-            }
-            if constexpr (MORE) {
-                if (kk < PA) ta.template load_piece<VEC>(kk, p.A, p.lda, k0n, kend, p.K, m0, p.M, p.cF, tid);
-                else if (kk < PA + PB) tb.template load_piece<VEC>(kk - PA, p.B, p.ldb, k0n, kend, p.K, n0, p.N, p.cF, tid);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < TM; ++a)
+                    fa[(g + 1) & 1][a] = *reinterpret_cast<const float4*>(As + a * 32 * LDA + 8 * (g + 1));
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk % 3][a], fb[kk % 3][b], acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MORE) {
-                constexpr int S0 = NK - PA - PB;
-                if (kk >= S0 && kk < S0 + PA) ta.store_piece(kk - S0, An, tid);
-                else if (kk >= S0 + PA) tb.store_piece(kk - S0 - PA, Bn, tid);
+                    fb[(g + 1) & 1][b] = *reinterpret_cast<const float4*>(Bs + b * 32 * LDB + 8 * (g + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int step = g * 4 + j;
+                if constexpr (MODE != PF_NONE) {
+                    if (step < PA) load_a(mode_tag, step, k0n);
+                    else if (step < PA + PB) load_b(mode_tag, step - PA, k0n);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(fa[g & 1][a], j), f4c(fb[g & 1][b], j),
+                                                                         acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE != PF_NONE) {
+                    constexpr int S0 = NSTEP - PA - PB;
+                    if (step >= S0 && step < S0 + PA) ta.template store_piece<MODE == PF_MASKED>(step - S0, An, tid);
+                    else if (step >= S0 + PA) tb.template store_piece<MODE == PF_MASKED>(step - S0 - PA, Bn, tid);
+                }
             }
         }
         if (COLSUM && do_cs) {
-            const float* Bc = sB + cur * kBK * LDB + tid;
-#pragma unroll 8
-            for (int k = 0; k < kBK; ++k) cs += Bc[k * LDB];
+            const float* Bc = sB + cur * BN * LDB + tid * LDB;
+#pragma unroll
+            for (int k = 0; k < BK; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(Bc + k);
+                cs += (v.x + v.y) + (v.z + v.w);
+            }
         }
         __syncthreads();
     };
-    for (; t + 1 < ntiles; ++t) ktile(std::true_type{});
-    if (ntiles > 0) ktile(std::false_type{});
+    for (; t + 1 < nfull; ++t) ktile(std::integral_constant<int, PF_FAST>{});
+    for (; t + 1 < ntiles; ++t) ktile(std::integral_constant<int, PF_MASKED>{});
+    if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
 
-    if constexpr (KG == 2) {
-        // sum the two k-groups: group 1 parks its accumulators in LDS (the tile buffers are free after the
-        // loop's last barrier), group 0 adds them in a fixed order and owns the epilogue
-        float* xch = smem + ((wid & 3) * TM * TN * 16) * 64 + lane;
-        if (kg == 1) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((a * TN + b) * 16 + r) * 64] = acc[a][b][r];
-        }
-        __syncthreads();
-        if (kg == 1) return;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] += xch[((a * TN + b) * 16 + r) * 64];
-    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cz = p.C + (size_t)blockIdx.z * p.slab;
 #pragma unroll
@@ -323,9 +412,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_mfma_kernel(const GemmParams
 
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
 static int launch_gemm_cfg2(const GemmParams& p, int splits, hipStream_t s) {
-    // two k-groups (8 waves) whenever a k-tile leaves each group enough MFMA steps for its load/store slots
-    constexpr int THREADS = (BM == 64 && BN == 64 && BK == 64) ? 512 : 256;
-    auto kern = gemm_f32_mfma_kernel<KA, KB, BM, BN, BK, COLSUM, TAG, VEC, THREADS>;
+    auto kern = gemm_f32_mfma_kernel<KA, KB, BM, BN, BK, COLSUM, TAG, VEC>;
     constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK>();
     static bool attr_done = false;
     if (!attr_done) {
@@ -335,29 +422,26 @@ static int launch_gemm_cfg2(const GemmParams& p, int splits, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid(ceil_div(p.N, BN) * ceil_div(p.M, BM), 1, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(THREADS), smem, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 
+// the fast (unmasked, 32-bit-offset) loaders need both operands vector-legal and < 2 GiB
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG>
 static int launch_gemm_cfg(const GemmParams& p, int splits, hipStream_t s) {
-    constexpr bool needA = (KA == OP_ICONTIG || KA == OP_KCONTIG), needB = (KB == OP_ICONTIG || KB == OP_KCONTIG);
-    const bool vec = (!needA || p.vecA) && (!needB || p.vecB);
+    const bool vec = p.vecA && p.vecB;
     if (vec) return launch_gemm_cfg2<KA, KB, BM, BN, BK, COLSUM, TAG, true>(p, splits, s);
     return launch_gemm_cfg2<KA, KB, BM, BN, BK, COLSUM, TAG, false>(p, splits, s);
 }
 
-// tile choice: 128x128 only when it still yields >= 2 blocks per CU, else 64x64;
-// k-tile depth 64 when the K range is long enough to amortise it (fewer barriers, longer MFMA
-// runs to cover the global-load latency of the next tile), else 32
+// tile choice: 128x128x32 (four accumulators per wave) only when it still yields >= 2 blocks per CU,
+// else 64x64x64
 template <int KA, int KB, int COLSUM, int TAG>
 static int launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * splits;
-    const int krange = p.klen < p.K ? p.klen : p.K;
     if (big >= 2 * kCUs) return launch_gemm_cfg<KA, KB, 128, 128, 32, COLSUM, TAG>(p, splits, s);
-    if (krange >= 256 && krange % 64 == 0) return launch_gemm_cfg<KA, KB, 64, 64, 64, COLSUM, TAG>(p, splits, s);
-    return launch_gemm_cfg<KA, KB, 64, 64, 32, COLSUM, TAG>(p, splits, s);
+    return launch_gemm_cfg<KA, KB, 64, 64, 64, COLSUM, TAG>(p, splits, s);
 }
 
 // split-K plan for the weight-gradient GEMMs (K = batch rows is the long axis)
@@ -393,14 +477,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const long long i = ((long long)blockIdx.x * kRedLanes + lane) * (VEC4 ? 4 : 1);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
-#pragma unroll 8
-        for (int z = grp; z < splits; z += kRedGroups) {
-            const float* q = partial + (size_t)z * slab + i;
-            if constexpr (VEC4) {
-                const float4 v = *reinterpret_cast<const float4*>(q);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            } else {
-                s.x += q[0];
+        // batches of 8 slabs: loads first (clamped slab index, weight by validity), then a fixed-order sum
+        for (int zb = grp; zb < splits; zb += 8 * kRedGroups) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = min(zb + u * kRedGroups, splits - 1);
+                const float* q = partial + (size_t)z * slab + i;
+                if constexpr (VEC4) v[u] = *reinterpret_cast<const float4*>(q);
+                else v[u] = make_float4(q[0], 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (zb + u * kRedGroups < splits) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
             }
         }
     }
@@ -445,13 +535,22 @@ __global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict
     const int n = is_w ? e / F : 0, f = is_w ? e % F : (e - total);
     float a = 0.f, b = 0.f;
     if (is_w) {
-#pragma unroll 8
-        for (int z = grp; z < splits; z += kRedGroups) {
-            const float* P = partial + (size_t)z * slab;
-            const float2 top = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * N2 + 2 * f);
-            const float2 bot = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * N2 + 2 * f);
-            a += top.x - bot.y;
-            b += top.y - bot.x;
+        for (int zb = grp; zb < splits; zb += 8 * kRedGroups) {
+            float2 top[8], bot[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* P = partial + (size_t)min(zb + u * kRedGroups, splits - 1) * slab;
+                top[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * N2 + 2 * f);
+                bot[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * N2 + 2 * f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (zb + u * kRedGroups < splits) {
+                    a += top[u].x - bot[u].y;
+                    b += top[u].y - bot[u].x;
+                }
+            }
         }
     } else if (is_b) {
 #pragma unroll 8

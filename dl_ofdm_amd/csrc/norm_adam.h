@@ -37,22 +37,36 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (c4 < cols) {
         const bool vec = (c4 + 3 < cols) && ((cols & 3) == 0);
-#pragma unroll 4
-        for (int r = r0 + ty; r < r1; r += 4) {
-            const float* p = x + (size_t)r * cols + c4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (vec) {
-                const float4 t = *reinterpret_cast<const float4*>(p);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (c4 + e < cols) v[e] = p[e];
-            }
+        if (vec) {
+            // batches of 4 rows: the four 16-byte loads are issued together (clamped row + weight 0/1
+            // instead of a branch), then accumulated in row order
+            for (int rb = r0 + ty; rb < r1; rb += 16) {
+                float4 t[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double d = (double)v[e];
-                s[e] += d;
-                q[e] += d * d;
+                for (int u = 0; u < 4; ++u)
+                    t[u] = *reinterpret_cast<const float4*>(x + (size_t)min(rb + 4 * u, batch - 1) * cols + c4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (rb + 4 * u < r1) {
+                        const double d0 = t[u].x, d1 = t[u].y, d2 = t[u].z, d3 = t[u].w;
+                        s[0] += d0; q[0] += d0 * d0;
+                        s[1] += d1; q[1] += d1 * d1;
+                        s[2] += d2; q[2] += d2 * d2;
+                        s[3] += d3; q[3] += d3 * d3;
+                    }
+                }
+            }
+        } else {
+            for (int r = r0 + ty; r < r1; r += 4) {
+                const float* p = x + (size_t)r * cols + c4;
+                for (int e = 0; e < 4; ++e) {
+                    if (c4 + e < cols) {
+                        const double d = (double)p[e];
+                        s[e] += d;
+                        q[e] += d * d;
+                    }
+                }
             }
         }
     }
@@ -92,12 +106,17 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
         const int c = blockIdx.x * 256 + lin;
         float2 st = make_float2(0.f, 0.f);
         if (c < cols) {
+            // all chunk loads are issued before the first add (the sums are then formed in a fixed order)
+            double2 pv[kNormRowChunks];
+#pragma unroll
+            for (int z = 0; z < kNormRowChunks; ++z)
+                pv[z] = *reinterpret_cast<const double2*>(partial + ((size_t)z * cols + c) * 2);
+            __builtin_amdgcn_sched_barrier(0);
             double sm = 0.0, sq = 0.0;
 #pragma unroll
             for (int z = 0; z < kNormRowChunks; ++z) {
-                const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)z * cols + c) * 2);
-                sm += v.x;
-                sq += v.y;
+                sm += pv[z].x;
+                sq += pv[z].y;
             }
             const double mean = sm / (double)batch;
             double var = sq / (double)batch - mean * mean;    // biased variance; fp64, so no cancellation issue
@@ -306,10 +325,18 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
         if (full && seg4 && a.dw_slabs && i >= a.o_dw && i < a.o_dw + a.n_dw) {
             const float* q = a.dw_slabs + (i - a.o_dw);
             float4 s = *reinterpret_cast<const float4*>(q);
+            if constexpr (SPLITS > 1) {
+                float4 t[SPLITS - 1];
 #pragma unroll
-            for (int z = 1; z < splits; ++z) {
-                const float4 t = *reinterpret_cast<const float4*>(q + (size_t)z * a.n_dw);
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                for (int z = 1; z < SPLITS; ++z) t[z - 1] = *reinterpret_cast<const float4*>(q + (size_t)z * a.n_dw);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int z = 1; z < SPLITS; ++z) { s.x += t[z - 1].x; s.y += t[z - 1].y; s.z += t[z - 1].z; s.w += t[z - 1].w; }
+            } else {
+                for (int z = 1; z < splits; ++z) {
+                    const float4 t = *reinterpret_cast<const float4*>(q + (size_t)z * a.n_dw);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
             }
             g[0] = s.x; g[1] = s.y; g[2] = s.z; g[3] = s.w;
             *reinterpret_cast<float4*>(a.grad + i) = s;
