@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launch sequence instead of hipGraph replay")
-    ap.add_argument("--no-fork", action="store_true", help="single-stream graph (no concurrent dW branch)")
+    ap.add_argument("--fork", action="store_true", help="two-stream graph (dense dW on a forked stream) instead of the grouped dX+dW launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     args = ap.parse_args()
@@ -123,7 +123,7 @@ def main():
     g.manual_seed(1234 + rank)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
     eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
-    use_graph, fork = not args.no_graph, not args.no_fork
+    use_graph, fork = not args.no_graph, args.fork
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -166,7 +166,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
                    "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
-                   "launch": ("hipGraph replay" + (" (forked dW branch)" if fork else "")) if use_graph else "eager",
+                   "launch": ("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph else "eager",
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }
     if rank == 0:
@@ -179,7 +179,9 @@ def main():
             kt = time_ops(eng, iters=200, warmup=20)
             result["kernels"] = {k: {"us": round(v["ms"] * 1e3, 3), "tflops": round(v["tflops"], 2), "kernel": v["kernel"]}
                                  for k, v in kt.items()}
-            gemm = {k: v for k, v in kt.items() if v["flops"] > 0 and k != "tail_fwd_bwd"}
+            in_step = ("cconv_fwd", "dense_fwd", "dense_bwd", "cconv_bwd_w") if not fork else \
+                ("cconv_fwd", "dense_fwd", "dense_bwd_x", "dense_bwd_w", "cconv_bwd_w")
+            gemm = {k: v for k, v in kt.items() if k in in_step}
             dom = max(gemm, key=lambda k: gemm[k]["ms"])
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

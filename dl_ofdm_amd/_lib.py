@@ -75,6 +75,7 @@ SIGNATURES = {
     "dccn_dense_bwd_x": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dccn_dense_bwd_w_workspace_size": (_sz, [_i, _i, _i]),
     "dccn_dense_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_dense_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_tail_param_count": (_i, [_i]),
     "dccn_demod_tail_workspace_size": (_sz, [_ll, _i]),
     "dccn_demod_tail_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),

@@ -96,6 +96,17 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 
+static GemmParams dense_bwd_x_params(const float* dy, const float* w, float* dx, int M, int K, int N) {
+    GemmParams p = gp_zero();                 // dx[M,K] = dy[M,N] . w[K,N]^T
+    p.A = dy; p.B = w; p.C = dx;
+    p.M = M; p.N = K; p.K = N;
+    p.lda = N; p.ldb = N; p.ldc = K;
+    p.klen = round_k(N);
+    p.vecA = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
+    p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);
+    return p;
+}
+
 static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
     if (!dy || !w || !dx || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // dx[M,K] = dy[M,N] . w[K,N]^T
@@ -156,6 +167,38 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     const long long n = (long long)K * N;
     DCCN_TRY(launch_splitk_reduce(slabs, sp.splits, n, dw, n, s));
     if (dbias) DCCN_TRY(launch_splitk_reduce(cs, sp.splits, (long long)N, dbias, (long long)N, s));
+    return DCCN_OK;
+}
+
+// dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
+// (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
+// configuration does not apply (128x128 tiles, unaligned operands, single split).
+static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+                                  int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer) {
+    if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
+    const SplitPlan sp = plan_splitk(K, N, M);
+    GemmParams px = dense_bwd_x_params(dy, w, dx, M, K, N);
+    Carver c(ws, ws_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * K * N);
+    float* cs = c.take<float>((size_t)sp.splits * N);
+    GemmParams pw = gp_zero();                // dw[K,N] = x[M,K]^T . dy[M,N]
+    pw.A = x; pw.B = dy; pw.C = slabs; pw.colsum = dbias ? cs : nullptr;
+    pw.M = K; pw.N = N; pw.K = M;
+    pw.lda = K; pw.ldb = N; pw.ldc = N;
+    pw.klen = sp.klen;
+    pw.slab = (long long)K * N;
+    pw.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
+    pw.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
+    const bool vec = px.vecA && px.vecB && pw.vecA && pw.vecB;
+    if (sp.splits < 2 || !vec || !grouped_ok(px, pw, sp.splits)) {
+        DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, defer));
+        return dense_bwd_x_impl(dy, w, dx, M, K, N, s);
+    }
+    DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
+    defer->dw_slabs = slabs;
+    defer->db_slabs = dbias ? cs : nullptr;
+    defer->splits = sp.splits;
     return DCCN_OK;
 }
 
@@ -360,19 +403,21 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                        L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s));
     if (!train) return DCCN_OK;
 
-    hipStream_t sw = s;
+    DeferredSlabs ds;
     if (side) {
+        // two-stream variant: dense dW/db on `side`, dX -> C-Conv dW on the main stream
         DCCN_HIP(hipEventRecord(ev_fork, s));
         DCCN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-        sw = side;
+        DCCN_TRY(dense_bwd_w_impl(b->fft_out, b->dz, G + L.o_dense_w, G + L.o_dense_b, sh->batch, L.dK, L.dN, ws_dbw,
+                                  L.ws_dense_bw, side, &ds));
+        DCCN_HIP(hipEventRecord(ev_join, side));
+        DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
+    } else {
+        // default: dense dX and dW/db in one grouped launch (independent GEMMs packed on the same grid)
+        DCCN_TRY(dense_bwd_grouped_impl(b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_w, G + L.o_dense_b,
+                                        sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds));
     }
-    // dense dW/db  (independent of dX)
-    DeferredSlabs ds;
-    DCCN_TRY(dense_bwd_w_impl(b->fft_out, b->dz, G + L.o_dense_w, G + L.o_dense_b, sh->batch, L.dK, L.dN, ws_dbw,
-                              L.ws_dense_bw, sw, &ds));
-    if (side) DCCN_HIP(hipEventRecord(ev_join, side));
-    // dense dX -> C-Conv dW/db (the C-Conv input is data: no dX needed)
-    DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
+    // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                               L.ws_conv_bw, s));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
@@ -508,6 +553,19 @@ size_t dccn_dense_bwd_w_workspace_size(int M, int K, int N) {
 int dccn_dense_bwd_w(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* workspace,
                      size_t workspace_bytes, dccn_stream_t stream) {
     return dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dccn_dense_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias, int M, int K,
+                   int N, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DeferredSlabs ds;
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, workspace, workspace_bytes, s, &ds));
+    if (ds.dw_slabs) {
+        const long long n = (long long)K * N;
+        DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw, n, s));
+        if (dbias && ds.db_slabs) DCCN_TRY(launch_splitk_reduce(ds.db_slabs, ds.splits, (long long)N, dbias, (long long)N, s));
+    }
+    return DCCN_OK;
 }
 
 int dccn_tail_param_count(int nbits) {

@@ -231,9 +231,9 @@ constexpr size_t gemm_smem_bytes() {
 
 enum PrefetchMode : int { PF_NONE = 0, PF_FAST = 1, PF_MASKED = 2 };
 
-// TAG only makes the symbol unique per call site so profiles attribute time to the right operator
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
-__global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
+// One 64x64 / 128x128 output tile (block `L` of `T` tiles, split `z`) of C = A.B
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC>
+__device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, const int T, const int z) {
     using TA = Tile<KA, BM, BK>;
     using TB = Tile<KB, BN, BK>;
     constexpr int LDA = TA::LD, LDB = TB::LD;
@@ -252,12 +252,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmP
     const int ntn = (p.N + BN - 1) / BN;
     int tile;
     {
-        const int T = gridDim.x, L = blockIdx.x;
         const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int kbeg = blockIdx.z * p.klen;
+    const int kbeg = z * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     const int nfull = VEC ? (kend - kbeg) / BK : 0;     // k-tiles the fast loader may fetch
@@ -382,7 +381,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmP
     if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cz = p.C + (size_t)blockIdx.z * p.slab;
+    float* Cz = p.C + (size_t)z * p.slab;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -406,7 +405,29 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmP
     }
     if (COLSUM && do_cs) {
         const int col = n0 + tid;
-        if (col < p.N) p.colsum[(size_t)blockIdx.z * p.N + col] = cs;
+        if (col < p.N) p.colsum[(size_t)z * p.N + col] = cs;
+    }
+}
+
+// TAG only makes the symbol unique per call site so profiles attribute time to the right operator
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
+__global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
+    gemm_block<KA, KB, BM, BN, BK, COLSUM, VEC>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+}
+
+// Two independent GEMMs in ONE grid (the dense layer's dX = dY.W^T and dW = X^T.dY share dY but not
+// their outputs): blocks [0, nx) run problem X (the longer k-loops first), the rest run problem W's
+// tiles x splits.  ~830 blocks of mixed length pack the 256 CUs far better than 266 and 560 blocks in
+// two launches (each of which ends with a mostly idle chip).
+template <int BM, int BN, int BK, bool VEC>
+__global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_kernel(const GemmParams px, const GemmParams pw,
+                                                                         const int nx, const int tw) {
+    const int b = (int)blockIdx.x;
+    if (b < nx) {
+        gemm_block<OP_KCONTIG, OP_KCONTIG, BM, BN, BK, 0, VEC>(px, b, nx, 0);
+    } else {
+        const int c = b - nx;
+        gemm_block<OP_ICONTIG, OP_ICONTIG, BM, BN, BK, 1, VEC>(pw, c % tw, tw, c / tw);
     }
 }
 
@@ -433,6 +454,30 @@ static int launch_gemm_cfg(const GemmParams& p, int splits, hipStream_t s) {
     const bool vec = p.vecA && p.vecB;
     if (vec) return launch_gemm_cfg2<KA, KB, BM, BN, BK, COLSUM, TAG, true>(p, splits, s);
     return launch_gemm_cfg2<KA, KB, BM, BN, BK, COLSUM, TAG, false>(p, splits, s);
+}
+
+template <bool VEC>
+static int launch_dense_bwd_grouped(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
+    constexpr int BM = 64, BN = 64, BK = 64;
+    auto kern = dense_bwd_grouped_kernel<BM, BN, BK, VEC>;
+    constexpr size_t smem = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, BM, BN, BK>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+        attr_done = true;
+    }
+    const int nx = ceil_div(px.N, BN) * ceil_div(px.M, BM);
+    const int tw = ceil_div(pw.N, BN) * ceil_div(pw.M, BM);
+    hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+static inline bool grouped_ok(const GemmParams& px, const GemmParams& pw, int splits_w) {
+    // only worth it (and only instantiated) for the 64x64x64 configuration
+    const long long bigx = (long long)ceil_div(px.M, 128) * ceil_div(px.N, 128);
+    const long long bigw = (long long)ceil_div(pw.M, 128) * ceil_div(pw.N, 128) * splits_w;
+    return bigx < 2 * kCUs && bigw < 2 * kCUs;
 }
 
 // tile choice: 128x128x32 (four accumulators per wave) only when it still yields >= 2 blocks per CU,

@@ -159,7 +159,7 @@ class RxEngine:
         self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
         self.bits.copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
 
-    def train_step(self, x=None, bits=None, graph: bool = False, fork: bool = True):
+    def train_step(self, x=None, bits=None, graph: bool = False, fork: bool = False):
         if not self.train:
             raise _lib.DccnError("engine built with train=False")
         if x is not None:
@@ -286,6 +286,10 @@ def op_launchers(eng: RxEngine):
             eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(G, "demodulation/dense/kernel"),
             seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
             2.0 * B * dK * dN, "gemm<dense_bwd_w>+reduce"),
+        "dense_bwd": (lambda: lib.dccn_dense_bwd(
+            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
+            seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
+            4.0 * B * dK * dN, "dense_bwd_grouped(dX+dW)+reduce"),
         "cconv_bwd_w": (lambda: lib.dccn_cconv_gemm_bwd_w(
             eng.x_norm.data_ptr(), eng.dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
             seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),

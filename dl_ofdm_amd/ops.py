@@ -181,10 +181,19 @@ class _Dense(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[1]
         dx = dw = db = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[0] and need_w:            # both gradients: one grouped launch
+            dx, dw = torch.empty_like(x), torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_dense_bwd_w_workspace_size(M, K, N)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_dense_bwd(_p(x), _p(dy), _p(w), _p(dx), _p(dw), _p(db), M, K, N, _p(ws), nws, _stream()),
+                  "dccn_dense_bwd")
+            return dx, dw, db
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             check(lib.dccn_dense_bwd_x(_p(dy), _p(w), _p(dx), M, K, N, _stream()), "dccn_dense_bwd_x")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if need_w:
             dw = torch.empty_like(w)
             db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             nws = lib.dccn_dense_bwd_w_workspace_size(M, K, N)

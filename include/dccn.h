@@ -93,6 +93,12 @@ int dccn_dense_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                      int M, int K, int N,
                      void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 
+/* both gradients of the dense layer in ONE grouped launch (dx = dy.w^T and dw = x^T.dy are independent
+ * GEMMs that share dy; packing their blocks on one grid fills the CUs far better than two launches);
+ * workspace as dccn_dense_bwd_w_workspace_size(M,K,N). */
+int dccn_dense_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+                   int M, int K, int N, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 /* ---- R3-R6: demodulation tail + loss + BER ----------------------------------------
  * dev/py/model.py:1278-1291 (1x1 conv2d 2->m, leaky-ReLU 0.2, concat, dense (m+2)->2b,
  * leaky-ReLU, softmax over bit pairs), dev/py/ofdmreceiver_np.py:154-169 (one_hot,
