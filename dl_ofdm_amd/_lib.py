@@ -76,6 +76,7 @@ SIGNATURES = {
     "dccn_dense_bwd_w_workspace_size": (_sz, [_i, _i, _i]),
     "dccn_dense_bwd_w": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_dense_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_dense_bwd_slabs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, POINTER(c_int), _vp]),
     "dccn_tail_param_count": (_i, [_i]),
     "dccn_demod_tail_workspace_size": (_sz, [_ll, _i]),
     "dccn_demod_tail_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),

@@ -568,6 +568,15 @@ int dccn_dense_bwd(const float* x, const float* dy, const float* w, float* dx, f
     return DCCN_OK;
 }
 
+int dccn_dense_bwd_slabs(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias, int M,
+                         int K, int N, void* workspace, size_t workspace_bytes, int* splits, dccn_stream_t stream) {
+    DeferredSlabs ds;
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, workspace, workspace_bytes, (hipStream_t)stream,
+                                    &ds));
+    if (splits) *splits = ds.dw_slabs ? ds.splits : 1;
+    return DCCN_OK;
+}
+
 int dccn_tail_param_count(int nbits) {
     if (nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
     return tail_param_count(nbits);

@@ -290,6 +290,10 @@ def op_launchers(eng: RxEngine):
             eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
             seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
             4.0 * B * dK * dN, "dense_bwd_grouped(dX+dW)+reduce"),
+        "dense_bwd_slabs": (lambda: lib.dccn_dense_bwd_slabs(
+            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
+            seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, None,
+            s()), 4.0 * B * dK * dN, "dense_bwd_grouped_kernel"),
         "cconv_bwd_w": (lambda: lib.dccn_cconv_gemm_bwd_w(
             eng.x_norm.data_ptr(), eng.dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
             seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),

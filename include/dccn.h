@@ -99,6 +99,14 @@ int dccn_dense_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
 int dccn_dense_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                    int M, int K, int N, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 
+/* the same grouped launch, stopping before the split-K reduction: dx is final, the weight gradient is left
+ * as `*splits` slabs [splits][K*N] at the start of the workspace (bias slabs [splits][N] follow, 256-byte
+ * aligned) -- this is the stage the fused training step runs (its Adam kernel sums the slabs).
+ * `splits` is a host out-parameter (1 = dw/dbias were written directly). */
+int dccn_dense_bwd_slabs(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+                         int M, int K, int N, void* workspace, size_t workspace_bytes, int* splits,
+                         dccn_stream_t stream);
+
 /* ---- R3-R6: demodulation tail + loss + BER ----------------------------------------
  * dev/py/model.py:1278-1291 (1x1 conv2d 2->m, leaky-ReLU 0.2, concat, dense (m+2)->2b,
  * leaky-ReLU, softmax over bit pairs), dev/py/ofdmreceiver_np.py:154-169 (one_hot,
