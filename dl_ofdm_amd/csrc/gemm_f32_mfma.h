@@ -495,7 +495,9 @@ struct SplitPlan {
 };
 static inline SplitPlan plan_splitk(int M, int N, int K) {
     const long long tiles = (long long)ceil_div(M, 64) * ceil_div(N, 64);
-    long long want = (2LL * kCUs + tiles - 1) / tiles;          // ~2 blocks per CU
+    // ~2 blocks per CU when the output has many tiles; exactly one round of blocks when it has few
+    // (then every block is short and a second, partial round would double the kernel time)
+    long long want = tiles >= 32 ? (2LL * kCUs + tiles - 1) / tiles : (long long)kCUs / tiles;
     const long long max_splits = (K + 127) / 128;               // >= 4 k-tiles per split
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

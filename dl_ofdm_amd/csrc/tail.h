@@ -96,16 +96,21 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float u0 = leaky_relu(pre2[2 * j]), u1 = leaky_relu(pre2[2 * j + 1]);
-            const float mx = fmaxf(u0, u1);
-            const float e0 = expf(u0 - mx), e1 = expf(u1 - mx);
+            // softmax over the pair: exp(u - max) is exactly 1 for the larger logit, so one expf suffices
+            // (bit-identical to evaluating both); likewise for the second softmax on the probabilities
+            const bool u1_big = u1 > u0;
+            const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
+            const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
             const float es = e0 + e1;
             const float p0 = e0 / es, p1 = e1 / es;
             if (prob != nullptr)
                 *reinterpret_cast<float2*>(prob + (cell * NB + j) * 2) = make_float2(p0, p1);
             const int label = cur.lab[j];
             // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
-            const float mx2 = fmaxf(p0, p1);
-            const float f0 = expf(p0 - mx2), f1 = expf(p1 - mx2);
+            const bool p1_big = p1 > p0;
+            const float mx2 = p1_big ? p1 : p0;
+            const float fo = expf(p1_big ? (p0 - p1) : (p1 - p0));
+            const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
             const float fs = f0 + f1;
             const float lse = logf(fs) + mx2;
             ce_acc += (double)(lse - (label ? p1 : p0));
