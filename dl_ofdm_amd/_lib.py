@@ -95,6 +95,16 @@ SIGNATURES = {
     "dccn_timer_elapsed_ms": (_i, [_vp, POINTER(c_float)]),
     "dccn_timer_destroy": (_i, [_vp]),
     "dccn_stream_synchronize": (_i, [_vp]),
+    # equaliser stage
+    "dccn_layer_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dccn_layer_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "dccn_tanh_fwd": (_i, [_vp, _vp, _ll, _vp]),
+    "dccn_tanh_bwd": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "dccn_equalize_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    "dccn_equalize_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "dccn_pilot_snr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dccn_cconv2d_same_expand": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dccn_cconv2d_same_reduce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

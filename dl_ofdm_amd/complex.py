@@ -186,6 +186,11 @@ def _cconv_lower(x5: torch.Tensor, filters: int, ksize, strides, padding: str, s
     kern = scope.get(name + "/kernel", (len(tl), len(tw), C, 2 * filters), fan_in=kvol * C, fan_out=kvol * 2 * filters,
                      meta=dict(tf_shape=tuple(tf_kernel_shape), live_taps=(tuple(tl), tuple(tw))))
     bias = scope.get(name + "/bias", (2 * filters,), zeros=True)
+    if (C == 1 and filters == 1 and (sL, sW) == (1, 1) and padding.lower() == "same" and len(tl) == kL
+            and len(tw) == kW and kvol >= 64 and L * Wd * 2 <= 4096):
+        # big one-channel 'same' kernel (equaliser smoothing conv, model.py:428): im2col would blow the
+        # image up kL*kW-fold, so run it as a block-Toeplitz dense layer instead
+        return ops.cconv2d_same(x5[:, :, :, 0, :], kern.view(kL, kW, 2), bias).view(B, L, Wd, 1, 2)
     g = _gather_axis(x5, 1, L, tl, sL, Lo, pl0)                        # [B, Lo, tl, Wd, C, 2]
     g = _gather_axis(g, 3, Wd, tw, sW, Wo, pw0)                          # [B, Lo, tl, Wo, tw, C, 2]
     g = g.permute(0, 1, 3, 2, 4, 5, 6)                                   # [B, Lo, Wo, tl, tw, C, 2]

@@ -8,6 +8,7 @@
 #include "gemm_f32_mfma.h"
 #include "norm_adam.h"
 #include "tail.h"
+#include "equalizer.h"
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
@@ -717,6 +718,83 @@ int dccn_timer_destroy(dccn_timer* t) {
 }
 int dccn_stream_synchronize(dccn_stream_t stream) {
     DCCN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DCCN_OK;
+}
+
+// ---- equaliser stage operators ------------------------------------------------------------------
+static inline unsigned ew_blocks(long long n) {
+    long long b = ceil_div_ll(n, 256);
+    if (b > 8 * kCUs) b = 8 * kCUs;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+int dccn_layer_norm_fwd(const float* x, float* y, float* mean, float* inv, int rows, int cols, float eps,
+                        dccn_stream_t stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, y, mean, inv, cols,
+                       eps);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_layer_norm_bwd(const float* dy, const float* y, const float* inv, float* dx, int rows, int cols,
+                        dccn_stream_t stream) {
+    if (!dy || !y || !inv || !dx || rows <= 0 || cols <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, y, inv, dx, cols);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_tanh_fwd(const float* x, float* y, long long n, dccn_stream_t stream) {
+    if (!x || !y || n <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_tanh_bwd(const float* dy, const float* y, float* dx, long long n, dccn_stream_t stream) {
+    if (!dy || !y || !dx || n <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_equalize_fwd(const float* y, const float* h, float* eq, float* corr, long long n_pairs,
+                      dccn_stream_t stream) {
+    if (!y || !h || !eq || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)y, (const float2*)h, (float2*)eq, (float2*)corr, n_pairs);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_equalize_bwd(const float* y, const float* h, const float* d_eq, const float* d_corr, float* dy, float* dh,
+                      long long n_pairs, dccn_stream_t stream) {
+    if (!y || !h || (!d_eq && !d_corr) || (!dy && !dh) || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(equalize_bwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)y, (const float2*)h, (const float2*)d_eq, (const float2*)d_corr, (float2*)dy,
+                       (float2*)dh, n_pairs);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_pilot_snr(const float* eq, const int* carriers, float* snr_db, int frames, int S, int K, int P,
+                   dccn_stream_t stream) {
+    if (!eq || !carriers || !snr_db || frames <= 0 || S <= 0 || K <= 0 || P <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pilot_snr_kernel, dim3(frames), dim3(64), 0, (hipStream_t)stream, (const float2*)eq, carriers,
+                       snr_db, S, K, P);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_cconv2d_same_expand(const float* w, const float* bias, float* T, float* bias_eff, int L, int W, int kL,
+                             int kW, dccn_stream_t stream) {
+    if (!w || !T || L <= 0 || W <= 0 || kL <= 0 || kW <= 0) return DCCN_ERR_INVALID_ARG;
+    const long long n = (long long)L * W * 2;
+    if (n * n > (1LL << 31)) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks(n * n)), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       T, bias_eff, L, W, kL, kW);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw, float* dbias, int L, int W, int kL,
+                             int kW, dccn_stream_t stream) {
+    if (!dT || !dw || L <= 0 || W <= 0 || kL <= 0 || kW <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(kL * kW + 1), dim3(64), 0, (hipStream_t)stream, dT, dbias_eff,
+                       dw, dbias, L, W, kL, kW);
+    DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 

@@ -1,0 +1,222 @@
+// Element-wise and small-reduction kernels of the channel-equaliser stage (SURVEY.md 8(f-1);
+// dev/py/model.py:349-478).  The stage's GEMM-shaped layers reuse gemm_f32_mfma.h (dense,
+// C-Conv); what is new here is everything around them.  All of it is HBM/latency-bound: one pass
+// over the data, float2 (IQ pair) accesses, DPP wave reductions.
+#pragma once
+#include "common.h"
+
+namespace dccn {
+
+// sum over a 256-thread block, result in every thread; `sh` holds >= 4 elements
+template <typename T>
+__device__ __forceinline__ T block_sum_256(T v, T* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// tf.contrib.layers.layer_norm(center=False, scale=False, begin_norm_axis=1) (model.py:363):
+// one block per sample; two-pass moments (mean, then mean of squared differences), then
+// tf.nn.batch_normalization's  x*inv + (-mean*inv).
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             float* __restrict__ mean_out,
+                                                             float* __restrict__ inv_out, int cols, float eps) {
+    __shared__ float sh[4];
+    const float* xr = x + (size_t)blockIdx.x * cols;
+    float* yr = y + (size_t)blockIdx.x * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += xr[c];
+    const float mean = block_sum_256(s, sh) / (float)cols;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float d = xr[c] - mean;
+        q += d * d;
+    }
+    const float var = block_sum_256(q, sh) / (float)cols;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float shift = -mean * inv;
+    for (int c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] * inv + shift;
+    if (threadIdx.x == 0) {
+        if (mean_out) mean_out[blockIdx.x] = mean;
+        if (inv_out) inv_out[blockIdx.x] = inv;
+    }
+}
+
+// dx = inv * (dy - mean(dy) - y * mean(dy*y))   (y = normalised output)
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ inv, float* __restrict__ dx,
+                                                             int cols) {
+    __shared__ float sh[4];
+    const size_t base = (size_t)blockIdx.x * cols;
+    float s = 0.f, t = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float g = dy[base + c];
+        s += g;
+        t += g * y[base + c];
+    }
+    const float m1 = block_sum_256(s, sh) / (float)cols;
+    const float m2 = block_sum_256(t, sh) / (float)cols;
+    const float iv = inv[blockIdx.x];
+    for (int c = threadIdx.x; c < cols; c += 256) dx[base + c] = iv * (dy[base + c] - m1 - y[base + c] * m2);
+}
+
+// activation=tf.nn.tanh of the channel-estimate dense layer (model.py:421-426)
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dx, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = y[i];
+        dx[i] = dy[i] * (1.0f - v * v);
+    }
+}
+
+// model.py:431-438: eq = y * conj(h)/|h|,  corr = eq * conj(eq)   (IQ pairs as float2)
+__global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                           float2* __restrict__ eq, float2* __restrict__ corr,
+                                                           long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float2 yv = y[i], hv = h[i];
+        const float a = sqrtf(hv.x * hv.x + hv.y * hv.y);
+        const float cr = hv.x / a, ci = (-hv.y) / a;
+        const float er = yv.x * cr - yv.y * ci;
+        const float ei = yv.x * ci + yv.y * cr;
+        eq[i] = make_float2(er, ei);
+        if (corr) corr[i] = make_float2(er * er - ei * (-ei), er * (-ei) + ei * er);
+    }
+}
+
+// real-valued backward of the pair above; d_corr may be null.  corr = (er^2+ei^2, 0), so only its
+// real cotangent reaches eq.
+__global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                           const float2* __restrict__ d_eq,
+                                                           const float2* __restrict__ d_corr, float2* __restrict__ dy,
+                                                           float2* __restrict__ dh, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float2 yv = y[i], hv = h[i];
+        const float a = sqrtf(hv.x * hv.x + hv.y * hv.y);
+        const float cr = hv.x / a, ci = (-hv.y) / a;
+        const float er = yv.x * cr - yv.y * ci;
+        const float ei = yv.x * ci + yv.y * cr;
+        float2 g = d_eq ? d_eq[i] : make_float2(0.f, 0.f);
+        if (d_corr) {
+            const float gc = d_corr[i].x;
+            g.x += 2.0f * er * gc;
+            g.y += 2.0f * ei * gc;
+        }
+        if (dy) dy[i] = make_float2(g.x * cr + g.y * ci, g.y * cr - g.x * ci);
+        if (dh) {
+            const float dcr = g.x * yv.x + g.y * yv.y;
+            const float dci = g.y * yv.x - g.x * yv.y;
+            const float da = -(dcr * cr + dci * ci) / a;        // through 1/|h|
+            // cr = hr/a, ci = -hi/a, a = |h|:  d hr = dcr/a + da*hr/a,  d hi = -dci/a + da*hi/a
+            dh[i] = make_float2(dcr / a + da * cr, -dci / a - da * ci);
+        }
+    }
+}
+
+// model.py:465-475 pilot "SNR" monitor: log10(clip(mean/var of |pilot|^2 over the frame's pilot
+// cells)).  One wave per frame.
+__global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict__ eq, const int* __restrict__ carriers,
+                                                       float* __restrict__ snr_db, int S, int K, int P) {
+    const float2* f = eq + (size_t)blockIdx.x * S * K;
+    const int n = S * P;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float2 v = f[(i / P) * K + carriers[i % P]];
+        s += v.x * v.x + v.y * v.y;
+    }
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float2 v = f[(i / P) * K + carriers[i % P]];
+        const float d = (v.x * v.x + v.y * v.y) - mean;
+        q += d * d;
+    }
+    const float var = wave_sum(q) / (float)n;
+    const float ratio = fminf(fmaxf(mean / var, 0.001f), 10000.0f);
+    if (threadIdx.x == 0) snr_db[blockIdx.x] = logf(ratio) / logf(10.0f);
+}
+
+// ---- one-channel, one-filter complex "same" convolution as a dense layer ---------------------
+// layers_conv2d_complex(chest, 1, (n_sym, K), padding='same') (model.py:428) slides a kL x kW
+// complex kernel over an L x W complex image with TF's SAME zero padding.  At L x W = 7 x 64 the
+// im2col matrix would be 448x the image, so instead the kernel is expanded ONCE per step into the
+// block-Toeplitz matrix T [L*W*2, L*W*2] of the equivalent dense layer (row = input cell/IQ,
+// column = output cell/re-im) and the layer runs on the MFMA dense GEMM.  Entry for input (s',k')
+// and output (s,k): tap (a,b) = (s'-s+padL, k'-k+padW) if inside the kernel, else 0, with the
+// C-Conv sign pattern  [I->re]=Wa [I->im]=Wb [Q->re]=-Wb [Q->im]=-Wa  (complex.py:185-188).
+__global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* __restrict__ w,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ T, float* __restrict__ bias_eff,
+                                                                  int L, int W, int kL, int kW) {
+    const int n = L * W * 2;
+    const int padL = (kL - 1) / 2, padW = (kW - 1) / 2;
+    const long long total = (long long)n * n;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int row = (int)(i / n), col = (int)(i % n);
+        const int iq = row & 1, kp = (row >> 1) % W, sp = (row >> 1) / W;
+        const int ri = col & 1, k = (col >> 1) % W, s = (col >> 1) / W;
+        const int a = sp - s + padL, b = kp - k + padW;
+        float v = 0.f;
+        if (a >= 0 && a < kL && b >= 0 && b < kW) {
+            const float wa = w[(a * kW + b) * 2], wb = w[(a * kW + b) * 2 + 1];
+            v = iq == 0 ? (ri == 0 ? wa : wb) : (ri == 0 ? -wb : -wa);
+        }
+        T[i] = v;
+        if (bias_eff && i < n) {
+            const float d = bias ? bias[0] - bias[1] : 0.f;
+            bias_eff[i] = (i & 1) ? -d : d;
+        }
+    }
+}
+
+// transpose of the expansion: one wave per tap gathers its diagonal of dT; wave kL*kW reduces the
+// bias cotangent.
+__global__ __launch_bounds__(64) void cconv2d_same_reduce_kernel(const float* __restrict__ dT,
+                                                                 const float* __restrict__ dbias_eff,
+                                                                 float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 int L, int W, int kL, int kW) {
+    const int n = L * W * 2;
+    const int padL = (kL - 1) / 2, padW = (kW - 1) / 2;
+    const int tap = blockIdx.x;
+    if (tap == kL * kW) {
+        if (!dbias) return;
+        float d = 0.f;
+        if (dbias_eff)
+            for (int c = threadIdx.x; c < L * W; c += 64) d += dbias_eff[2 * c] - dbias_eff[2 * c + 1];
+        d = wave_sum(d);
+        if (threadIdx.x == 0) {
+            dbias[0] = d;
+            dbias[1] = -d;
+        }
+        return;
+    }
+    const int a = tap / kW, b = tap % kW;
+    float ga = 0.f, gb = 0.f;
+    for (int c = threadIdx.x; c < L * W; c += 64) {
+        const int s = c / W, k = c % W;
+        const int sp = s + a - padL, kp = k + b - padW;
+        if (sp < 0 || sp >= L || kp < 0 || kp >= W) continue;
+        const size_t r0 = (size_t)((sp * W + kp) * 2) * n + (size_t)c * 2;
+        ga += dT[r0] - dT[r0 + n + 1];          // d/dWa: (I->re) - (Q->im)
+        gb += dT[r0 + 1] - dT[r0 + n];          // d/dWb: (I->im) - (Q->re)
+    }
+    ga = wave_sum(ga);
+    gb = wave_sum(gb);
+    if (threadIdx.x == 0) {
+        dw[tap * 2] = ga;
+        dw[tap * 2 + 1] = gb;
+    }
+}
+
+}  // namespace dccn

@@ -81,6 +81,67 @@ def ofdm_dense_rx(inputs: torch.Tensor, FLAGS, ofdmobj, outshape=None, *, scope:
     return prob, ce, mbuf, fft_out
 
 
+def _dense_layer(inputs: torch.Tensor, units: int, *, scope: VariableStore, activation=None) -> torch.Tensor:
+    out = layers_dense(inputs, units, scope=scope)
+    return activation(out) if activation is not None else out
+
+
+def equalizer_ofdm(inputs: torch.Tensor, FLAGS, ofdmobj, *, scope: VariableStore):
+    """DCCN channel equaliser (model.py:349-478): layer-norm -> dense -> C-Conv "DFT" -> pilot
+    bottleneck (dense x4, tanh on the last) -> (n_sym x K) smoothing C-Conv = channel estimate ->
+    eq = y * conj(h)/|h| -> C-Conv "IDFT" of eq and of its autocorrelation -> dense back to the
+    receiver's input shape.
+
+    inputs [batch, n_sym, n_sc, 2] (`input:0`); returns (equalized [batch, n_sym, n_sc, 2],
+    snr_db [batch, 1], chest complex64 [batch, n_sym, K]) like the reference.  Variables are created
+    under the caller's scope in TF's order: dense, conv3d, dense_1..dense_4, conv3d_1, conv3d_2,
+    conv3d_3, dense_5 (all dense layers carry l2(0.01) on kernel and bias -- see
+    :func:`regularization_loss`)."""
+    K, CP = ofdmobj.K, ofdmobj.CP
+    pilot_size = ofdmobj.pilot_size
+    pilotCarriers = np.asarray(ofdmobj.pilotCarriers).astype(np.int32)
+    _, n_sym, n_sc, m_iq = inputs.shape
+    chest = ops.layer_norm(inputs)                                              # :363
+    if not FLAGS.cp:
+        chest = chest[:, :, CP:CP + K, :].reshape(-1, n_sym, K * m_iq)          # :365-366
+    else:
+        chest = chest.reshape(-1, n_sym, n_sc * m_iq)                           # :368
+    chest = _dense_layer(chest, K * m_iq, scope=scope)                          # :369-375
+    chest = chest.reshape(-1, n_sym, K, 1, m_iq)                                # :377
+    chest = layers_conv2d_complex(chest, K, (1, K), strides=1, padding="valid", scope=scope)   # :378
+    chest = chest.permute(0, 1, 3, 2, 4)                                        # :379 [B,S,K,1,2]
+    inputs_iq = chest.reshape(-1, n_sym, K, m_iq)                               # inputs_complex (:382-386)
+    chest = chest.reshape(-1, n_sym * K * m_iq)                                 # :392
+    chest = _dense_layer(chest, pilot_size * m_iq, scope=scope)                 # :394 pilot extraction
+    chest = _dense_layer(chest, n_sym * K * m_iq, scope=scope)                  # :402
+    chest = _dense_layer(chest, n_sym * K * m_iq, scope=scope)                  # :408
+    chest = _dense_layer(chest, n_sym * K * m_iq, scope=scope, activation=ops.tanh)   # :421
+    chest = chest.reshape(-1, n_sym, K, 1, m_iq)
+    chest = layers_conv2d_complex(chest, 1, (n_sym, K), strides=(1, 1), padding="same", scope=scope)   # :428
+    chest_iq = chest.reshape(-1, n_sym, K, m_iq)                                # :429-430
+    equalized_freq, corr = ops.equalize(inputs_iq, chest_iq)                    # :432-438
+    corr = layers_conv2d_complex(corr.reshape(-1, n_sym, K, 1, m_iq), K, (1, K), strides=1, padding="valid",
+                                 scope=scope)                                   # :439 [B,S,1,K,2]
+    corr_re = corr.reshape(-1, n_sym, K, m_iq)                                  # :440-441 (transpose of a size-1 axis)
+    eq = layers_conv2d_complex(equalized_freq.reshape(-1, n_sym, K, 1, m_iq), K, (1, K), strides=1,
+                               padding="valid", scope=scope)                    # :443
+    equalized = eq.reshape(-1, n_sym, K, m_iq)                                  # :444-449
+    equal_corr = torch.cat([equalized, corr_re], dim=-1)                        # :456
+    equalized = equal_corr.reshape(-1, n_sym, K * (2 * m_iq))                   # :457
+    equalized = _dense_layer(equalized, n_sc * m_iq, scope=scope)               # :458-462
+    equalized = equalized.reshape(-1, n_sym, n_sc, m_iq)                        # :463
+    snr_db = ops.pilot_snr(equalized_freq, pilotCarriers)                       # :465-475
+    chest_c = torch.complex(chest_iq[..., 0].detach(), chest_iq[..., 1].detach())   # :477
+    return equalized, snr_db, chest_c
+
+
+def regularization_loss(scope: VariableStore, prefix: str = "", l: float = 0.01) -> torch.Tensor:
+    """sum of tf.keras.regularizers.l2(l) over every dense kernel/bias under ``prefix`` -- the
+    REGULARIZATION_LOSSES collection of the reference graph (only tf.layers.dense carries one)."""
+    terms = [scope.tensor(n) for n in scope.names() if n.startswith(prefix) and "/dense" in "/" + n]
+    return l * sum((t * t).sum() for t in terms)
+
+
 class OfdmDenseRx(torch.nn.Module):
     """The basic-receiver graph of dev/py/ofdmreceiver_np.py:121-171 as a module over the layer API:
     batch-moment normalisation -> complex_clip monitor -> ofdm_dense_rx -> loss / BER."""

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -279,3 +280,137 @@ def demod_tail_loss(z: torch.Tensor, tailp: torch.Tensor, bits: torch.Tensor, nb
 def demod_tail_eval(z, tailp, bits, nbits, want_prob=True):
     with torch.no_grad():
         return demod_tail_loss(z, tailp, bits, nbits, want_prob)
+
+
+# ---- equaliser stage (model.py:349-478) --------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _need_cuda(x); _f32(x)
+        lib = _lib.load()
+        rows, cols = x.shape[0], x.numel() // x.shape[0]
+        y = torch.empty_like(x)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.dccn_layer_norm_fwd(_p(x), _p(y), None, _p(inv), rows, cols, eps, _stream()), "dccn_layer_norm_fwd")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        rows, cols = y.shape[0], y.numel() // y.shape[0]
+        check(lib.dccn_layer_norm_bwd(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _stream()), "dccn_layer_norm_bwd")
+        return dx, None
+
+
+def layer_norm(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """tf.contrib.layers.layer_norm(x, center=False, scale=False, begin_norm_axis=1) (model.py:363):
+    per-sample moments over every non-batch axis."""
+    if x.dim() < 2:
+        raise TypeError("layer_norm: expected [batch, ...]")
+    return _LayerNorm.apply(x.contiguous(), float(eps))
+
+
+class _Tanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x); _f32(x)
+        y = torch.empty_like(x)
+        check(_lib.load().dccn_tanh_fwd(_p(x), _p(y), x.numel(), _stream()), "dccn_tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(_lib.load().dccn_tanh_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "dccn_tanh_bwd")
+        return dx
+
+
+def tanh(x: torch.Tensor) -> torch.Tensor:
+    """tf.nn.tanh (activation of the channel-estimate dense layer, model.py:421-426)."""
+    return _Tanh.apply(x.contiguous())
+
+
+class _Equalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, h):
+        _need_cuda(y, h); _f32(y, h)
+        eq, corr = torch.empty_like(y), torch.empty_like(y)
+        check(_lib.load().dccn_equalize_fwd(_p(y), _p(h), _p(eq), _p(corr), y.numel() // 2, _stream()),
+              "dccn_equalize_fwd")
+        ctx.save_for_backward(y, h)
+        return eq, corr
+
+    @staticmethod
+    def backward(ctx, d_eq, d_corr):
+        y, h = ctx.saved_tensors
+        d_eq = None if d_eq is None else d_eq.contiguous()
+        d_corr = None if d_corr is None else d_corr.contiguous()
+        dy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        dh = torch.empty_like(h) if ctx.needs_input_grad[1] else None
+        if dy is None and dh is None:
+            return None, None
+        check(_lib.load().dccn_equalize_bwd(_p(y), _p(h), _p(d_eq), _p(d_corr), _p(dy), _p(dh), y.numel() // 2,
+                                            _stream()), "dccn_equalize_bwd")
+        return dy, dh
+
+
+def equalize(y: torch.Tensor, h: torch.Tensor):
+    """model.py:431-438 on IQ-pair tensors [..., 2]: (eq, corr) = (y*conj(h)/|h|, eq*conj(eq))."""
+    if y.shape != h.shape or y.shape[-1] != 2:
+        raise TypeError("equalize: y and h must both be [..., 2]")
+    return _Equalize.apply(y.contiguous(), h.contiguous())
+
+
+def pilot_snr(eq_freq: torch.Tensor, pilot_carriers) -> torch.Tensor:
+    """model.py:465-475 monitor: eq_freq [B,S,K,2] -> log10(clip(mean/var of |pilot|^2)) [B,1]."""
+    _need_cuda(eq_freq); _f32(eq_freq)
+    B, S, K, _ = eq_freq.shape
+    car = torch.as_tensor(np.asarray(pilot_carriers, dtype=np.int32), device=eq_freq.device)
+    out = torch.empty(B, 1, dtype=torch.float32, device=eq_freq.device)
+    eqc = eq_freq.detach().contiguous()
+    check(_lib.load().dccn_pilot_snr(_p(eqc), _p(car), _p(out), B, S, K, int(car.numel()), _stream()),
+          "dccn_pilot_snr")
+    return out
+
+
+class _SameConvExpand(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, bias, L, W):
+        _need_cuda(w, bias); _f32(w, bias)
+        kL, kW, _ = w.shape
+        n = L * W * 2
+        T = torch.empty(n, n, dtype=torch.float32, device=w.device)
+        be = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(_lib.load().dccn_cconv2d_same_expand(_p(w), _p(bias), _p(T), _p(be), L, W, kL, kW, _stream()),
+              "dccn_cconv2d_same_expand")
+        ctx.geom = (L, W, kL, kW, bias is not None)
+        return T, be
+
+    @staticmethod
+    def backward(ctx, dT, dbe):
+        L, W, kL, kW, has_bias = ctx.geom
+        dT = dT.contiguous()
+        dbe = None if dbe is None else dbe.contiguous()
+        dw = torch.empty(kL, kW, 2, dtype=torch.float32, device=dT.device)
+        db = torch.empty(2, dtype=torch.float32, device=dT.device) if has_bias else None
+        check(_lib.load().dccn_cconv2d_same_reduce(_p(dT), _p(dbe), _p(dw), _p(db), L, W, kL, kW, _stream()),
+              "dccn_cconv2d_same_reduce")
+        return dw, db, None, None
+
+
+def cconv2d_same(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """One-channel, one-filter ``layers_conv2d_complex(x, 1, (kL,kW), padding='same')`` (model.py:428):
+    x [B,L,W,2], w [kL,kW,2] (= TF kernel [kL,kW,1,1,2]), bias [2] -> [B,L,W,2].  The kernel is expanded
+    into the block-Toeplitz matrix of the equivalent dense layer and run on the MFMA dense GEMM."""
+    if x.dim() != 4 or x.shape[-1] != 2 or w.dim() != 3 or w.shape[-1] != 2:
+        raise TypeError("cconv2d_same: x [B,L,W,2], w [kL,kW,2]")
+    B, L, W, _ = x.shape
+    T, be = _SameConvExpand.apply(w.contiguous(), None if bias is None else bias.contiguous(), L, W)
+    return dense(x.reshape(B, L * W * 2), T, be).view(B, L, W, 2)

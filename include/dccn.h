@@ -227,6 +227,44 @@ int dccn_timer_elapsed_ms(dccn_timer* t, float* ms);     /* synchronises on the 
 int dccn_timer_destroy(dccn_timer* t);
 int dccn_stream_synchronize(dccn_stream_t stream);
 
+/* ==== channel-equaliser stage: dev/py/model.py:349-478 =====================
+ * The stage's dense / C-Conv layers use dccn_dense_* / dccn_cconv_gemm_* above; these are the
+ * remaining operators.  All tensors fp32, IQ pairs interleaved on the last axis. */
+
+/* model.py:363  tf.contrib.layers.layer_norm(center=False, scale=False, begin_norm_axis=1):
+ * per-row (sample) y = x*inv + (-mean*inv), inv = rsqrt(var + eps), biased variance over `cols`.
+ * mean, inv [rows] nullable (inv is what dccn_layer_norm_bwd needs). */
+int dccn_layer_norm_fwd(const float* x, float* y, float* mean, float* inv, int rows, int cols, float eps,
+                        dccn_stream_t stream);
+int dccn_layer_norm_bwd(const float* dy, const float* y, const float* inv, float* dx, int rows, int cols,
+                        dccn_stream_t stream);
+
+/* model.py:421-426  activation=tf.nn.tanh of the channel-estimate dense layer; bwd: dx = dy*(1-y^2). */
+int dccn_tanh_fwd(const float* x, float* y, long long n, dccn_stream_t stream);
+int dccn_tanh_bwd(const float* dy, const float* y, float* dx, long long n, dccn_stream_t stream);
+
+/* model.py:431-438  eq = y*conj(h)/|h| and corr = eq*conj(eq) over [n_pairs,2] (corr nullable).
+ * bwd: cotangents d_eq / d_corr (either nullable) -> dy / dh (either nullable). */
+int dccn_equalize_fwd(const float* y, const float* h, float* eq, float* corr, long long n_pairs,
+                      dccn_stream_t stream);
+int dccn_equalize_bwd(const float* y, const float* h, const float* d_eq, const float* d_corr, float* dy,
+                      float* dh, long long n_pairs, dccn_stream_t stream);
+
+/* model.py:465-475  pilot "SNR" monitor: eq [frames,S,K,2], carriers: device int32[P] -> snr_db [frames]
+ * = log10(clip(mean/var of |pilot cell|^2, 1e-3, 1e4)). */
+int dccn_pilot_snr(const float* eq, const int* carriers, float* snr_db, int frames, int S, int K, int P,
+                   dccn_stream_t stream);
+
+/* model.py:428  layers_conv2d_complex(chest, 1, (kL,kW), padding='same') on a one-channel L x W
+ * complex image, lowered to a dense layer: expand w [kL,kW,2] (=[Wa|Wb] per tap, the TF kernel
+ * [kL,kW,1,1,2]) and bias [2] (nullable) into T [L*W*2, L*W*2] and bias_eff [L*W*2] (nullable);
+ * run dccn_dense_fwd/bwd with them; reduce dT / dbias_eff back onto dw [kL,kW,2] / dbias [2]
+ * (dbias, dbias_eff nullable). */
+int dccn_cconv2d_same_expand(const float* w, const float* bias, float* T, float* bias_eff, int L, int W,
+                             int kL, int kW, dccn_stream_t stream);
+int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw, float* dbias, int L, int W,
+                             int kL, int kW, dccn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,3 +166,68 @@ class LiteralRx:
                 a = a[0, (c.kin - 1) // 2, 0]
             out[k] = a.copy()
         return out
+
+
+class LiteralEqualizer:
+    """``equalizer_ofdm`` (dev/py/model.py:349-478) + the transfer-learning loss of
+    dev/py/ofdmreceiver_np_mp.py:283-330 as a torch-CPU autograd graph: batch-moment norm ->
+    equaliser (trainable) -> frozen basic receiver -> ce_mean + 1e-3 * sum(reg)."""
+
+    def __init__(self, eq_params: Dict[str, np.ndarray], rx: "LiteralRx", ecfg, dtype=torch.float64):
+        from . import equalizer_oracle as E
+        self.E, self.c, self.rx, self.dtype = E, ecfg, rx, dtype
+        self.p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in eq_params.items()}
+
+    def _conv(self, x5, name, padding):
+        return conv2d_complex_literal(x5, self.p[name + "/kernel"], self.p[name + "/bias"], padding)
+
+    def equalizer(self, x):
+        c, p = self.c, self.p
+        B, S, K = x.shape[0], c.S, c.K
+        mean = x.mean(dim=(1, 2, 3), keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+        inv = torch.rsqrt(var + self.E.LN_EPS)
+        chest = x * inv + (-mean * inv)
+        if not c.cp:
+            chest = chest[:, :, c.CP:c.CP + K, :]
+        t1 = chest.reshape(B, S, -1) @ p["Equalizer/dense/kernel"] + p["Equalizer/dense/bias"]
+        y5 = self._conv(t1.reshape(B, S, K, 1, 2), "Equalizer/conv3d", "valid").permute(0, 1, 3, 2, 4)
+        y = torch.complex(y5[:, :, :, :, 0].contiguous(), y5[:, :, :, :, 1].contiguous())      # [B,S,K,1]
+        d = y5.reshape(B, S * K * 2)
+        d = d @ p["Equalizer/dense_1/kernel"] + p["Equalizer/dense_1/bias"]
+        d = d @ p["Equalizer/dense_2/kernel"] + p["Equalizer/dense_2/bias"]
+        d = d @ p["Equalizer/dense_3/kernel"] + p["Equalizer/dense_3/bias"]
+        d = torch.tanh(d @ p["Equalizer/dense_4/kernel"] + p["Equalizer/dense_4/bias"])
+        h5 = self._conv(d.reshape(B, S, K, 1, 2), "Equalizer/conv3d_1", "same")
+        h = torch.complex(h5[:, :, :, :, 0].contiguous(), h5[:, :, :, :, 1].contiguous())
+        hc = torch.conj(h)
+        ha = torch.abs(h)
+        hc = torch.complex(hc.real / ha, hc.imag / ha)
+        eq = y * hc
+        corr = eq * torch.conj(eq)
+        corr5 = self._conv(torch.view_as_real(corr).reshape(B, S, K, 1, 2), "Equalizer/conv3d_2", "valid")
+        corr_re = corr5[:, :, 0, :, :]
+        e5 = self._conv(torch.view_as_real(eq).reshape(B, S, K, 1, 2), "Equalizer/conv3d_3", "valid")
+        equalized = e5[:, :, 0, :, :]
+        cat = torch.cat([equalized, corr_re], dim=-1).reshape(B, S, 4 * K)
+        out = cat @ p["Equalizer/dense_5/kernel"] + p["Equalizer/dense_5/bias"]
+        return out.reshape(B, S, c.n_sc, 2), torch.view_as_real(h)[:, :, :, 0, :], torch.view_as_real(eq)[:, :, :, 0, :]
+
+    def forward_backward(self, x_raw: np.ndarray, bits: np.ndarray):
+        x = torch.as_tensor(x_raw, dtype=self.dtype)
+        for v in self.p.values():
+            v.grad = None
+        x_norm = self.rx.normalise(x)
+        out_eq, h, eq = self.equalizer(x_norm)
+        out_eq.retain_grad()
+        prob, fft_out, z = self.rx.receiver(out_eq)
+        ce_mean, conf, berlin, _ = self.rx.losses(prob, bits)
+        reg = sum(O.REG_L2 * (self.p[n] ** 2).sum() for n in self.E.regularized(self.c))
+        reg = reg + sum(O.REG_L2 * (self.rx.p[n] ** 2).sum() for n in O.REGULARIZED)
+        loss = ce_mean + self.E.EQ_REG_COEFF * reg
+        loss.backward()
+        grads = {k: v.grad.detach().numpy().copy() for k, v in self.p.items()}
+        return grads, dict(ce_mean=float(ce_mean.detach()), conf=conf.numpy(), berlin=berlin, loss=float(loss.detach()),
+                           out_eq=out_eq.detach().numpy(), d_out_eq=out_eq.grad.numpy().copy(),
+                           chest=h.detach().numpy(), eq=eq.detach().numpy(), prob=prob.detach().numpy(),
+                           x_norm=x_norm.detach().numpy())

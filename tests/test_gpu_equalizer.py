@@ -1,0 +1,229 @@
+"""GPU parity of the channel-equaliser stage (dev/py/model.py:349-478,
+dev/py/ofdmreceiver_np_mp.py:283-330) against oracle/equalizer_oracle.py (NumPy, literal conv3d)
+and oracle/torch_ref.py::LiteralEqualizer (fp64 autograd).
+
+Tolerances (fp32 kernels vs fp64 oracle): forward 2e-5 of the tensor's scale; operator backward
+1e-5; whole-stage gradients by cosine >= 1 - 1e-6 per parameter and 2e-4 of the gradient's scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dccn_oracle as O
+from oracle import equalizer_oracle as E
+from oracle.torch_ref import LiteralEqualizer, LiteralRx, conv2d_complex_literal
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+def close(got, want, tol, what=""):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= tol, "%s: rel err %.3e > %.1e" % (what, err, tol)
+
+
+# ---- operators -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 7, 80, 2), (1, 5), (37, 1120), (2, 3000)])
+def test_layer_norm(shape):
+    from dl_ofdm_amd import ops
+    rng = np.random.RandomState(1)
+    x = (rng.standard_normal(shape) * 3 + 0.7).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = ops.layer_norm(xt)
+    close(y, E.layer_norm(x.astype(np.float64)), 2e-5, "layer_norm fwd")
+    g = rng.standard_normal(shape).astype(np.float32)
+    y.backward(dev(g))
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ax = tuple(range(1, xr.dim()))
+    m = xr.mean(dim=ax, keepdim=True)
+    v = ((xr - m) ** 2).mean(dim=ax, keepdim=True)
+    ((xr - m) * torch.rsqrt(v + E.LN_EPS)).backward(torch.tensor(g, dtype=torch.float64))
+    close(xt.grad, xr.grad.numpy(), 2e-5, "layer_norm bwd")
+
+
+def test_tanh():
+    from dl_ofdm_amd import ops
+    rng = np.random.RandomState(2)
+    x = (rng.standard_normal((33, 129)) * 2).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = ops.tanh(xt)
+    close(y, np.tanh(x.astype(np.float64)), 1e-6, "tanh fwd")
+    y.backward(dev(g))
+    close(xt.grad, g * (1 - np.tanh(x.astype(np.float64)) ** 2), 2e-6, "tanh bwd")
+
+
+def test_equalize():
+    from dl_ofdm_amd import ops
+    rng = np.random.RandomState(3)
+    y = rng.standard_normal((6, 7, 64, 2)).astype(np.float32)
+    h = rng.standard_normal((6, 7, 64, 2)).astype(np.float32)
+    h[np.abs(h).sum(-1) < 0.2] += 0.5                          # keep |h| away from the 1/|h| pole
+    eq_o, corr_o = E.equalize(y.astype(np.float64), h.astype(np.float64))
+    yt, ht = dev(y).requires_grad_(True), dev(h).requires_grad_(True)
+    eq, corr = ops.equalize(yt, ht)
+    close(eq, eq_o, 2e-6, "eq")
+    close(corr, corr_o, 2e-6, "corr")
+    assert float(corr[..., 1].abs().max()) == 0.0               # imaginary part cancels exactly
+    g1 = rng.standard_normal(y.shape).astype(np.float32)
+    g2 = rng.standard_normal(y.shape).astype(np.float32)
+    (eq * dev(g1)).sum().add((corr * dev(g2)).sum()).backward()
+    yr = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    hr = torch.tensor(h, dtype=torch.float64, requires_grad=True)
+    yc, hc = torch.view_as_complex(yr), torch.view_as_complex(hr)
+    cj = torch.conj(hc)
+    a = torch.abs(hc)
+    e = yc * torch.complex(cj.real / a, cj.imag / a)
+    c = e * torch.conj(e)
+    ((torch.view_as_real(e) * torch.tensor(g1, dtype=torch.float64)).sum()
+     + (torch.view_as_real(c) * torch.tensor(g2, dtype=torch.float64)).sum()).backward()
+    close(yt.grad, yr.grad.numpy(), 1e-5, "d y")
+    close(ht.grad, hr.grad.numpy(), 1e-5, "d h")
+
+
+def test_pilot_snr():
+    from dl_ofdm_amd import ops
+    rng = np.random.RandomState(4)
+    eq = rng.standard_normal((9, 7, 64, 2)).astype(np.float32)
+    car = (4, 12, 20, 28, 35, 43, 51, 59)
+    close(ops.pilot_snr(dev(eq), car), E.pilot_snr(eq.astype(np.float64), car), 2e-5, "pilot snr")
+
+
+@pytest.mark.parametrize("geom", [(7, 64, 7, 64), (3, 8, 3, 8), (4, 10, 3, 6), (5, 6, 2, 5)])
+def test_cconv2d_same_toeplitz(geom):
+    """block-Toeplitz dense lowering == literal zero-padded conv3d, forward and all gradients"""
+    from dl_ofdm_amd import ops
+    L, W, kL, kW = geom
+    rng = np.random.RandomState(5)
+    B = 4
+    x = rng.standard_normal((B, L, W, 2)).astype(np.float32)
+    w = (rng.standard_normal((kL, kW, 2)) / np.sqrt(kL * kW)).astype(np.float32)
+    b = rng.standard_normal(2).astype(np.float32)
+    g = rng.standard_normal((B, L, W, 2)).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.cconv2d_same(xt, wt, bt)
+    y.backward(dev(g))
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wr = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    br = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yr = conv2d_complex_literal(xr.reshape(B, L, W, 1, 2), wr.reshape(kL, kW, 1, 1, 2), br, "same")[:, :, :, 0, :]
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    lit = O.layers_conv2d_complex_literal(x.astype(np.float64).reshape(B, L, W, 1, 2),
+                                          w.astype(np.float64).reshape(kL, kW, 1, 1, 2), b.astype(np.float64),
+                                          (1, 1), "same")[:, :, :, 0, :]
+    close(yr, lit, 1e-12, "torch literal vs numpy literal")
+    close(y, lit, 2e-5, "fwd")
+    close(xt.grad, xr.grad.numpy(), 2e-5, "dx")
+    close(wt.grad, wr.grad.numpy(), 2e-5, "dw")
+    close(bt.grad, br.grad.numpy(), 2e-5, "db")
+
+
+# ---- the stage -------------------------------------------------------------------------------------
+class _Flags:
+    nfft, nsymbol, nbits, npilot, nguard, nfilter = 64, 7, 2, 8, 8, 64
+    cp, longcp, pilot, channel = True, True, "lte", "EPA"
+
+
+def _store_shape(name, shp):
+    return (shp[0], shp[1], shp[3], shp[4]) if len(shp) == 5 else shp
+
+
+def build_stage(nbits=2, cp=True, seed=11):
+    from dl_ofdm_amd.complex import VariableStore
+    from dl_ofdm_amd.model import OfdmDenseRx, equalizer_ofdm
+    from dl_ofdm_amd.ofdm import ofdm_tx
+    F = _Flags()
+    F.nbits, F.cp = nbits, cp
+    tx = ofdm_tx(F)
+    ecfg = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=cp, pilot_size=tx.pilot_size,
+                      pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
+    rcfg = O.RxConfig(S=7, kin=ecfg.n_sc, F=64, D=tx.frame_size, nbits=nbits)
+    pe = E.init_params(ecfg, seed=seed, bias_scale=0.05)
+    pr = O.init_params(rcfg, seed=seed + 1)
+    rng = np.random.RandomState(seed)
+    for n in pr:                                            # non-zero biases in the frozen receiver too
+        if n.endswith("bias"):
+            pr[n] = (0.05 * rng.standard_normal(pr[n].shape)).astype(np.float32)
+    rx = OfdmDenseRx(F, tx, seed=1)
+    rx.import_params(pr)
+    for p_ in rx.store.parameters():
+        p_.requires_grad_(False)
+    eq_store = VariableStore(seed=2)
+
+    def run_eq(x_norm):
+        eq_store.begin()
+        with eq_store.scope("Equalizer"):
+            return equalizer_ofdm(x_norm, F, tx, scope=eq_store)
+    run_eq(torch.randn(2, 7, 64 + 16, 2, device="cuda"))                 # create the variables
+    assert [n for n in eq_store.names()] == list(E.param_shapes(ecfg).keys())
+    for n, shp in E.param_shapes(ecfg).items():
+        assert tuple(eq_store.tensor(n).shape) == _store_shape(n, shp), n
+        eq_store.set(n, pe[n])
+    return F, tx, ecfg, rcfg, pe, pr, rx, eq_store, run_eq
+
+
+@pytest.mark.parametrize("nbits,B", [(2, 6), (1, 3), (4, 9)])
+def test_equalizer_forward_and_gradients(nbits, B):
+    from dl_ofdm_amd import ops
+    from dl_ofdm_amd.model import ofdm_dense_rx, regularization_loss
+    F, tx, ecfg, rcfg, pe, pr, rx, eq_store, run_eq = build_stage(nbits)
+    rng = np.random.RandomState(100 + nbits)
+    x = (rng.standard_normal((B, 7, 80, 2)) * 2).astype(np.float32)
+    bits = rng.randint(0, 2, (B, tx.frame_size, nbits)).astype(np.int32)
+
+    lit_rx = LiteralRx({k: v.astype(np.float64) for k, v in pr.items()}, rcfg, dtype=torch.float64, literal_conv=False)
+    lit = LiteralEqualizer({k: v.astype(np.float64) for k, v in pe.items()}, lit_rx, ecfg)
+    g_ref, info = lit.forward_backward(x.astype(np.float64), bits)
+    out_np, snr_np, h_np = E.equalizer_forward({k: v.astype(np.float64) for k, v in pe.items()}, info["x_norm"], ecfg)
+    close(out_np, info["out_eq"], 1e-11, "numpy vs torch oracle")
+
+    x_norm = ops.batch_moment_norm(dev(x))
+    out_eq, snr_db, chest = run_eq(x_norm)
+    close(out_eq, info["out_eq"], 5e-5, "equalized")
+    close(torch.view_as_real(chest), info["chest"], 5e-5, "chest")
+    close(snr_db, snr_np, 2e-4, "snr_db")
+    rx.store.begin()
+    prob, ce, mbuf, _ = ofdm_dense_rx(out_eq, F, tx, rx.outshape, scope=rx.store, bits=dev(bits, torch.int32))
+    close(prob, info["prob"], 5e-5, "prob")
+    loss = ce + E.EQ_REG_COEFF * (regularization_loss(eq_store, "Equalizer") + regularization_loss(rx.store))
+    assert abs(float(loss) - info["loss"]) <= 2e-6 * abs(info["loss"])
+    assert abs(float(ce) - info["ce_mean"]) <= 2e-6 * abs(info["ce_mean"])
+    loss.backward()
+    m = ops.read_metrics(mbuf)
+    assert np.array_equal(np.asarray(m["conf"]).reshape(2, 2), info["conf"])
+    for n in E.param_shapes(ecfg):
+        got = eq_store.tensor(n).grad.detach().cpu().numpy().astype(np.float64).ravel()
+        want = g_ref[n].ravel()
+        cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+        assert cos >= 1 - 1e-6, (n, cos)
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), (n, np.abs(got - want).max(), np.abs(want).max())
+    assert all(p_.grad is None for p_ in rx.store.parameters())           # receiver stays frozen
+
+
+def test_equalizer_without_cp():
+    """FLAGS.cp=False: the stage drops the cyclic prefix itself (model.py:364-366) but still maps back
+    to the input width (:458)."""
+    from dl_ofdm_amd.complex import VariableStore
+    from dl_ofdm_amd.model import equalizer_ofdm
+    from dl_ofdm_amd.ofdm import ofdm_tx
+    F = _Flags()
+    tx = ofdm_tx(F)
+    F.cp = False
+    st = VariableStore(seed=5)
+    x = torch.randn(3, 7, 80, 2, device="cuda") * 1.5
+    with st.scope("Equalizer"):
+        out, snr, chest = equalizer_ofdm(x, F, tx, scope=st)
+    assert out.shape == (3, 7, 80, 2) and snr.shape == (3, 1) and chest.shape == (3, 7, 64)
+    c = E.EqConfig(S=7, K=64, CP=16, cp=False, pilot_size=tx.pilot_size,
+                   pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
+    p = {n: st.tensor(n).detach().cpu().numpy().astype(np.float64).reshape(s) for n, s in E.param_shapes(c).items()}
+    o_out, o_snr, o_h = E.equalizer_forward(p, x.cpu().numpy().astype(np.float64), c)
+    close(out, o_out, 5e-5, "equalized (no cp)")
+    close(torch.view_as_real(chest), o_h, 5e-5, "chest (no cp)")
