@@ -71,7 +71,7 @@ def test_equalize():
     eq, corr = ops.equalize(yt, ht)
     close(eq, eq_o, 2e-6, "eq")
     close(corr, corr_o, 2e-6, "corr")
-    assert float(corr[..., 1].abs().max()) == 0.0               # imaginary part cancels exactly
+    assert float(corr.detach()[..., 1].abs().max()) == 0.0               # imaginary part cancels exactly
     g1 = rng.standard_normal(y.shape).astype(np.float32)
     g2 = rng.standard_normal(y.shape).astype(np.float32)
     (eq * dev(g1)).sum().add((corr * dev(g2)).sum()).backward()
@@ -193,8 +193,8 @@ def test_equalizer_forward_and_gradients(nbits, B):
     prob, ce, mbuf, _ = ofdm_dense_rx(out_eq, F, tx, rx.outshape, scope=rx.store, bits=dev(bits, torch.int32))
     close(prob, info["prob"], 5e-5, "prob")
     loss = ce + E.EQ_REG_COEFF * (regularization_loss(eq_store, "Equalizer") + regularization_loss(rx.store))
-    assert abs(float(loss) - info["loss"]) <= 2e-6 * abs(info["loss"])
-    assert abs(float(ce) - info["ce_mean"]) <= 2e-6 * abs(info["ce_mean"])
+    assert abs(float(loss.detach()) - info["loss"]) <= 2e-6 * abs(info["loss"])
+    assert abs(float(ce.detach()) - info["ce_mean"]) <= 2e-6 * abs(info["ce_mean"])
     loss.backward()
     m = ops.read_metrics(mbuf)
     assert np.array_equal(np.asarray(m["conf"]).reshape(2, 2), info["conf"])
@@ -227,3 +227,124 @@ def test_equalizer_without_cp():
     o_out, o_snr, o_h = E.equalizer_forward(p, x.cpu().numpy().astype(np.float64), c)
     close(out, o_out, 5e-5, "equalized (no cp)")
     close(torch.view_as_real(chest), o_h, 5e-5, "chest (no cp)")
+
+
+# ---- the transfer-learning step (ofdmreceiver_np_mp.py:319-330) -----------------------------------------
+def _trainer(nbits=2, seed=21):
+    from dl_ofdm_amd.equalizer import EqualizerTrainer
+    from dl_ofdm_amd.ofdm import ofdm_tx
+    F = _Flags()
+    F.nbits, F.opt, F.init_learning = nbits, 0, 1e-3
+    tx = ofdm_tx(F)
+    ecfg = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=True, pilot_size=tx.pilot_size,
+                      pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
+    rcfg = O.RxConfig(S=7, kin=80, F=64, D=tx.frame_size, nbits=nbits)
+    pe = E.init_params(ecfg, seed=seed, bias_scale=0.05)
+    pr = O.init_params(rcfg, seed=seed + 1)
+    tr = EqualizerTrainer(F, tx, pr, seed=3)
+    assert tr.names == list(E.param_shapes(ecfg).keys()) and tr.n_params == 1_753_282
+    tr.load_params(pe)
+    return F, tx, ecfg, rcfg, pe, pr, tr
+
+
+def test_trainer_step_gradients_and_adam():
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer()
+    rng = np.random.RandomState(7)
+    B = 8
+    st = O.adam_init(pe)
+    p_or = {k: v.copy() for k, v in pe.items()}
+    for step in range(3):
+        x = (rng.standard_normal((B, 7, 80, 2)) * 2).astype(np.float32)
+        bits = rng.randint(0, 2, (B, tx.frame_size, 2)).astype(np.int32)
+        p_before = tr.get_params()
+        lit_rx = LiteralRx({k: v.astype(np.float64) for k, v in pr.items()}, rcfg, dtype=torch.float64,
+                           literal_conv=False)
+        lit = LiteralEqualizer({k: v.astype(np.float64).reshape(pe[k].shape) for k, v in p_before.items()}, lit_rx, ecfg)
+        g_ref, info = lit.forward_backward(x.astype(np.float64), bits)
+        m = tr.train_step(x, bits)
+        assert abs(m["ce_mean"] - info["ce_mean"]) <= 3e-6 * abs(info["ce_mean"])
+        assert np.array_equal(np.asarray(m["conf"]).reshape(2, 2), info["conf"])
+        assert abs(tr.total_loss(m) - info["loss"]) <= 5e-3 * abs(info["loss"])      # reg term read after the update: loose
+        g_gpu = tr.get_grads()
+        used = {}
+        for n in tr.names:
+            reg = E.EQ_REG_COEFF * 2 * O.REG_L2 * p_before[n].astype(np.float64) if "/dense" in n else 0.0
+            got = (g_gpu[n].astype(np.float64) + reg).ravel()
+            want = g_ref[n].ravel()
+            cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+            assert cos >= 1 - 1e-6, (step, n, cos)
+            assert np.abs(got - want).max() <= 3e-4 * np.abs(want).max(), (step, n)
+            used[n] = (g_gpu[n] + np.float32(E.EQ_REG_COEFF * 2 * O.REG_L2) * p_before[n]).astype(np.float32) \
+                if "/dense" in n else g_gpu[n]
+        # the optimizer itself: TF ApplyAdam on the GPU's own gradients, from the GPU's own parameters
+        for k in p_or:
+            p_or[k] = p_before[k].reshape(pe[k].shape).copy()
+        alpha = O.adam_tf_step(p_or, {k: used[k].reshape(pe[k].shape) for k in p_or}, st)
+        a = tr.adam()
+        assert a["global_step"] == step + 1 and abs(a["alpha"] - float(alpha)) <= 1e-6 * float(alpha)
+        p_after = tr.get_params()
+        for n in tr.names:
+            d_gpu = (p_after[n] - p_before[n]).ravel().astype(np.float64)
+            d_or = (p_or[n].ravel() - p_before[n].ravel()).astype(np.float64)
+            # |update| <= ~lr; agreement to 1e-3 of lr except where g ~ 0 flips m/sqrt(v) (measure by quantile)
+            err = np.abs(d_gpu - d_or)
+            assert np.quantile(err, 0.999) <= 2e-6, (step, n, np.quantile(err, 0.999))
+            m_or, m_gpu = st.m[n].ravel(), tr.view(n, tr.adam_m).detach().cpu().numpy().ravel()
+            assert np.abs(m_or - m_gpu).max() <= 1e-6 * max(np.abs(m_or).max(), 1e-30) + 1e-12
+
+
+def test_trainer_checkpoint_roundtrip_and_unsupported_variant(tmp_path):
+    from dl_ofdm_amd import receiver_mp as H
+    from dl_ofdm_amd.equalizer import EqualizerTrainer
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer()
+    rng = np.random.RandomState(8)
+    x = (rng.standard_normal((5, 7, 80, 2)) * 2).astype(np.float32)
+    bits = rng.randint(0, 2, (5, tx.frame_size, 2)).astype(np.int32)
+    tr.train_step(x, bits)
+    hf = H.Flags(nbits=2, nfilter=64, token="T", channel="EPA", save_dir=str(tmp_path))
+    path = H.save_checkpoint(str(tmp_path / H.save_model_name(hf)), tr, hf)
+    z = np.load(path + ".npz")
+    for key in ("Equalizer/dense_3/kernel", "optimizer/Equalizer/dense_3/kernel/Adam",
+                "optimizer/Equalizer/conv3d_1/bias/Adam_1", "optimizer/global_step", "optimizer/beta1_power"):
+        assert key in z.files
+    e1 = tr.eval_step(x, bits)
+    tr2 = EqualizerTrainer(F, tx, pr, seed=99)
+    H.load_checkpoint(path, tr2)
+    e2 = tr2.eval_step(x, bits)
+    assert e1["ce_sum"] == e2["ce_sum"] and e1["conf"] == e2["conf"]
+    assert tr2.adam()["global_step"] == 1.0
+    assert torch.equal(tr.adam_v, tr2.adam_v)
+    F.opt = 3
+    with pytest.raises(NotImplementedError):
+        EqualizerTrainer(F, tx, pr)
+
+
+def test_equalizer_learns_a_flat_fading_channel():
+    """End to end through the harness pieces: a receiver trained on AWGN cannot demodulate a random
+    phase rotation (flat Rayleigh tap); a few hundred equaliser steps must cut its BER."""
+    from dl_ofdm_amd import receiver as R, receiver_mp as H
+    from dl_ofdm_amd import ofdm
+    base = R.Flags(nbits=2, nfilter=64, channel="AWGN", SNR=10.0, msg_length=7 * 4096, batch_size=512,
+                   max_epoch_num=6, early_stop=100, token="B", save_dir="/tmp/_eq_test/", seed=5)
+    res = R.train(base, verbose=False, run_test=False)
+    hf = H.Flags(nbits=2, nfilter=64, channel="Flat", msg_length=7 * 2048, batch_size=512, max_epoch_num=5,
+                 early_stop=100, token="B", save_dir="/tmp/_eq_test/", seed=6, eval_frames=2048)
+    out = H.train(hf, verbose=False, run_test=False, rx_params=res["params"])
+    hist = out["history"]
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"] - 0.02, hist
+    tr = out["trainer"]
+    tx = ofdm.ofdm_tx(hf)
+    np.random.seed(11)
+    xs, ys, _, _ = H.make_batch(hf, tx, H.RayleighChanParallel(hf, tx.Fs), 2048, 20.0)
+    with_eq = tr.eval_step(xs, ys)["berlin"]
+    from dl_ofdm_amd.engine import RxEngine
+    eng = RxEngine(R.rx_dims(base, tx), 2048, train=False, params=res["params"], want_prob=False)
+    eng.eval_step(xs, ys)
+    without = eng.metrics()["berlin"]
+    assert without > 0.25, without                       # random phase: the bare receiver is lost
+    assert with_eq < without - 0.05, (with_eq, without)
+    sw = H.test_model_cross(H.Flags(**{**hf.__dict__, "test_frames": 256, "snr_lo": 0, "snr_hi": 20, "snr_step": 10}),
+                            tr, tx, out_dir="/tmp/_eq_test", verbose=False, channels=("Flat", "EPA"))
+    import os
+    assert os.path.basename(sw["EPA"][3]) == "Test_DCCN_B_Equalizer0_Flat_test_chan_EPA.csv" and os.path.exists(sw["EPA"][3])
+    assert len(sw["Flat"][1]) == 3

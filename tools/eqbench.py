@@ -1,0 +1,66 @@
+"""Time the equaliser transfer-learning step (dl_ofdm_amd.equalizer.EqualizerTrainer) on one GPU.
+
+    python tools/eqbench.py [--frames 73 1170] [--steps 50]
+
+Prints one JSON line per batch size: frames, ms/step (HIP events around `steps` steps, inputs resident),
+OFDM symbols/s, model GFLOP/step (dense + C-Conv GEMMs, forward 1x + backward: 2x for trainable
+layers, 1x for the frozen receiver's backward-to-input).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dl_ofdm_amd import ofdm, receiver_mp as H          # noqa: E402
+from dl_ofdm_amd.engine import HipTimer, glorot_init    # noqa: E402
+from dl_ofdm_amd.equalizer import EqualizerTrainer      # noqa: E402
+from dl_ofdm_amd.receiver import rx_dims                 # noqa: E402
+
+
+def step_flops(B, S=7, K=64, n_sc=80, F=64, D=320):
+    SK2 = S * K * 2
+    eq = (B * S * (2 * n_sc) * (2 * K)                      # dense
+          + 3 * B * S * (2 * K) * (2 * K)                   # three (1,K) C-Convs
+          + 2 * B * SK2 * 32                                # pilot bottleneck in/out
+          + 3 * B * SK2 * SK2                               # dense_3, dense_4, Toeplitz smoothing conv
+          + B * S * (4 * K) * (2 * n_sc))                   # dense_5
+    rx = B * S * (2 * n_sc) * (2 * F) + B * (2 * S * F) * (2 * D)
+    return 2.0 * (3 * eq + 2 * rx)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, nargs="+", default=[73, 1170])
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    a = ap.parse_args()
+    F = H.Flags(nbits=2, nfilter=64, channel="EPA")
+    tx = ofdm.ofdm_tx(F)
+    tr = EqualizerTrainer(F, tx, glorot_init(rx_dims(F, tx), 1), seed=1)
+    for B in a.frames:
+        x = torch.randn(B, 7, 80, 2, device="cuda")
+        bits = torch.randint(0, 2, (B, tx.frame_size, 2), dtype=torch.int32, device="cuda")
+        for _ in range(a.warmup):
+            tr.train_step(x, bits)
+        torch.cuda.synchronize()
+        t = HipTimer()
+        st = torch.cuda.current_stream().cuda_stream
+        t.start(st)
+        for _ in range(a.steps):
+            tr.grads.zero_()
+            ce, mbuf, *_ = tr._forward(x, bits)
+            ce.backward()
+            tr._adam_step()
+        t.stop(st)
+        ms = t.elapsed_ms() / a.steps
+        fl = step_flops(B)
+        print(json.dumps(dict(frames=B, ms_per_step=round(ms, 4), symbols_per_s=round(B * 7 / ms * 1e3),
+                              gflop_per_step=round(fl / 1e9, 3), tflops=round(fl / ms / 1e9, 2))))
+
+
+if __name__ == "__main__":
+    main()
