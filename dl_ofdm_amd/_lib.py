@@ -52,6 +52,21 @@ class RxBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
+class EqShape(C.Structure):
+    """dccn_eq_shape"""
+    _fields_ = [("batch", c_int), ("S", c_int), ("K", c_int), ("CP", c_int), ("cp", c_int), ("F", c_int),
+                ("D", c_int), ("nbits", c_int), ("pilot_size", c_int), ("P", c_int)]
+
+
+class EqBuffers(C.Structure):
+    """dccn_eq_buffers"""
+    _fields_ = [("x", c_void_p), ("bits", c_void_p), ("eq_params", c_void_p), ("eq_grads", c_void_p),
+                ("adam_m", c_void_p), ("adam_v", c_void_p), ("reg_coef", c_void_p), ("adam", c_void_p),
+                ("rx_params", c_void_p), ("out_eq", c_void_p), ("chest", c_void_p), ("snr_db", c_void_p),
+                ("pilot_carriers", c_void_p), ("prob", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 METRICS_BYTES = C.sizeof(Metrics)
 ADAM_STATE_BYTES = C.sizeof(AdamState)
 
@@ -105,6 +120,11 @@ SIGNATURES = {
     "dccn_pilot_snr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dccn_cconv2d_same_expand": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dccn_cconv2d_same_reduce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "dccn_eq_param_offsets": (_i, [POINTER(EqShape), POINTER(c_longlong)]),
+    "dccn_eq_workspace_size": (_sz, [POINTER(EqShape), _i]),
+    "dccn_eq_eval_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), _vp]),
+    "dccn_eq_train_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), AdamHParams, _vp]),
+    "dccn_eq_graph_create": (_i, [POINTER(EqShape), POINTER(EqBuffers), _i, AdamHParams, _vp, POINTER(c_void_p)]),
 }
 
 _lib = None

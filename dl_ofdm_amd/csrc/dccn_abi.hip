@@ -21,7 +21,7 @@ struct Carver {
     template <typename T>
     T* take(size_t count) {
         off = align_up(off, 256);
-        T* r = reinterpret_cast<T*>(base + off);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;     // base == nullptr: size-only dry run
         off += count * sizeof(T);
         return r;
     }
@@ -441,6 +441,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     return DCCN_OK;
 }
 
+#include "eq_step.h"
+
 }  // namespace dccn
 
 using namespace dccn;
@@ -666,6 +668,54 @@ int dccn_rx_graph_create(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
     *out = g;
     return DCCN_OK;
 }
+// ---- fused equaliser step ---------------------------------------------------------------------------
+int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets) {
+    if (!eq_shape_ok(shape) || !offsets) return DCCN_ERR_INVALID_ARG;
+    const EqDims d = eq_dims(shape);
+    for (int i = 0; i < 21; ++i) offsets[i] = d.o[i];
+    return DCCN_OK;
+}
+size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train) {
+    if (!eq_shape_ok(shape)) return 0;
+    return eq_ws_bytes(shape, train);
+}
+int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream) {
+    return eq_step_impl(shape, buf, false, dccn_adam_hparams(), (hipStream_t)stream);
+}
+int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_adam_hparams hp,
+                       dccn_stream_t stream) {
+    return eq_step_impl(shape, buf, true, hp, (hipStream_t)stream);
+}
+int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,
+                         dccn_stream_t stream, dccn_rx_graph** out) {
+    if (!out || !eq_shape_ok(shape) || !buf) return DCCN_ERR_INVALID_ARG;
+    (void)stream;
+    dccn_rx_graph* g = new dccn_rx_graph();
+    memset(g, 0, sizeof(*g));
+    if (hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking) != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return DCCN_ERR_LAUNCH;
+    }
+    hipError_t e = hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return hip_fail(e);
+    }
+    const int st = eq_step_impl(shape, buf, (mode & 1) != 0, hp, g->cap);
+    e = hipStreamEndCapture(g->cap, &g->graph);
+    if (st != DCCN_OK || e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return st != DCCN_OK ? st : hip_fail(e);
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        dccn_rx_graph_destroy(g);
+        return hip_fail(e);
+    }
+    *out = g;
+    return DCCN_OK;
+}
+
 int dccn_rx_graph_launch(dccn_rx_graph* g, dccn_stream_t stream) {
     if (!g || !g->exec) return DCCN_ERR_STATE;
     DCCN_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
@@ -722,11 +772,7 @@ int dccn_stream_synchronize(dccn_stream_t stream) {
 }
 
 // ---- equaliser stage operators ------------------------------------------------------------------
-static inline unsigned ew_blocks(long long n) {
-    long long b = ceil_div_ll(n, 256);
-    if (b > 8 * kCUs) b = 8 * kCUs;
-    return (unsigned)(b < 1 ? 1 : b);
-}
+static inline unsigned ew_blocks(long long n) { return ew_blocks_n(n); }
 int dccn_layer_norm_fwd(const float* x, float* y, float* mean, float* inv, int rows, int cols, float eps,
                         dccn_stream_t stream) {
     if (!x || !y || rows <= 0 || cols <= 0) return DCCN_ERR_INVALID_ARG;

@@ -1,0 +1,230 @@
+// Fused equaliser transfer-learning step: dev/py/ofdmreceiver_np_mp.py:283-330 as one
+// pre-planned launch sequence (capturable into a hipGraph) over flat arenas --
+//   R0 normalise -> equalizer_ofdm (model.py:349-478) -> frozen basic receiver -> loss/BER
+//   -> backward to the Equalizer/* variables only -> TF Adam on the equaliser arena.
+// Included inside namespace dccn of dccn_abi.hip, after the *_impl helpers it is built from.
+// Only FLAGS.cp=True is planned here (the composable layer API covers cp=False).
+
+static bool eq_shape_ok(const dccn_eq_shape* sh) {
+    return sh && sh->batch > 0 && sh->S > 0 && sh->K > 0 && sh->CP >= 0 && sh->F > 0 && sh->D > 0 && sh->nbits >= 1 &&
+           sh->nbits <= 4 && sh->pilot_size > 0 && sh->cp == 1;
+}
+
+struct EqDims {
+    int B, S, K, nsc, R, SK2, Pp, F, D;
+    long long o[21];        // parameter offsets, TF creation order (dense, conv3d, dense_1..4, conv3d_1..3, dense_5)
+};
+static EqDims eq_dims(const dccn_eq_shape* sh) {
+    EqDims d;
+    d.B = sh->batch; d.S = sh->S; d.K = sh->K; d.nsc = sh->K + sh->CP; d.R = d.B * d.S;
+    d.SK2 = d.S * d.K * 2; d.Pp = 2 * sh->pilot_size; d.F = sh->F; d.D = sh->D;
+    const long long K2 = 2LL * d.K, N2 = 2LL * d.nsc, SK2 = d.SK2;
+    const long long sizes[20] = {N2 * K2, K2,                 // dense
+                                 (long long)d.K * K2, K2,     // conv3d     (1,K) -> K filters
+                                 SK2 * d.Pp, d.Pp,            // dense_1    pilot extraction
+                                 d.Pp * SK2, SK2,             // dense_2
+                                 SK2 * SK2, SK2,              // dense_3
+                                 SK2 * SK2, SK2,              // dense_4    (tanh)
+                                 SK2, 2,                      // conv3d_1   (S,K) -> 1 filter
+                                 (long long)d.K * K2, K2,     // conv3d_2   (corr)
+                                 (long long)d.K * K2, K2,     // conv3d_3   (equalized)
+                                 4LL * d.K * N2, N2};         // dense_5
+    d.o[0] = 0;
+    for (int i = 0; i < 20; ++i) d.o[i + 1] = d.o[i] + sizes[i];
+    return d;
+}
+
+struct EqWs {
+    void *ws_norm, *ws_tail, *ws_split;
+    size_t n_norm, n_tail, n_split;
+    float *x_norm, *ln, *t1, *y, *d1, *d2, *d3, *d4, *T, *be, *eq, *corr, *eqc, *corc, *cat, *fft, *z;
+    // training only
+    float *dz, *dfft, *dout, *dcat, *deqc, *dcorc, *deq, *dcorr, *dy, *dh, *dT, *dbe, *dd4, *dd3, *dd2, *dd1,
+        *dflat, *dt1, *dtail;
+};
+static size_t eq_split_ws(const EqDims& d) {
+    size_t m = 0;
+    auto upd = [&](int Mo, int No, int Kr) { const size_t v = splitk_ws_bytes(Mo, No, Kr); if (v > m) m = v; };
+    upd(2 * d.nsc, 2 * d.K, d.R);          // dense
+    upd(2 * d.K, 2 * d.K, d.R);            // the three (1,K) C-Convs
+    upd(d.SK2, d.Pp, d.B);
+    upd(d.Pp, d.SK2, d.B);
+    upd(d.SK2, d.SK2, d.B);                // dense_3, dense_4, Toeplitz
+    upd(4 * d.K, 2 * d.nsc, d.R);          // dense_5
+    return m;
+}
+static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool train, EqWs& w) {
+    const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
+    w.n_norm = norm_ws_bytes(d.B, d.S * d.nsc * 2);
+    w.n_tail = tail_ws_bytes((long long)d.B * d.D, sh->nbits);
+    w.n_split = train ? eq_split_ws(d) : 0;
+    w.ws_norm = c.take<char>(w.n_norm);
+    w.ws_tail = c.take<char>(w.n_tail);
+    w.ws_split = train ? c.take<char>(w.n_split) : nullptr;
+    w.x_norm = c.take<float>(R * N2);
+    w.ln = c.take<float>(R * N2);
+    w.t1 = c.take<float>(R * K2);
+    w.y = c.take<float>(R * K2);
+    w.d1 = c.take<float>(B * d.Pp);
+    w.d2 = c.take<float>(B * SK2);
+    w.d3 = c.take<float>(B * SK2);
+    w.d4 = c.take<float>(B * SK2);
+    w.T = c.take<float>(SK2 * SK2);
+    w.be = c.take<float>(SK2);
+    w.eq = c.take<float>(B * SK2);
+    w.corr = c.take<float>(B * SK2);
+    w.eqc = c.take<float>(R * K2);
+    w.corc = c.take<float>(R * K2);
+    w.cat = c.take<float>(R * 2 * K2);
+    w.fft = c.take<float>(R * 2 * (size_t)d.F);
+    w.z = c.take<float>(B * 2 * (size_t)d.D);
+    if (!train) return;
+    w.dz = c.take<float>(B * 2 * (size_t)d.D);
+    w.dfft = c.take<float>(R * 2 * (size_t)d.F);
+    w.dout = c.take<float>(R * N2);
+    w.dcat = c.take<float>(R * 2 * K2);
+    w.deqc = c.take<float>(R * K2);
+    w.dcorc = c.take<float>(R * K2);
+    w.deq = c.take<float>(B * SK2);
+    w.dcorr = c.take<float>(B * SK2);
+    w.dy = c.take<float>(B * SK2);
+    w.dh = c.take<float>(B * SK2);
+    w.dT = c.take<float>(SK2 * SK2);
+    w.dbe = c.take<float>(SK2);
+    w.dd4 = c.take<float>(B * SK2);
+    w.dd3 = c.take<float>(B * SK2);
+    w.dd2 = c.take<float>(B * SK2);
+    w.dd1 = c.take<float>(B * d.Pp);
+    w.dflat = c.take<float>(B * SK2);
+    w.dt1 = c.take<float>(R * K2);
+    w.dtail = c.take<float>(tail_param_count(sh->nbits));
+}
+static size_t eq_ws_bytes(const dccn_eq_shape* sh, int train) {
+    const EqDims d = eq_dims(sh);
+    Carver c(nullptr, 0);
+    EqWs w;
+    eq_carve(c, sh, d, train != 0, w);
+    return align_up(c.off, 256);
+}
+
+// dense backward with reduced outputs: dx (nullable: weight gradient only), dw, dbias
+static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+                               int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!dx) return dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s);
+    DeferredSlabs ds;
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds));
+    if (ds.dw_slabs) {
+        const long long n = (long long)K * N;
+        DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw, n, s));
+        if (dbias && ds.db_slabs)
+            DCCN_TRY(launch_splitk_reduce(ds.db_slabs, ds.splits, (long long)N, dbias, (long long)N, s));
+    }
+    return DCCN_OK;
+}
+
+static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool train, dccn_adam_hparams hp,
+                        hipStream_t s) {
+    if (!eq_shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
+    if (!b->x || !b->bits || !b->eq_params || !b->rx_params || !b->out_eq || !b->chest || !b->metrics)
+        return DCCN_ERR_INVALID_ARG;
+    if (train && (!b->eq_grads || !b->adam_m || !b->adam_v || !b->adam)) return DCCN_ERR_INVALID_ARG;
+    if (!b->workspace || b->workspace_bytes < eq_ws_bytes(sh, train ? 1 : 0)) return DCCN_ERR_WORKSPACE;
+    const EqDims d = eq_dims(sh);
+    Carver c(b->workspace, b->workspace_bytes);
+    EqWs w;
+    eq_carve(c, sh, d, train, w);
+    const float* P = b->eq_params;
+    float* G = b->eq_grads;
+    const int B = d.B, R = d.R, K = d.K, SK2 = d.SK2, K2 = 2 * d.K, N2 = 2 * d.nsc;
+    const long long nBK = (long long)B * SK2;          // floats in a [B,S,K,2] tensor
+    dccn_rx_shape rsh;
+    rsh.batch = B; rsh.S = d.S; rsh.kin = d.nsc; rsh.F = d.F; rsh.D = d.D; rsh.nbits = sh->nbits;
+    const RxLayout L = rx_layout(&rsh);
+    const float* Q = b->rx_params;
+    float* h = b->chest;
+
+    // `input:0` (ofdmreceiver_np.py:128-137) + tx_power partials
+    PowerPartials pp;
+    DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, d.S * N2, 1e-9f, 8.0f, nullptr,
+                       hp, w.ws_norm, w.n_norm, s));
+    // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"
+    hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
+                       (float*)nullptr, d.S * N2, 1e-12f);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_fwd_impl(w.ln, P + d.o[0], P + d.o[1], w.t1, R, N2, K2, s));
+    DCCN_TRY(cconv_fwd_impl(w.t1, P + d.o[2], P + d.o[3], w.y, R, K, K, s));
+    // :394-426 pilot bottleneck
+    DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
+    DCCN_TRY(dense_fwd_impl(w.d1, P + d.o[6], P + d.o[7], w.d2, B, d.Pp, SK2, s));
+    DCCN_TRY(dense_fwd_impl(w.d2, P + d.o[8], P + d.o[9], w.d3, B, SK2, SK2, s));
+    DCCN_TRY(dense_fwd_impl(w.d3, P + d.o[10], P + d.o[11], w.d4, B, SK2, SK2, s));
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.d4, w.d4, nBK);
+    DCCN_LAUNCH_CHECK();
+    // :428 smoothing C-Conv (S x K, same) as a block-Toeplitz dense layer -> channel estimate
+    hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s,
+                       P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s));
+    // :431-438 equalise + autocorrelation
+    hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
+                       (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2);
+    DCCN_LAUNCH_CHECK();
+    if (b->snr_db && b->pilot_carriers && sh->P > 0) {
+        hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
+                           d.S, K, sh->P);
+        DCCN_LAUNCH_CHECK();
+    }
+    // :439-449 C-Conv "IDFT" of corr and eq, :456-463 concat + dense back to the receiver's input
+    DCCN_TRY(cconv_fwd_impl(w.corr, P + d.o[14], P + d.o[15], w.corc, R, K, K, s));
+    DCCN_TRY(cconv_fwd_impl(w.eq, P + d.o[16], P + d.o[17], w.eqc, R, K, K, s));
+    hipLaunchKernelGGL(concat_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float2*)w.eqc,
+                       (const float2*)w.corc, (float4*)w.cat, (long long)R * K);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
+    // frozen basic receiver (model.py:1222-1292) + loss/BER
+    DCCN_TRY(cconv_fwd_impl(b->out_eq, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, d.nsc, d.F, s));
+    DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
+    DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
+                       train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+    if (!train) return DCCN_OK;
+
+    // ---- backward: through the frozen receiver to its input ...
+    DCCN_TRY(dense_bwd_x_impl(w.dz, Q + L.o_dense_w, w.dfft, B, L.dK, L.dN, s));
+    DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout, R, d.nsc, d.F, s));
+    // ... then the equaliser, last layer first
+    DCCN_TRY(dense_bwd_full_impl(w.cat, w.dout, P + d.o[18], w.dcat, G + d.o[18], G + d.o[19], R, 4 * K, N2, w.ws_split,
+                                 w.n_split, s));
+    hipLaunchKernelGGL(split_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float4*)w.dcat,
+                       (float2*)w.deqc, (float2*)w.dcorc, (long long)R * K);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(cconv_bwd_x_impl(w.deqc, P + d.o[16], w.deq, R, K, K, s));
+    DCCN_TRY(cconv_bwd_w_impl(w.eq, w.deqc, G + d.o[16], G + d.o[17], R, K, K, w.ws_split, w.n_split, s));
+    DCCN_TRY(cconv_bwd_x_impl(w.dcorc, P + d.o[14], w.dcorr, R, K, K, s));
+    DCCN_TRY(cconv_bwd_w_impl(w.corr, w.dcorc, G + d.o[14], G + d.o[15], R, K, K, w.ws_split, w.n_split, s));
+    hipLaunchKernelGGL(equalize_bwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
+                       (const float2*)h, (const float2*)w.deq, (const float2*)w.dcorr, (float2*)w.dy, (float2*)w.dh,
+                       nBK / 2);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_split, w.n_split, s));
+    hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
+                       (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.dd4, (const float*)w.d4,
+                       w.dd4, nBK);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_bwd_full_impl(w.d3, w.dd4, P + d.o[10], w.dd3, G + d.o[10], G + d.o[11], B, SK2, SK2, w.ws_split,
+                                 w.n_split, s));
+    DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_split,
+                                 w.n_split, s));
+    DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_split,
+                                 w.n_split, s));
+    DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
+                                 w.n_split, s));
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
+    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
+    DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_split, w.n_split, s));
+    DCCN_TRY(dense_bwd_w_impl(w.ln, w.dt1, G + d.o[0], G + d.o[1], R, N2, K2, w.ws_split, w.n_split, s));
+    // optimizer: Equalizer/* only (ofdmreceiver_np_mp.py:330), L2 terms enter through reg_coef
+    return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s);
+}

@@ -7,6 +7,13 @@
 
 namespace dccn {
 
+// grid size of the grid-stride element-wise kernels below
+static inline unsigned ew_blocks_n(long long n) {
+    long long b = ceil_div_ll(n, 256);
+    if (b > 8 * kCUs) b = 8 * kCUs;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
 // sum over a 256-thread block, result in every thread; `sh` holds >= 4 elements
 template <typename T>
 __device__ __forceinline__ T block_sum_256(T v, T* sh) {
@@ -217,6 +224,32 @@ __global__ __launch_bounds__(64) void cconv2d_same_reduce_kernel(const float* __
         dw[tap * 2] = ga;
         dw[tap * 2 + 1] = gb;
     }
+}
+
+// ---- glue of the fused equaliser step ------------------------------------------------------------------
+// tf.concat([equalized, corr_re], axis=-1) (model.py:456): two IQ-pair streams -> [n, 4]
+__global__ __launch_bounds__(256) void concat_pairs_kernel(const float2* __restrict__ a, const float2* __restrict__ b,
+                                                           float4* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float2 u = a[i], v = b[i];
+        out[i] = make_float4(u.x, u.y, v.x, v.y);
+    }
+}
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restrict__ in, float2* __restrict__ a,
+                                                          float2* __restrict__ b, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float4 v = in[i];
+        a[i] = make_float2(v.x, v.y);
+        b[i] = make_float2(v.z, v.w);
+    }
+}
+// a += b  (the two gradient paths into the frequency-domain input, model.py:383 and :392)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b,
+                                                          long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a[i] += b[i];
 }
 
 }  // namespace dccn

@@ -21,13 +21,76 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import AdamHParams, check
+from ._lib import AdamHParams, EqBuffers, EqShape, check
 from .complex import VariableStore
+from .engine import PARAM_NAMES, param_layout
 from .model import OfdmDenseRx, equalizer_ofdm, ofdm_dense_rx
 
 EQ_REG_COEFF = 1e-3          # ofdmreceiver_np_mp.py:321
 REG_L2 = 0.01                # tf.keras.regularizers.l2(l=0.01) on every dense kernel/bias (model.py:371-462)
 SUPPORTED_OPTS = (0, 9, 10)  # the variants that build ``equalizer_ofdm`` (ofdmreceiver_np_mp.py:285,301-304)
+
+
+class _FusedPlan:
+    """Resident buffers + captured hipGraphs of ``dccn_eq_train_step`` / ``dccn_eq_eval_step`` for one batch
+    size (include/dccn.h: "the fused equaliser transfer-learning step")."""
+
+    def __init__(self, tr: "EqualizerTrainer", batch: int):
+        F, o, dev = tr.FLAGS, tr.ofdmobj, tr.device
+        self.tr, self.batch = tr, int(batch)
+        self.shape = EqShape(self.batch, F.nsymbol, o.K, o.CP, 1, F.nfilter, o.frame_size, F.nbits, o.pilot_size,
+                             len(o.pilotCarriers))
+        offs = (C.c_longlong * 21)()
+        check(tr.lib.dccn_eq_param_offsets(C.byref(self.shape), offs), "dccn_eq_param_offsets")
+        assert offs[20] == tr.n_params and [offs[i] for i in range(20)] == [tr.layout[n][0] for n in tr.names]
+        f32 = dict(dtype=torch.float32, device=dev)
+        B, S, n_sc = self.batch, F.nsymbol, o.K + o.CP
+        self.x = torch.zeros(B, S, n_sc, 2, **f32)
+        self.bits = torch.zeros(B, o.frame_size, F.nbits, dtype=torch.int32, device=dev)
+        self.out_eq = torch.empty(B, S, n_sc, 2, **f32)
+        self.chest = torch.empty(B, S, o.K, 2, **f32)
+        self.snr_db = torch.empty(B, 1, **f32)
+        self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=dev)
+        self.tx_power = torch.zeros(1, **f32)
+        nws = tr.lib.dccn_eq_workspace_size(C.byref(self.shape), 1)
+        self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        p = lambda t: t.data_ptr()          # noqa: E731
+        self.buffers = EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
+                                 p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
+                                 p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
+                                 p(self.ws), nws)
+        self.graphs: Dict[int, C.c_void_p] = {}
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.tr.device).cuda_stream)
+
+    def set_batch(self, x, bits):
+        self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        self.bits.copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
+
+    def run(self, train: bool, graph: bool = True):
+        lib, tr = self.tr.lib, self.tr
+        if not graph:
+            if train:
+                check(lib.dccn_eq_train_step(C.byref(self.shape), C.byref(self.buffers), tr.hp, self._stream()),
+                      "dccn_eq_train_step")
+            else:
+                check(lib.dccn_eq_eval_step(C.byref(self.shape), C.byref(self.buffers), self._stream()),
+                      "dccn_eq_eval_step")
+            return
+        mode = 1 if train else 0
+        if mode not in self.graphs:
+            g = C.c_void_p(0)
+            torch.cuda.synchronize(tr.device)
+            check(lib.dccn_eq_graph_create(C.byref(self.shape), C.byref(self.buffers), mode, tr.hp, self._stream(),
+                                           C.byref(g)), "dccn_eq_graph_create")
+            self.graphs[mode] = g
+        check(lib.dccn_rx_graph_launch(self.graphs[mode], self._stream()), "dccn_rx_graph_launch")
+
+    def close(self):
+        for g in self.graphs.values():
+            self.tr.lib.dccn_rx_graph_destroy(g)
+        self.graphs = {}
 
 
 class EqualizerTrainer:
@@ -61,6 +124,16 @@ class EqualizerTrainer:
         self.hp = AdamHParams.default(float(lr0 if lr0 is not None else getattr(FLAGS, "init_learning", 1e-3)))
         self.adam_state = torch.tensor([0.0, 0.9, 0.999, 0.0], dtype=torch.float32, device=self.device)
         self.last: dict = {}
+        # frozen receiver as one arena (dccn_rx_param_offsets layout) + pilot carriers for the fused step
+        lay, total = param_layout(self.rx.dims())
+        self.rx_arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for n in PARAM_NAMES:
+            o_, shp = lay[n]
+            self.rx_arena[o_:o_ + int(np.prod(shp))] = torch.as_tensor(
+                np.asarray(rx_params[n], dtype=np.float32).reshape(-1)).to(self.device)
+        self.pilot_carriers = torch.as_tensor(np.asarray(ofdmobj.pilotCarriers, dtype=np.int32)).to(self.device)
+        self.fused_ok = bool(FLAGS.cp)               # the planned step covers cp=True (include/dccn.h)
+        self._plans: Dict[int, _FusedPlan] = {}
 
     # ---- arena ---------------------------------------------------------------------------------
     def _flatten(self):
@@ -139,7 +212,32 @@ class EqualizerTrainer:
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
               "dccn_adam_tf_step")
 
-    def train_step(self, x, bits, chan_gt=None) -> dict:
+    def _plan(self, batch: int) -> _FusedPlan:
+        if batch not in self._plans:
+            self._plans[batch] = _FusedPlan(self, batch)
+        return self._plans[batch]
+
+    def _fused_step(self, x, bits, train: bool, graph: bool, chan_gt=None) -> dict:
+        pl = self._plan(int(np.shape(x)[0]) if not isinstance(x, torch.Tensor) else int(x.shape[0]))
+        pl.set_batch(x, bits)
+        pl.run(train, graph)
+        rms = None
+        if chan_gt is not None:
+            rms = self.chan_rms(torch.view_as_complex(pl.chest), chan_gt)
+        return self._metrics(pl.metrics_buf, pl.tx_power, rms)
+
+    def __del__(self):
+        try:
+            for pl in self._plans.values():
+                pl.close()
+        except Exception:
+            pass
+
+    def train_step(self, x, bits, chan_gt=None, fused: bool = True, graph: bool = True) -> dict:
+        """fused=True: the pre-planned ``dccn_eq_train_step`` sequence (hipGraph replay); fused=False: the
+        same kernels composed through the layer API and the autograd tape (the only path for cp=False)."""
+        if fused and self.fused_ok:
+            return self._fused_step(x, bits, True, graph, chan_gt)
         self.grads.zero_()
         ce, mbuf, tx_power, snr_db, chest, _, _ = self._forward(x, bits)
         ce.backward()
@@ -148,7 +246,9 @@ class EqualizerTrainer:
         return self._metrics(mbuf, tx_power, rms)
 
     @torch.no_grad()
-    def eval_step(self, x, bits) -> dict:
+    def eval_step(self, x, bits, fused: bool = True, graph: bool = True) -> dict:
+        if fused and self.fused_ok:
+            return self._fused_step(x, bits, False, graph)
         ce, mbuf, tx_power, _, _, _, _ = self._forward(x, bits)
         return self._metrics(mbuf, tx_power)
 

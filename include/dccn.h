@@ -265,6 +265,52 @@ int dccn_cconv2d_same_expand(const float* w, const float* bias, float* T, float*
 int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw, float* dbias, int L, int W,
                              int kL, int kW, dccn_stream_t stream);
 
+/* ---- the fused equaliser transfer-learning step ------------------------------------------------------
+ * dev/py/ofdmreceiver_np_mp.py:283-330,414 (session.run(train_op...)) and :87 (evaluation run) as ONE
+ * pre-planned launch sequence: R0 normalise -> equalizer_ofdm -> frozen basic receiver -> loss/BER ->
+ * backward to the Equalizer/ variables only -> TF Adam on the equaliser arena.  cp must be 1 (the
+ * composable operators above cover cp=0).  Equaliser parameter arena, TF creation order (floats):
+ *   dense k[2n_sc,2K] b | conv3d k[K,2K] b | dense_1 k[S*K*2,2*pilot_size] b | dense_2 | dense_3 |
+ *   dense_4 | conv3d_1 k[S,K,2] b[2] | conv3d_2 k[K,2K] b | conv3d_3 | dense_5 k[4K,2n_sc] b
+ * (offsets[0..19] = start of each tensor, offsets[20] = total).  rx_params: the frozen receiver in the
+ * dccn_rx_param_offsets layout with kin = n_sc = K + CP. */
+typedef struct dccn_eq_shape {
+    int batch, S, K, CP, cp;      /* frames, OFDM symbols per frame, nfft, cyclic prefix, FLAGS.cp */
+    int F, D, nbits;              /* receiver: nfilter, data cells per frame, bits per cell */
+    int pilot_size, P;            /* pilot cells per frame (model.py:359), pilot carriers per symbol */
+} dccn_eq_shape;
+
+typedef struct dccn_eq_buffers {
+    const float* x;               /* [batch,S,n_sc,2] raw `tx_ofdm` */
+    const int32_t* bits;          /* [batch,D,nbits] */
+    float* eq_params;             /* equaliser arena (updated by the train step) */
+    float* eq_grads;              /* train: gradient arena (data term; L2 enters in the optimizer) */
+    float* adam_m;
+    float* adam_v;
+    const float* reg_coef;        /* nullable, see dccn_adam_tf_step (gate = 1) */
+    dccn_adam_state* adam;
+    const float* rx_params;       /* frozen receiver arena */
+    float* out_eq;                /* [batch,S,n_sc,2] equalised receiver input (model.py:463) */
+    float* chest;                 /* [batch,S,K,2] channel estimate (model.py:477) */
+    float* snr_db;                /* [batch] nullable (model.py:465-475) */
+    const int* pilot_carriers;    /* device int32[P], nullable with snr_db */
+    float* prob;                  /* [batch,D,nbits,2] nullable */
+    dccn_metrics* metrics;
+    float* tx_power;              /* device float[1], nullable */
+    void* workspace;
+    size_t workspace_bytes;
+} dccn_eq_buffers;
+
+int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets /* [21] */);
+size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train);
+int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream);
+int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_adam_hparams hp,
+                       dccn_stream_t stream);
+/* mode bit0: train.  The handle is a dccn_rx_graph: launch / destroy it with dccn_rx_graph_launch /
+ * dccn_rx_graph_destroy. */
+int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,
+                         dccn_stream_t stream, dccn_rx_graph** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,7 +247,9 @@ def _trainer(nbits=2, seed=21):
     return F, tx, ecfg, rcfg, pe, pr, tr
 
 
-def test_trainer_step_gradients_and_adam():
+@pytest.mark.parametrize("mode", ["fused-graph", "fused-eager", "composed"])
+def test_trainer_step_gradients_and_adam(mode):
+    fused, graph = mode != "composed", mode == "fused-graph"
     F, tx, ecfg, rcfg, pe, pr, tr = _trainer()
     rng = np.random.RandomState(7)
     B = 8
@@ -261,7 +263,7 @@ def test_trainer_step_gradients_and_adam():
                            literal_conv=False)
         lit = LiteralEqualizer({k: v.astype(np.float64).reshape(pe[k].shape) for k, v in p_before.items()}, lit_rx, ecfg)
         g_ref, info = lit.forward_backward(x.astype(np.float64), bits)
-        m = tr.train_step(x, bits)
+        m = tr.train_step(x, bits, fused=fused, graph=graph)
         assert abs(m["ce_mean"] - info["ce_mean"]) <= 3e-6 * abs(info["ce_mean"])
         assert np.array_equal(np.asarray(m["conf"]).reshape(2, 2), info["conf"])
         assert abs(tr.total_loss(m) - info["loss"]) <= 5e-3 * abs(info["loss"])      # reg term read after the update: loose
@@ -348,3 +350,28 @@ def test_equalizer_learns_a_flat_fading_channel():
     import os
     assert os.path.basename(sw["EPA"][3]) == "Test_DCCN_B_Equalizer0_Flat_test_chan_EPA.csv" and os.path.exists(sw["EPA"][3])
     assert len(sw["Flat"][1]) == 3
+
+
+def test_fused_step_equals_composed_step():
+    """the planned launch sequence and the autograd-composed one run the same kernels on the same arenas"""
+    F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=31)
+    _, _, _, _, _, _, tr_b = _trainer(seed=31)
+    rng = np.random.RandomState(9)
+    for step in range(4):
+        x = (rng.standard_normal((12, 7, 80, 2)) * 2).astype(np.float32)
+        bits = rng.randint(0, 2, (12, tx.frame_size, 2)).astype(np.int32)
+        chan = (rng.standard_normal((12, 7, 64)) + 1j * rng.standard_normal((12, 7, 64))).astype(np.complex64)
+        ma = tr_a.train_step(x, bits, chan, fused=True, graph=(step % 2 == 0))
+        mb = tr_b.train_step(x, bits, chan, fused=False)
+        assert ma["conf"] == mb["conf"] and abs(ma["ce_mean"] - mb["ce_mean"]) <= 1e-6
+        assert abs(ma["chan_rms"] - mb["chan_rms"]) <= 1e-5 * abs(mb["chan_rms"])
+        assert abs(ma["tx_power"] - mb["tx_power"]) <= 1e-6 * abs(mb["tx_power"])
+        ga, gb = tr_a.grads.cpu().numpy(), tr_b.grads.cpu().numpy()
+        assert np.abs(ga - gb).max() <= 1e-5 * np.abs(gb).max()
+    ea, eb = tr_a.eval_step(x, bits, fused=True), tr_b.eval_step(x, bits, fused=False)
+    assert ea["conf"] == eb["conf"] and abs(ea["ce_mean"] - eb["ce_mean"]) <= 1e-6
+    pl = tr_a._plan(12)
+    out_b = tr_b._forward(x, bits)
+    close(pl.out_eq, out_b[5].detach().cpu().numpy(), 1e-5, "out_eq")
+    close(pl.snr_db, out_b[3].detach().cpu().numpy(), 1e-5, "snr_db")
+    close(pl.chest, torch.view_as_real(out_b[4]).cpu().numpy(), 1e-5, "chest")

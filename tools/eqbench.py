@@ -44,22 +44,30 @@ def main():
     for B in a.frames:
         x = torch.randn(B, 7, 80, 2, device="cuda")
         bits = torch.randint(0, 2, (B, tx.frame_size, 2), dtype=torch.int32, device="cuda")
-        for _ in range(a.warmup):
-            tr.train_step(x, bits)
-        torch.cuda.synchronize()
-        t = HipTimer()
-        st = torch.cuda.current_stream().cuda_stream
-        t.start(st)
-        for _ in range(a.steps):
+        fl = step_flops(B)
+        pl = tr._plan(B)
+        pl.set_batch(x, bits)
+
+        def composed():
             tr.grads.zero_()
             ce, mbuf, *_ = tr._forward(x, bits)
             ce.backward()
             tr._adam_step()
-        t.stop(st)
-        ms = t.elapsed_ms() / a.steps
-        fl = step_flops(B)
-        print(json.dumps(dict(frames=B, ms_per_step=round(ms, 4), symbols_per_s=round(B * 7 / ms * 1e3),
-                              gflop_per_step=round(fl / 1e9, 3), tflops=round(fl / ms / 1e9, 2))))
+
+        for name, fn in (("fused-graph", lambda: pl.run(True, True)), ("fused-eager", lambda: pl.run(True, False)),
+                         ("composed-autograd", composed)):
+            for _ in range(a.warmup):
+                fn()
+            torch.cuda.synchronize()
+            t = HipTimer()
+            st = torch.cuda.current_stream().cuda_stream
+            t.start(st)
+            for _ in range(a.steps):
+                fn()
+            t.stop(st)
+            ms = t.elapsed_ms() / a.steps
+            print(json.dumps(dict(path=name, frames=B, ms_per_step=round(ms, 4), symbols_per_s=round(B * 7 / ms * 1e3),
+                                  gflop_per_step=round(fl / 1e9, 3), tflops=round(fl / ms / 1e9, 2))))
 
 
 if __name__ == "__main__":
