@@ -125,6 +125,13 @@ SIGNATURES = {
     "dccn_eq_eval_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), _vp]),
     "dccn_eq_train_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), AdamHParams, _vp]),
     "dccn_eq_graph_create": (_i, [POINTER(EqShape), POINTER(EqBuffers), _i, AdamHParams, _vp, POINTER(c_void_p)]),
+    # device-side input generator
+    "dccn_philox_fill": (_i, [_vp, _ll, C.c_uint, C.c_uint, C.c_ulonglong, _vp]),
+    "dccn_ofdm_tx_frames": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_ulonglong,
+                                 C.c_uint, _vp]),
+    "dccn_channel_awgn_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_channel_awgn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, C.c_ulonglong,
+                               C.c_uint, _vp, _sz, _vp]),
 }
 
 _lib = None

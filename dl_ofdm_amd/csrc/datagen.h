@@ -1,0 +1,206 @@
+// Device-side input generator: what the reference produces per batch on the host with
+// NumPy -- label bits (dev/py/util.py:25-29), the OFDM transmitter (dev/py/ofdm.py:328-380), a static
+// multipath Rayleigh channel (dev/py/radio.py:277-372, 409-470) and AWGN (radio.py:513-526) -- written
+// straight into the receiver engine's resident input buffers.  Random streams are Philox4x32-10
+// (counter = (index lo, index hi, stream, batch offset), key = seed), so a batch is a pure function of
+// (seed, offset) and every thread draws independently.  All of it is one pass over HBM; the IFFT + cyclic
+// prefix is a dense MFMA GEMM with a constant [2K, 2(K+CP)] matrix (gemm_f32_mfma.h).
+#pragma once
+#include "common.h"
+
+namespace dccn {
+
+constexpr unsigned kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u, kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
+constexpr int kStreamBits = 0, kStreamTaps = 1, kStreamNoise = 2;
+
+struct Philox4 {
+    unsigned v[4];
+};
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long index, unsigned stream, unsigned offset,
+                                                 unsigned long long seed) {
+    unsigned c0 = (unsigned)index, c1 = (unsigned)(index >> 32), c2 = stream, c3 = offset;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(kPhiloxM0, c0), lo0 = kPhiloxM0 * c0;
+        const unsigned hi1 = __umulhi(kPhiloxM1, c2), lo1 = kPhiloxM1 * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += kPhiloxW0;
+        k1 += kPhiloxW1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+__device__ __forceinline__ float uniform01(unsigned w) { return ((float)(w >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+__device__ __forceinline__ float2 box_muller(unsigned w0, unsigned w1) {
+    const float r = sqrtf(-2.0f * logf(uniform01(w0)));
+    float sn, cs;
+    sincosf(6.2831853071795864769f * uniform01(w1), &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+
+// test hook: out[i] = the four words of counter (i, stream, offset)
+__global__ __launch_bounds__(256) void philox_fill_kernel(unsigned* __restrict__ out, long long n, unsigned stream,
+                                                          unsigned offset, unsigned long long seed) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Philox4 p = philox4x32_10((unsigned long long)i, stream, offset, seed);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[i * 4 + j] = p.v[j];
+}
+
+// util.py:25-29 bit_source + ofdm.py:339-356 constellation / pilot / guard mapping: one thread per resource
+// cell.  cell_map[S*K]: >= 0 data-cell index d, -1 pilot, -2 empty.  bits_in == nullptr: draw the label bits
+// (bit j of cell (frame,d) = bit j of Philox word 0 at index frame*D+d) and store them to bits_out;
+// the constellation index is MSB-first over the nbits labels (ofdm.py:121-153 const_map order).
+__global__ __launch_bounds__(256) void tx_grid_kernel(const int* __restrict__ bits_in, int* __restrict__ bits_out,
+                                                      const int* __restrict__ cell_map,
+                                                      const float2* __restrict__ const_tab, float2 pilot,
+                                                      float2* __restrict__ grid, long long n_cells, int SK, int D,
+                                                      int nbits, unsigned offset, unsigned long long seed) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cells) return;
+    const long long frame = i / SK;
+    const int d = cell_map[(int)(i - frame * SK)];
+    float2 v = make_float2(0.f, 0.f);
+    if (d == -1) {
+        v = pilot;
+    } else if (d >= 0) {
+        const long long cell = frame * D + d;
+        unsigned word = 0;
+        if (!bits_in) word = philox4x32_10((unsigned long long)cell, kStreamBits, offset, seed).v[0];
+        int idx = 0;
+        for (int j = 0; j < nbits; ++j) {
+            const int b = bits_in ? (bits_in[cell * nbits + j] & 1) : (int)((word >> j) & 1u);
+            if (bits_out) bits_out[cell * nbits + j] = b;
+            idx = (idx << 1) | b;
+        }
+        v = const_tab[idx];
+    }
+    grid[i] = v;
+}
+
+// radio.py:352-372 static taps: tap_k = (z0 + i z1)/sqrt(2) * coeff_k, impulse response g = taps . alpha
+// ([n_taps, L] sinc-interpolation matrix), H = fft(g, nfft).  One block (64 threads) per frame.
+// taps_in (standard normals [n, n_taps, 2]) == nullptr: draw them.  identity != 0: g = [1] (AWGN channel).
+__global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restrict__ taps_in,
+                                                          const float* __restrict__ coeff,
+                                                          const float* __restrict__ alpha, float2* __restrict__ g,
+                                                          float2* __restrict__ H, int n_taps, int L, int nfft,
+                                                          int identity, unsigned offset, unsigned long long seed) {
+    __shared__ float2 tap[16];
+    __shared__ float2 gs[64];
+    const int fr = blockIdx.x, t = threadIdx.x;
+    if (identity) {
+        if (t < L) gs[t] = make_float2(t == 0 ? 1.f : 0.f, 0.f);
+    } else {
+        if (t < n_taps) {
+            float2 z;
+            if (taps_in) {
+                z = make_float2(taps_in[((size_t)fr * n_taps + t) * 2], taps_in[((size_t)fr * n_taps + t) * 2 + 1]);
+            } else {
+                const Philox4 p = philox4x32_10((unsigned long long)fr * n_taps + t, kStreamTaps, offset, seed);
+                z = box_muller(p.v[0], p.v[1]);
+            }
+            const float c = coeff[t] * 0.70710678118654752440f;
+            tap[t] = make_float2(z.x * c, z.y * c);
+        }
+        __syncthreads();
+        if (t < L) {
+            float2 a = make_float2(0.f, 0.f);
+            for (int k = 0; k < n_taps; ++k) {
+                const float w = alpha[k * L + t];
+                a.x += tap[k].x * w;
+                a.y += tap[k].y * w;
+            }
+            gs[t] = a;
+        }
+    }
+    __syncthreads();
+    if (t < L) g[(size_t)fr * L + t] = gs[t];
+    if (H) {
+        for (int f = t; f < nfft; f += 64) {
+            float2 a = make_float2(0.f, 0.f);
+            for (int l = 0; l < L; ++l) {
+                float sn, cs;
+                sincosf(-6.2831853071795864769f * (float)((f * l) % nfft) / (float)nfft, &sn, &cs);
+                a.x += gs[l].x * cs - gs[l].y * sn;
+                a.y += gs[l].x * sn + gs[l].y * cs;
+            }
+            H[(size_t)fr * nfft + f] = a;
+        }
+    }
+}
+
+// radio.py:360-366: y = np.convolve(frame, g, 'same') over the frame's T = n_sym*n_sc samples
+// (y[t] = sum_l g[l] x[t + off - l], off = (L-1)//2, zero outside the frame) + per-block partial sums of
+// |y|^2 for the AWGN stage's power normalisation.  grid = (ceil(T/256), frames).
+__global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
+                                                       float2* __restrict__ y, double* __restrict__ partial, int T,
+                                                       int L) {
+    __shared__ double sh[4];
+    __shared__ float2 gs[64];
+    const int fr = blockIdx.y;
+    if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * L + threadIdx.x];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int off = (L - 1) / 2;
+    double pw = 0.0;
+    if (t < T) {
+        const float2* xf = x + (size_t)fr * T;
+        float2 a = make_float2(0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const int u = t + off - l;
+            if (u < 0 || u >= T) continue;
+            const float2 v = xf[u];
+            a.x += gs[l].x * v.x - gs[l].y * v.y;
+            a.y += gs[l].x * v.y + gs[l].y * v.x;
+        }
+        y[(size_t)fr * T + t] = a;
+        pw = (double)a.x * a.x + (double)a.y * a.y;
+    }
+    pw = wave_sum(pw);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// radio.py:513-526 AWGN_channel_np: out = y / sqrt(mean |y|^2 over the batch) + noise * sqrt(0.5) 10^(-SNR/20),
+// SNR per frame; mean_power[0] = mean |y|^2 (sum_partials_kernel over the FIR stage's partials).
+// noise_in (standard normals [n, T, 2]) == nullptr: draw them.  Also emits the per-block partial sums of the
+// noise power (finished by sum_partials_kernel).  grid = (ceil(T/256), frames).
+__global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y, const float* __restrict__ mean_power,
+                                                   const float* __restrict__ snr_db,
+                                                   const float* __restrict__ noise_in, float2* __restrict__ out,
+                                                   double* __restrict__ noise_partial, int T, unsigned offset,
+                                                   unsigned long long seed) {
+    __shared__ double sh[4];
+    const float inv_scale = 1.0f / sqrtf(mean_power[0]);
+    const int fr = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    double pw = 0.0;
+    if (t < T) {
+        const size_t i = (size_t)fr * T + t;
+        const float std_ = 0.70710678118654752440f * exp10f(-snr_db[fr] * 0.05f);
+        float2 z;
+        if (noise_in) {
+            z = make_float2(noise_in[2 * i], noise_in[2 * i + 1]);
+        } else {
+            const Philox4 p = philox4x32_10((unsigned long long)i, kStreamNoise, offset, seed);
+            z = box_muller(p.v[0], p.v[1]);
+        }
+        z.x *= std_;
+        z.y *= std_;
+        const float2 v = y[i];
+        out[i] = make_float2(v.x * inv_scale + z.x, v.y * inv_scale + z.y);
+        pw = (double)z.x * z.x + (double)z.y * z.y;
+    }
+    pw = wave_sum(pw);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0 && noise_partial)
+        noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+}  // namespace dccn

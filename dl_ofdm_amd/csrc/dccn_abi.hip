@@ -9,6 +9,7 @@
 #include "norm_adam.h"
 #include "tail.h"
 #include "equalizer.h"
+#include "datagen.h"
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
@@ -841,6 +842,78 @@ int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw,
     hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(kL * kW + 1), dim3(64), 0, (hipStream_t)stream, dT, dbias_eff,
                        dw, dbias, L, W, kL, kW);
     DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---- device-side input generator ------------------------------------------------------------------
+int dccn_philox_fill(uint32_t* out, long long n, unsigned stream, unsigned offset, unsigned long long seed,
+                     dccn_stream_t stream_handle) {
+    if (!out || n <= 0) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream_handle, out, n, stream, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t* cell_map, const float* const_tab,
+                        float pilot_re, float pilot_im, const float* idft, float* grid_ws, float* tx, int frames,
+                        int S, int K, int CP, int D, int nbits, unsigned long long seed, unsigned offset,
+                        dccn_stream_t stream) {
+    if (!cell_map || !const_tab || !idft || !grid_ws || !tx || frames <= 0 || S <= 0 || K <= 0 || CP < 0 || D <= 0 ||
+        nbits < 1 || nbits > 4)
+        return DCCN_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_cells = (long long)frames * S * K;
+    hipLaunchKernelGGL(tx_grid_kernel, dim3((unsigned)ceil_div_ll(n_cells, 256)), dim3(256), 0, s, bits_in, bits_out,
+                       cell_map, (const float2*)const_tab, make_float2(pilot_re, pilot_im), (float2*)grid_ws, n_cells,
+                       S * K, D, nbits, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    return dense_fwd_impl(grid_ws, idft, nullptr, tx, frames * S, 2 * K, 2 * (K + CP), s);
+}
+static int chan_blocks_x(int T) { return ceil_div(T, 256); }
+size_t dccn_channel_awgn_workspace_size(int frames, int T, int L) {
+    if (frames <= 0 || T <= 0 || L <= 0) return 0;
+    size_t o = 0;
+    o = carve_size(o, (size_t)frames * L * 2 * sizeof(float));
+    o = carve_size(o, (size_t)frames * T * 2 * sizeof(float));
+    o = carve_size(o, (size_t)frames * chan_blocks_x(T) * sizeof(double));
+    o = carve_size(o, (size_t)frames * chan_blocks_x(T) * sizeof(double));
+    o = carve_size(o, 4 * sizeof(float));
+    return align_up(o, 256);
+}
+int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff, const float* alpha, int n_taps,
+                      int L, int identity, const float* snr_db, const float* noise_in, float* out, float* H, int nfft,
+                      float* noise_power, int frames, int T, unsigned long long seed, unsigned offset,
+                      void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!tx || !snr_db || !out || frames <= 0 || frames > 65535 || T <= 0 || L <= 0 || L > 64) return DCCN_ERR_INVALID_ARG;
+    if (!identity && (!coeff || !alpha || n_taps <= 0 || n_taps > 16)) return DCCN_ERR_INVALID_ARG;
+    if (H && nfft <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_channel_awgn_workspace_size(frames, T, L)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    float* g = c.take<float>((size_t)frames * L * 2);
+    float* y = c.take<float>((size_t)frames * T * 2);
+    const int bx = chan_blocks_x(T);
+    double* partial = c.take<double>((size_t)frames * bx);
+    double* npartial = c.take<double>((size_t)frames * bx);
+    float* mean_power = c.take<float>(4);
+    hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
+                       n_taps, L, nfft, identity, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fir_same_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                       (float2*)y, partial, T, L);
+    DCCN_LAUNCH_CHECK();
+    const double total = (double)frames * (double)T;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
+                       mean_power);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
+                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    if (noise_power) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
+                           noise_power);
+        DCCN_LAUNCH_CHECK();
+    }
     return DCCN_OK;
 }
 

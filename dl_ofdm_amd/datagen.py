@@ -1,0 +1,140 @@
+"""Device-side input generator: label bits -> OFDM frames -> static Rayleigh / flat /
+AWGN channel -> noise, produced on the GPU straight into the receiver engine's resident buffers.
+
+The reference generates every epoch on the host with NumPy (dev/py/ofdmreceiver_np.py:220-229:
+``bit_source`` -> ``ofdm_tx_frame_np`` -> ``rayleigh_chan_lte.run`` -> ``AWGN_channel_np``); that host path is
+kept in ofdm.py / radio.py (bit-pinned to the reference) and is ~2000x slower than the fused GPU step.
+``DeviceDataGen.make_batch`` is the same chain as libdccn kernels (include/dccn.h: "device-side input
+generator"): same constellation tables, grid layout, ifft + cyclic prefix (as one MFMA GEMM), tap model,
+'same' FIR, power normalisation and noise scaling; its random streams are Philox4x32-10 instead of NumPy's
+Mersenne Twister, so agreement with the host path is exact for the deterministic stages (given the same
+bits / tap draws / noise draws -- tests/test_gpu_datagen.py) and statistical for the draws themselves.
+
+Scope: the static single-profile channels of the reference's sweep driver ('AWGN', 'Flat', 'EPA', 'EVA',
+'ETU', 'Custom', mobile=False).  Doppler (mobile=True) and the frame-interleaved 'mix*' channels stay on the
+host path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ofdm, radio
+from ._lib import check
+
+
+class DeviceDataGen:
+    def __init__(self, FLAGS, ofdmobj=None, device="cuda", seed: int = 1, mobile: bool = False):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DccnError("DeviceDataGen needs a CUDA (ROCm) device; use ofdm.py/radio.py on the host")
+        self.FLAGS, self.o = FLAGS, ofdmobj or ofdm.ofdm_tx(FLAGS)
+        chan = FLAGS.channel.lower()
+        if mobile or chan in ("mixrayleigh", "mixall"):
+            raise NotImplementedError("device generator covers static single-profile channels; "
+                                      "use radio.rayleigh_chan_lte for mobile / mix channels")
+        o = self.o
+        self.S, self.K, self.CP, self.D, self.nbits = o.nSymbol, o.K, o.CP, o.frame_size, int(FLAGS.nbits)
+        self.n_sc, self.T = o.K + o.CP, o.nSymbol * (o.K + o.CP)
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+        dev = self.device
+        cell = np.full(self.S * self.K, -2, dtype=np.int32)
+        cell[o.dataSc] = np.arange(self.D, dtype=np.int32)
+        cell[o.pilotSc] = -1
+        self.cell_map = torch.from_numpy(cell).to(dev)
+        tab = ofdm.const_map(self.nbits)
+        self.const_tab = torch.from_numpy(np.stack([tab.real, tab.imag], -1).astype(np.float32)).to(dev)
+        self.pilot = complex(o.pilotValue)
+        self.idft = torch.from_numpy(self.idft_cp_matrix(self.K, self.CP)).to(dev)
+        self.identity = chan == "awgn"
+        prof = radio._Profile(chan, False, radio._alpha_matrices())
+        self.n_taps, self.L = int(prof.n_taps), int(prof.alpha.shape[1])
+        self.coeff = torch.from_numpy(np.asarray(prof.ch_coeff, dtype=np.float32)).to(dev)
+        self.alpha = torch.from_numpy(np.ascontiguousarray(prof.alpha, dtype=np.float32)).to(dev)
+        if self.identity:
+            self.L = 1
+        self._ws = {}
+
+    @staticmethod
+    def idft_cp_matrix(K: int, CP: int) -> np.ndarray:
+        """real [2K, 2(K+CP)] form of ``np.fft.ifft`` followed by the cyclic-prefix copy (ofdm.py:357-362):
+        row (k, iq) -> column (t', iq'), t = (t' - CP) mod K, W = exp(+2 pi i k t / K) / K."""
+        k = np.arange(K)[:, None]
+        t = (np.arange(K + CP)[None, :] - CP) % K
+        w = np.exp(2j * np.pi * k * t / K) / K
+        m = np.empty((K, 2, K + CP, 2), dtype=np.float64)
+        m[:, 0, :, 0], m[:, 0, :, 1] = w.real, w.imag
+        m[:, 1, :, 0], m[:, 1, :, 1] = -w.imag, w.real
+        return m.reshape(2 * K, 2 * (K + CP)).astype(np.float32)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, n: int):
+        if n not in self._ws:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            nws = self.lib.dccn_channel_awgn_workspace_size(n, self.T, self.L)
+            self._ws[n] = dict(grid=torch.empty(n, self.S, self.K, 2, **f32), tx=torch.empty(n, self.S, self.n_sc, 2, **f32),
+                               ws=torch.empty(nws, dtype=torch.uint8, device=self.device), nws=nws,
+                               snr=torch.empty(n, **f32), npow=torch.zeros(1, **f32))
+        return self._ws[n]
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else t.data_ptr()
+
+    def transmit(self, n_frames: int, bits: Optional[torch.Tensor] = None, out_bits: Optional[torch.Tensor] = None,
+                 offset: Optional[int] = None):
+        """(tx [n,S,n_sc,2], bits int32 [n,D,nbits]); ``bits`` given: modulate those (no draw)."""
+        w = self._workspace(n_frames)
+        off = self.offset if offset is None else int(offset)
+        if bits is not None:
+            bits = torch.as_tensor(bits).to(device=self.device, dtype=torch.int32).contiguous()
+            out_bits = bits
+        elif out_bits is None:
+            out_bits = torch.empty(n_frames, self.D, self.nbits, dtype=torch.int32, device=self.device)
+        check(self.lib.dccn_ofdm_tx_frames(self._p(bits), None if bits is not None else self._p(out_bits),
+                                           self._p(self.cell_map), self._p(self.const_tab), self.pilot.real,
+                                           self.pilot.imag, self._p(self.idft), self._p(w["grid"]), self._p(w["tx"]),
+                                           n_frames, self.S, self.K, self.CP, self.D, self.nbits, self.seed, off,
+                                           self._stream()), "dccn_ofdm_tx_frames")
+        return w["tx"], out_bits
+
+    def channel(self, tx: torch.Tensor, snr_db, out_x: Optional[torch.Tensor] = None, taps: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None, want_H: bool = False, offset: Optional[int] = None):
+        """fading + AWGN on [n,S,n_sc,2] frames; ``taps`` / ``noise``: external standard normals instead of draws."""
+        n = tx.shape[0]
+        w = self._workspace(n)
+        off = self.offset if offset is None else int(offset)
+        if isinstance(snr_db, torch.Tensor):
+            w["snr"].copy_(snr_db.reshape(-1).to(torch.float32))
+        elif np.isscalar(snr_db):
+            w["snr"].fill_(float(snr_db))
+        else:
+            w["snr"].copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)))
+        if out_x is None:
+            out_x = torch.empty(n, self.S, self.n_sc, 2, dtype=torch.float32, device=self.device)
+        H = torch.empty(n, self.K, 2, dtype=torch.float32, device=self.device) if want_H else None
+        if taps is not None:
+            taps = torch.as_tensor(taps, dtype=torch.float32).to(self.device).contiguous()
+        if noise is not None:
+            noise = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()
+        check(self.lib.dccn_channel_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
+                                         self.n_taps, self.L, 1 if self.identity else 0, self._p(w["snr"]),
+                                         self._p(noise), self._p(out_x), self._p(H), self.K, self._p(w["npow"]), n,
+                                         self.T, self.seed, off, self._p(w["ws"]), w["nws"], self._stream()),
+              "dccn_channel_awgn")
+        return out_x, w["npow"], (torch.view_as_complex(H) if want_H else None)
+
+    def make_batch(self, n_frames: int, snr_db, out_x: Optional[torch.Tensor] = None,
+                   out_bits: Optional[torch.Tensor] = None, want_H: bool = False):
+        """receiver.make_batch on the device: (x float32 [n,S,n_sc,2], bits int32 [n,D,nbits], noise power[, H]);
+        advances the batch offset so consecutive calls draw fresh data."""
+        tx, bits = self.transmit(n_frames, out_bits=out_bits)
+        x, npow, H = self.channel(tx, snr_db, out_x=out_x, want_H=want_H)
+        self.offset = (self.offset + 1) & 0xFFFFFFFF
+        return (x, bits, npow, H) if want_H else (x, bits, npow)

@@ -311,6 +311,37 @@ int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, d
 int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,
                          dccn_stream_t stream, dccn_rx_graph** out);
 
+/* ==== device-side input generator ================================================
+ * What the reference computes per batch on the host with NumPy, written straight into device buffers.
+ * Random streams: Philox4x32-10, counter = (index lo, index hi, stream, offset), key = seed; a batch is
+ * a pure function of (seed, offset).  Streams: 0 label bits, 1 channel taps, 2 noise. */
+
+/* test hook: out[4*i..4*i+3] = Philox words of counter (i, stream, offset) */
+int dccn_philox_fill(uint32_t* out, long long n, unsigned stream, unsigned offset, unsigned long long seed,
+                     dccn_stream_t stream_handle);
+
+/* dev/py/util.py:25-29 bit_source + dev/py/ofdm.py:328-380 ofdm_tx_frame_np.
+ * bits_in [frames,D,nbits] nullable (null: draw the labels and store them to bits_out, nullable otherwise);
+ * cell_map int32[S*K]: >= 0 data-cell index, -1 pilot, -2 empty; const_tab [2^nbits,2] (MSB-first index);
+ * idft [2K, 2(K+CP)]: real form of ifft + cyclic prefix; grid_ws [frames,S,K,2] scratch;
+ * tx [frames,S,K+CP,2] time-domain frames. */
+int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t* cell_map, const float* const_tab,
+                        float pilot_re, float pilot_im, const float* idft, float* grid_ws, float* tx, int frames,
+                        int S, int K, int CP, int D, int nbits, unsigned long long seed, unsigned offset,
+                        dccn_stream_t stream);
+
+/* dev/py/radio.py:352-372 (static Rayleigh taps, 'same' FIR over the frame) + :513-526 AWGN_channel_np.
+ * tx [frames,T,2]; taps_in [frames,n_taps,2] standard normals, nullable (null: draw); coeff [n_taps];
+ * alpha [n_taps,L] (L <= 64, n_taps <= 16); identity != 0: pass-through channel (AWGN only);
+ * snr_db [frames]; noise_in [frames,T,2] standard normals, nullable (null: draw);
+ * out [frames,T,2] = y/sqrt(mean|y|^2) + noise; H [frames,nfft,2] nullable = fft(impulse response, nfft);
+ * noise_power device float[1] nullable. */
+size_t dccn_channel_awgn_workspace_size(int frames, int T, int L);
+int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff, const float* alpha, int n_taps,
+                      int L, int identity, const float* snr_db, const float* noise_in, float* out, float* H, int nfft,
+                      float* noise_power, int frames, int T, unsigned long long seed, unsigned offset,
+                      void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

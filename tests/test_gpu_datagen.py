@@ -1,0 +1,155 @@
+"""Device-side input generator against the host substrate (dl_ofdm_amd/ofdm.py, radio.py --
+themselves bit-pinned to the reference by tests/test_golden_substrate.py) and oracle/datagen_oracle.py.
+
+Deterministic stages: fed the same bits / tap draws / noise draws, fp32 kernels vs the fp64 host chain agree to
+1e-5 of the signal scale.  Random streams: Philox words bit-exact vs the oracle (which carries the Random123
+known-answer vectors); label bits bit-exact; normals to 2e-6 (libm differences in log/sincos); moments within
+5 sigma.  End to end: closed-form AWGN BER through the analytic DFT receiver."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import datagen_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def flags(**kw):
+    from dl_ofdm_amd.receiver import Flags
+    f = Flags(channel="EPA", nfilter=64, nbits=2, SNR=5.0)
+    for k, v in kw.items():
+        setattr(f, k, v)
+    return f
+
+
+def test_philox_words_bit_exact():
+    from dl_ofdm_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    n = 5000
+    for stream, off, seed in ((0, 0, 1), (2, 7, 0xDEADBEEFCAFE1234), (1, 0xFFFFFFFF, 42)):
+        out = torch.zeros(n, 4, dtype=torch.int32, device="cuda")
+        _lib.check(lib.dccn_philox_fill(out.data_ptr(), n, stream, off, seed, None), "philox")
+        want = G.philox4x32_10(G.counters(np.arange(n), stream, off), G.key_of(seed))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+    for c, k, o in G.KAT:                                       # the oracle itself is pinned by the published vectors
+        assert tuple(int(v) for v in G.philox4x32_10(np.array(c, dtype=np.uint32), k)) == o
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4])
+def test_transmitter_matches_host(nbits):
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(nbits=nbits)
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=3)
+    rng = np.random.RandomState(nbits)
+    bits = rng.randint(0, 2, (37, o.frame_size, nbits))
+    _, want, _ = o.ofdm_tx_frame_np(bits)
+    tx, b = gen.transmit(37, bits=bits)
+    assert np.abs(tx.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    # drawn labels: bit-exact vs the oracle stream, and the frames are the modulation of exactly those labels
+    tx2, b2 = gen.transmit(11, offset=5)
+    want_bits = G.bits(3, 5, 11, o.frame_size, nbits)
+    assert np.array_equal(b2.cpu().numpy(), want_bits)
+    _, want2, _ = o.ofdm_tx_frame_np(want_bits)
+    assert np.abs(tx2.cpu().numpy() - want2).max() <= 1e-5 * np.abs(want2).max()
+
+
+@pytest.mark.parametrize("chan", ["EPA", "EVA", "ETU", "Flat", "Custom", "AWGN"])
+def test_channel_and_awgn_match_host_given_the_same_draws(chan):
+    from dl_ofdm_amd import ofdm, radio, util
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(channel=chan)
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=9)
+    n = 23
+    np.random.seed(77)
+    bits = util.bit_source(2, o.frame_size, n)
+    iq, _, _ = o.ofdm_tx_frame_np(bits)
+    fading = radio.rayleigh_chan_lte(F, o.Fs)
+    snr = np.linspace(-3, 25, n).reshape(n, 1)
+    np.random.seed(123)
+    y_host, H_host = fading.run(iq)
+    out_host, npow_host = radio.AWGN_channel_np(y_host, snr)
+    # replay numpy's draws: per frame normal(size=[n_taps,2]) (radio.py static taps), then randn(*shape)
+    np.random.seed(123)
+    taps = None
+    if chan != "AWGN":
+        taps = np.stack([np.random.normal(loc=0.0, scale=1.0, size=[gen.n_taps, 2]) for _ in range(n)])
+        # the host draws with scale 1/sqrt(2); standard normals * 1/sqrt(2) are the same stream scaled
+    noise = np.random.randn(n, 7, 80, 2)
+    tx, _ = gen.transmit(n, bits=bits)
+    out, npow, H = gen.channel(tx, snr, taps=taps, noise=noise.reshape(n, -1, 2), want_H=True)
+    scale = np.abs(out_host).max()
+    assert np.abs(out.cpu().numpy() - out_host).max() <= 2e-5 * scale
+    assert abs(float(npow) - npow_host) <= 1e-5 * npow_host
+    Hh = H_host[:, 0, :]
+    assert np.abs(H.cpu().numpy() - Hh).max() <= 2e-5 * max(np.abs(Hh).max(), 1.0)
+
+
+def test_random_streams_statistics():
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(channel="ETU")
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=11)
+    n = 4000
+    x, bits, npow, H = gen.make_batch(n, 10.0, want_H=True)
+    b = bits.cpu().numpy()
+    N = b.size
+    assert abs(b.mean() - 0.5) <= 5 * 0.5 / math.sqrt(N)
+    assert abs(float(npow) - 0.1) <= 5 * 0.1 / math.sqrt(n * 560)            # E|n|^2 = 10^(-SNR/10)
+    xp = x.cpu().numpy()
+    sig_plus_noise = (xp ** 2).sum(-1).mean()
+    assert abs(sig_plus_noise - 1.1) <= 0.02                                  # unit signal power + noise
+    Hn = H.cpu().numpy()
+    coeff, alpha = gen.coeff.cpu().numpy().astype(np.float64), gen.alpha.cpu().numpy().astype(np.float64)
+    expect = float(((coeff[:, None] * alpha) ** 2).sum())          # Parseval: mean_f |H|^2 = sum_l E|g_l|^2
+    assert abs((np.abs(Hn) ** 2).mean() - expect) <= 0.05 * expect
+    # the drawn normals are the oracle's stream: isolate them as (noisy - noiseless) on an AWGN pass-through
+    gen2 = DeviceDataGen(flags(channel="AWGN"), o, seed=11)
+    tx1, _ = gen2.transmit(1, offset=0)
+    o1 = gen2.channel(tx1, 0.0, offset=0)[0].clone()
+    o2 = gen2.channel(tx1, 0.0, offset=0, noise=np.zeros((1, 560, 2), np.float32))[0].clone()
+    drawn = (o1 - o2).cpu().numpy().reshape(-1, 2)[:64] / math.sqrt(0.5)
+    assert np.abs(drawn - G.noise_normals(11, 0, 64)).max() <= 2e-5
+    # consecutive batches differ; the same (seed, offset) repeats exactly
+    a = gen2.make_batch(3, 5.0)[0].clone()
+    b2 = gen2.make_batch(3, 5.0)[0].clone()
+    assert not torch.equal(a, b2)
+    gen3 = DeviceDataGen(flags(channel="AWGN"), o, seed=11)
+    assert torch.equal(gen3.make_batch(3, 5.0)[0], a)
+
+
+@pytest.mark.parametrize("nbits,snr_db", [(1, 1.0), (2, 4.0)])
+def test_awgn_ber_closed_form_with_device_generated_data(nbits, snr_db):
+    from test_gpu_harness import dft_receiver_params, qfunc
+    from dl_ofdm_amd import ofdm, receiver
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    from dl_ofdm_amd.engine import RxEngine
+    F = flags(nbits=nbits, channel="AWGN")
+    o = ofdm.ofdm_tx(F)
+    dims = receiver.rx_dims(F, o)
+    frames = 6000
+    eng = RxEngine(dims, frames, train=False, params=dft_receiver_params(dims, o, nbits), want_prob=False)
+    gen = DeviceDataGen(F, o, seed=2024 + nbits)
+    gen.make_batch(frames, snr_db, out_x=eng.x, out_bits=eng.bits)             # straight into the engine's buffers
+    eng.eval_step()
+    m = eng.metrics()
+    sigma2 = 10.0 ** (-snr_db / 10.0)
+    per_dim = (64.0 / 24.0 if nbits == 1 else 64.0 / 48.0) / sigma2
+    theory = qfunc(math.sqrt(per_dim))
+    n_bits = frames * o.frame_size * nbits
+    tol = 4.0 * math.sqrt(theory * (1 - theory) / n_bits) + 0.02 * theory
+    assert abs(m["berlin"] - theory) <= tol, (m["berlin"], theory)
+
+
+def test_unsupported_channels_raise():
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    with pytest.raises(NotImplementedError):
+        DeviceDataGen(flags(channel="mixRayleigh"))
+    with pytest.raises(NotImplementedError):
+        DeviceDataGen(flags(channel="EPA"), mobile=True)
