@@ -60,6 +60,7 @@ class Flags:
     eval_frames: int = 1024         # per-epoch evaluation batch (:249)
     snr_lo: int = -10
     snr_hi: int = 30                # inclusive (:72)
+    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py) instead of NumPy
 
 
 def parse_flags(argv=None) -> Flags:
@@ -129,6 +130,21 @@ def load_checkpoint(path: str, eng, with_optimizer: bool = True):
                                            float(z["beta2_power"]), 0.0]))
 
 
+# ---- device-side data ----------------------------------------------------------------
+def _device_gen(FLAGS: Flags, ofdmobj, device):
+    from .datagen import DeviceDataGen
+    return DeviceDataGen(FLAGS, ofdmobj, device=device, seed=FLAGS.seed)
+
+
+def _gen_into(gen, eng, FLAGS: Flags, ofdmobj, n_frames: int, snr_db):
+    """make_batch on the GPU, written into the engine's resident input buffers (cropped when cp=False)."""
+    if FLAGS.cp:
+        return gen.make_batch(n_frames, snr_db, out_x=eng.x, out_bits=eng.bits)[2]
+    x, _, npow = gen.make_batch(n_frames, snr_db, out_bits=eng.bits)
+    eng.x.copy_(x[:, :, ofdmobj.CP:ofdmobj.CP + ofdmobj.K, :])
+    return npow
+
+
 # ---- sweep (H4) ------------------------------------------------------------------------------------
 def test_model(FLAGS: Flags, params: Dict[str, np.ndarray], ofdmobj=None, rank: int = 0, world: int = 1,
                device="cuda", out_dir: str = ".", verbose: bool = True):
@@ -141,11 +157,17 @@ def test_model(FLAGS: Flags, params: Dict[str, np.ndarray], ofdmobj=None, rank: 
     eng = RxEngine(rx_dims(FLAGS, ofdmobj), FLAGS.test_frames, device=device, train=False, params=params,
                    want_prob=False)
     fading = radio.rayleigh_chan_lte(FLAGS, ofdmobj.Fs)
+    gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
 
     def evaluate(p):
-        np.random.seed(p.seed)
-        xs, ys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.test_frames, p.snr_db)
-        eng.eval_step(xs, ys)
+        if gen is not None:
+            gen.seed, gen.offset = p.seed, 0
+            _gen_into(gen, eng, FLAGS, ofdmobj, FLAGS.test_frames, p.snr_db)
+            eng.eval_step()
+        else:
+            np.random.seed(p.seed)
+            xs, ys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.test_frames, p.snr_db)
+            eng.eval_step(xs, ys)
         m = eng.metrics()
         if verbose:
             print("SNR: %.2f, BER: %.8f, Loss: %f" % (p.snr_db, m["berlin"], m["ce_mean"]))
@@ -186,17 +208,33 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
     ev = RxEngine(dims, FLAGS.eval_frames, device=device, train=False, want_prob=False)
     loss_min, epoch_min, best_path = 100.0, 0, ""
     history = []
+    gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
+    import torch
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))           # reference: int(time.time()) + epoch
         train_snr = FLAGS.SNR + np.repeat(snr_seq, frame_cnt // 8, axis=0)
         n_use = train_snr.shape[0]
-        xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
         losses, pwrs, berl = [], [], 0.5
-        for i in range(n_use // batch_size):
-            sl = slice(i * batch_size, (i + 1) * batch_size)
-            eng.train_step(xs[sl], ys[sl])
-            m = eng.metrics()
-            losses.append(m["ce_mean"]); pwrs.append(m["tx_power"]); berl = m["berlin"]
+        if gen is not None:
+            # every step draws its own batch on the GPU into the engine's buffers; the per-step scalars the
+            # reference fetches are accumulated on the device and read once per epoch (no per-step sync)
+            mview = eng.metrics_buf.view(torch.float32)              # dccn_metrics: [12] ce_mean, [13] berlin
+            acc = torch.zeros(3, dtype=torch.float32, device=eng.device)
+            steps = n_use // batch_size
+            for i in range(steps):
+                noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR)
+                eng.train_step(graph=True)
+                acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power); acc[2:3].add_(noise_t)
+            a = acc.cpu().numpy() / max(steps, 1)
+            losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
+            berl = eng.metrics()["berlin"]
+        else:
+            xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
+            for i in range(n_use // batch_size):
+                sl = slice(i * batch_size, (i + 1) * batch_size)
+                eng.train_step(xs[sl], ys[sl])
+                m = eng.metrics()
+                losses.append(m["ce_mean"]); pwrs.append(m["tx_power"]); berl = m["berlin"]
         train_loss_epoch = float(np.mean(losses))
         new_bs = max(batch_size, ideal_batch_size(berl, FLAGS.nbits))
         new_bs = min(new_bs, n_use)
@@ -204,9 +242,13 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             eng = engine_for(new_bs, eng)
             batch_size = new_bs
         # per-epoch evaluation on fresh frames (:249-262)
-        txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
         ev.params.copy_(eng.params)
-        ev.eval_step(txs, tys)
+        if gen is not None:
+            _gen_into(gen, ev, FLAGS, ofdmobj, FLAGS.eval_frames, FLAGS.SNR)
+            ev.eval_step()
+        else:
+            txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
+            ev.eval_step(txs, tys)
         em = ev.metrics()
         history.append(dict(epoch=epoch, train_loss=train_loss_epoch, test_loss=em["ce_mean"], test_ber=em["berlin"],
                             batch_size=batch_size))

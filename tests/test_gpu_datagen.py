@@ -153,3 +153,17 @@ def test_unsupported_channels_raise():
         DeviceDataGen(flags(channel="mixRayleigh"))
     with pytest.raises(NotImplementedError):
         DeviceDataGen(flags(channel="EPA"), mobile=True)
+
+
+def test_harness_trains_on_device_generated_data(tmp_path):
+    """receiver.train(device_data=True): data never touches the host; the receiver still learns AWGN QPSK"""
+    from dl_ofdm_amd import receiver as R
+    F = R.Flags(nbits=2, nfilter=64, channel="AWGN", SNR=10.0, msg_length=7 * 8192, batch_size=512, max_epoch_num=8,
+                early_stop=100, token="D", save_dir=str(tmp_path) + "/", seed=5, device_data=True,
+                test_frames=2000, snr_lo=0, snr_hi=10)
+    res = R.train(F, verbose=False, run_test=True)
+    h = res["history"]
+    assert h[-1]["train_loss"] < h[0]["train_loss"] - 0.05, h
+    assert h[-1]["test_ber"] < 0.2, h
+    snrs, ber, loss, csv = res["sweep"]
+    assert ber[-1] < ber[0] and len(snrs) == 11

@@ -1,0 +1,59 @@
+"""End-to-end training throughput of the basic-receiver harness: data generation + fused step, host-generated
+(NumPy substrate, the reference's way) vs device-generated (dl_ofdm_amd.datagen).
+
+    python tools/e2ebench.py [--frames 1170] [--steps 200]
+
+Prints one JSON line per mode: OFDM symbols/s including the generation of every batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dl_ofdm_amd import ofdm, radio, receiver as R      # noqa: E402
+from dl_ofdm_amd.datagen import DeviceDataGen           # noqa: E402
+from dl_ofdm_amd.engine import RxEngine                 # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1170)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--host-steps", type=int, default=5)
+    ap.add_argument("--channel", default="EPA")
+    a = ap.parse_args()
+    F = R.Flags(nbits=2, nfilter=64, channel=a.channel, SNR=10.0)
+    o = ofdm.ofdm_tx(F)
+    eng = RxEngine(R.rx_dims(F, o), a.frames, train=True, want_prob=False)
+    gen = DeviceDataGen(F, o, seed=1)
+    for _ in range(20):
+        gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
+        eng.train_step(graph=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
+        eng.train_step(graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps(dict(mode="device-generated", channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
+                          symbols_per_s=round(a.frames * 7 / dt), final_ce=round(eng.metrics()["ce_mean"], 4))))
+    fading = radio.rayleigh_chan_lte(F, o.Fs)
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    for _ in range(a.host_steps):
+        xs, ys, _ = R.make_batch(F, o, fading, a.frames, F.SNR)
+        eng.train_step(xs, ys, graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.host_steps
+    print(json.dumps(dict(mode="host-generated (NumPy substrate)", channel=a.channel, frames=a.frames,
+                          ms_per_step=round(dt * 1e3, 3), symbols_per_s=round(a.frames * 7 / dt))))
+
+
+if __name__ == "__main__":
+    main()
