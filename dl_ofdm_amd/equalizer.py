@@ -226,6 +226,14 @@ class EqualizerTrainer:
             rms = self.chan_rms(torch.view_as_complex(pl.chest), chan_gt)
         return self._metrics(pl.metrics_buf, pl.tx_power, rms)
 
+    def resident(self, batch: int) -> _FusedPlan:
+        """the fused plan of this batch size: fill ``.x`` / ``.bits`` in place (e.g. from
+        :class:`~dl_ofdm_amd.datagen.DeviceDataGen`), then ``.run(train)``; ``.metrics_buf`` / ``.tx_power`` /
+        ``.chest`` / ``.out_eq`` / ``.snr_db`` hold the step's outputs on the device."""
+        if not self.fused_ok:
+            raise _lib.DccnError("the planned step covers FLAGS.cp=True only")
+        return self._plan(batch)
+
     def __del__(self):
         try:
             for pl in self._plans.values():

@@ -72,6 +72,7 @@ class Flags:
     snr_lo: int = -10
     snr_hi: int = 30
     snr_step: int = 5               # :81
+    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py); static channels
 
 
 def parse_flags(argv=None) -> Flags:
@@ -127,14 +128,27 @@ def test_model_cross(FLAGS, trainer, ofdmobj, rank: int = 0, world: int = 1, out
     pts = sweep.make_points([FLAGS.nbits], list(channels), snrs, base_seed=FLAGS.seed)
     fadings = {}
 
+    on_device = bool(getattr(FLAGS, "device_data", False)) and not FLAGS.mobile and trainer.fused_ok
+
     def evaluate(p):
         if p.channel not in fadings:
             fl = copy.deepcopy(FLAGS)
             fl.channel = p.channel
-            fadings[p.channel] = RayleighChanParallel(fl, ofdmobj.Fs, mobile=FLAGS.mobile)
-        np.random.seed(p.seed)
-        xs, ys, _, _ = make_batch(FLAGS, ofdmobj, fadings[p.channel], FLAGS.test_frames, p.snr_db)
-        m = trainer.eval_step(xs, ys)
+            if on_device:
+                from .datagen import DeviceDataGen
+                fadings[p.channel] = DeviceDataGen(fl, ofdmobj, device=trainer.device, seed=p.seed)
+            else:
+                fadings[p.channel] = RayleighChanParallel(fl, ofdmobj.Fs, mobile=FLAGS.mobile)
+        if on_device:
+            gen, pl = fadings[p.channel], trainer.resident(FLAGS.test_frames)
+            gen.seed, gen.offset = p.seed, 0
+            gen.make_batch(FLAGS.test_frames, p.snr_db, out_x=pl.x, out_bits=pl.bits)
+            pl.run(False)
+            m = trainer._metrics(pl.metrics_buf, pl.tx_power)
+        else:
+            np.random.seed(p.seed)
+            xs, ys, _, _ = make_batch(FLAGS, ofdmobj, fadings[p.channel], FLAGS.test_frames, p.snr_db)
+            m = trainer.eval_step(xs, ys)
         if verbose:
             print("Test in %s: SNR: %.2f, BER: %.8f, Loss: %f" % (p.channel, p.snr_db, m["berlin"], m["ce_mean"]))
         c = m["conf"]
@@ -179,6 +193,9 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
     fading1 = RayleighChanParallel(FLAGS, ofdmobj.Fs, mobile=True, mix=True) if FLAGS.mobile else None
     phase2 = True                                                      # :393
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
+    on_device = bool(FLAGS.device_data) and not FLAGS.mobile and trainer.fused_ok
+    if on_device:
+        return _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, run_test)
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))              # reference: int(time.time()) + epoch
         train_snr = np.random.choice(TRAIN_SNR_GRID, [frame_cnt, 1], p=TRAIN_SNR_PROB)     # :407
@@ -207,6 +224,54 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
             epoch_min, loss_min = epoch, train_loss_epoch
             best_path = save_checkpoint(os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), trainer, FLAGS)
         if epoch - FLAGS.early_stop > epoch_min:                         # :460-466
+            break
+    if verbose:
+        print("Training Done!, Best model saved to\n%s" % best_path)
+    result = dict(history=history, best_path=best_path, trainer=trainer)
+    if run_test and best_path:
+        load_checkpoint(best_path, trainer, with_optimizer=False)
+        result["sweep"] = test_model_cross(FLAGS, trainer, ofdmobj, verbose=verbose)
+    return result
+
+
+def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, run_test):
+    """the epoch loop of :func:`train` with every batch drawn on the GPU (static channels) straight into the fused
+    plan's buffers; per-step scalars are accumulated on the device and fetched once per epoch."""
+    import torch
+    from .datagen import DeviceDataGen
+    gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed)
+    pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
+    mview = pl.metrics_buf.view(torch.float32)                      # dccn_metrics: [12] ce_mean, [13] berlin
+    loss_min, epoch_min, best_path, history = 100.0, 0, "", []
+    steps = frame_cnt // batch_size
+    for epoch in range(FLAGS.max_epoch_num):
+        np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))
+        acc = torch.zeros(5, dtype=torch.float32, device=trainer.device)
+        for i in range(steps):
+            snr = np.random.choice(TRAIN_SNR_GRID, [batch_size], p=TRAIN_SNR_PROB)         # :407
+            tx, _ = gen.transmit(batch_size, out_bits=pl.bits)
+            _, npow, H = gen.channel(tx, snr, out_x=pl.x, want_H=True)
+            gen.offset += 1
+            pl.run(True)
+            rms = trainer.chan_rms(torch.view_as_complex(pl.chest), H[:, None, :].expand(-1, FLAGS.nsymbol, -1))
+            acc[0:2].add_(mview[12:14]); acc[2:3].add_(pl.tx_power); acc[3:4].add_(npow); acc[4:5].add_(rms)
+        a = acc.cpu().numpy() / max(steps, 1)
+        train_loss_epoch = float(a[0])
+        snr = np.random.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)       # :438
+        tx, _ = gen.transmit(FLAGS.eval_frames, out_bits=ev.bits)
+        gen.channel(tx, snr, out_x=ev.x)
+        gen.offset += 1
+        ev.run(False)
+        em = trainer._metrics(ev.metrics_buf, ev.tx_power)
+        history.append(dict(epoch=epoch, train_loss=train_loss_epoch, train_ber=float(a[1]), chan_rms=float(a[4]),
+                            test_loss=em["ce_mean"], test_ber=em["berlin"]))
+        if verbose:
+            print("Epoch: %d  Train Loss: %f  Tx Power: %f  Noise Power: %f  SNR MSE: %f | Test Loss: %f  Test BER: %.8f"
+                  % (epoch, train_loss_epoch, a[2], a[3], a[4], em["ce_mean"], em["berlin"]))
+        if train_loss_epoch < loss_min:
+            epoch_min, loss_min = epoch, train_loss_epoch
+            best_path = save_checkpoint(os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), trainer, FLAGS)
+        if epoch - FLAGS.early_stop > epoch_min:
             break
     if verbose:
         print("Training Done!, Best model saved to\n%s" % best_path)

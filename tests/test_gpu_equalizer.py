@@ -375,3 +375,22 @@ def test_fused_step_equals_composed_step():
     close(pl.out_eq, out_b[5].detach().cpu().numpy(), 1e-5, "out_eq")
     close(pl.snr_db, out_b[3].detach().cpu().numpy(), 1e-5, "snr_db")
     close(pl.chest, torch.view_as_real(out_b[4]).cpu().numpy(), 1e-5, "chest")
+
+
+def test_equalizer_harness_on_device_generated_data():
+    """receiver_mp.train(device_data=True): bits, frames, fading, noise and the true channel response all come
+    from the GPU generator; same learning criterion as the host-data test above."""
+    from dl_ofdm_amd import receiver as R, receiver_mp as H
+    base = R.Flags(nbits=2, nfilter=64, channel="AWGN", SNR=10.0, msg_length=7 * 4096, batch_size=512,
+                   max_epoch_num=6, early_stop=100, token="B2", save_dir="/tmp/_eq_test2/", seed=5, device_data=True)
+    res = R.train(base, verbose=False, run_test=False)
+    hf = H.Flags(nbits=2, nfilter=64, channel="Flat", msg_length=7 * 2048, batch_size=512, max_epoch_num=5,
+                 early_stop=100, token="B2", save_dir="/tmp/_eq_test2/", seed=6, eval_frames=2048, device_data=True,
+                 test_frames=512, snr_lo=0, snr_hi=20, snr_step=10)
+    out = H.train(hf, verbose=False, run_test=True, rx_params=res["params"])
+    hist = out["history"]
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"] - 0.02, hist
+    assert np.isfinite(hist[-1]["chan_rms"]) and hist[-1]["chan_rms"] > 0
+    sw = out["sweep"]
+    assert set(sw) == set(H.TEST_CHANNELS) and all(len(v[1]) == 3 for v in sw.values())
+    assert sw["Flat"][1][-1] < sw["Flat"][1][0]                 # BER falls with SNR on the training channel
