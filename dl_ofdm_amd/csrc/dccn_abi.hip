@@ -917,4 +917,37 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
     return DCCN_OK;
 }
 
+// ---- CRC32C (host) --------------------------------------------------------------------------------------
+static uint32_t g_crc32c_table[8][256];
+static bool g_crc32c_ready = false;
+static void crc32c_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+        g_crc32c_table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t)
+            g_crc32c_table[t][i] = (g_crc32c_table[t - 1][i] >> 8) ^ g_crc32c_table[0][g_crc32c_table[t - 1][i] & 0xffu];
+    g_crc32c_ready = true;
+}
+uint32_t dccn_crc32c(uint32_t crc, const void* data, size_t n) {
+    if (!g_crc32c_ready) crc32c_init();
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = crc ^ 0xffffffffu;
+    while (n >= 8) {                                     // slicing-by-8
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = g_crc32c_table[7][lo & 0xffu] ^ g_crc32c_table[6][(lo >> 8) & 0xffu] ^ g_crc32c_table[5][(lo >> 16) & 0xffu] ^
+            g_crc32c_table[4][lo >> 24] ^ g_crc32c_table[3][hi & 0xffu] ^ g_crc32c_table[2][(hi >> 8) & 0xffu] ^
+            g_crc32c_table[1][(hi >> 16) & 0xffu] ^ g_crc32c_table[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = g_crc32c_table[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+
 }  // extern "C"

@@ -61,6 +61,7 @@ class Flags:
     snr_lo: int = -10
     snr_hi: int = 30                # inclusive (:72)
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py) instead of NumPy
+    tf_checkpoint: bool = False     # also write <save_dir>/<token>.index/.data-00000-of-00001 (tf.train.Saver format)
 
 
 def parse_flags(argv=None) -> Flags:
@@ -113,14 +114,28 @@ def save_checkpoint(path: str, eng, FLAGS: Flags):
     out["global_step"] = np.float32(a["global_step"])
     out["beta1_power"] = np.float32(a["beta1_power"])
     out["beta2_power"] = np.float32(a["beta2_power"])
+    if getattr(FLAGS, "tf_checkpoint", False):                  # the reference's own format (tf.train.Saver, :191,271)
+        from . import tf_bundle
+        tf_bundle.write_checkpoint(path[:-4] if path.endswith(".npz") else path, tf_bundle.rx_to_tf(out, eng.dims.kin))
     out["__flags__"] = np.array(repr(asdict(FLAGS)))
     np.savez(path if path.endswith(".npz") else path + ".npz", **out)
     return path
 
 
+def read_checkpoint_file(path: str) -> Dict[str, np.ndarray]:
+    """<path>.npz, or -- when only the TensorFlow bundle <path>.index/.data-* exists (a receiver trained by
+    the reference) -- that, mapped to the engine's layouts."""
+    stem = path[:-4] if path.endswith(".npz") else path
+    if not os.path.exists(stem + ".npz") and os.path.exists(stem + ".index"):
+        from . import tf_bundle
+        return tf_bundle.rx_from_tf(tf_bundle.read_checkpoint(stem))
+    z = np.load(stem + ".npz", allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
 def load_checkpoint(path: str, eng, with_optimizer: bool = True):
     import torch
-    z = np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False)
+    z = read_checkpoint_file(path)
     eng.load_params({n: z[n] for n in PARAM_NAMES})
     if with_optimizer and eng.train and all((n + "/Adam") in z for n in PARAM_NAMES):
         for n in PARAM_NAMES:
@@ -264,7 +279,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
         print("Training Done!, Best model saved to\n%s" % best_path)
     result = dict(history=history, best_path=best_path, params=eng.get_params())
     if run_test and best_path:
-        z = np.load(best_path + ".npz" if not best_path.endswith(".npz") else best_path)
+        z = read_checkpoint_file(best_path)
         result["sweep"] = test_model(FLAGS, {n: z[n] for n in PARAM_NAMES}, ofdmobj, device=device, verbose=verbose)
     return result
 
@@ -272,7 +287,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
 def main(argv=None):
     FLAGS = parse_flags(argv)
     if FLAGS.test:
-        z = np.load(os.path.join(FLAGS.save_dir, FLAGS.token) + ".npz")
+        z = read_checkpoint_file(os.path.join(FLAGS.save_dir, FLAGS.token))
         test_model(FLAGS, {n: z[n] for n in PARAM_NAMES})
         return
     t0 = time.time()

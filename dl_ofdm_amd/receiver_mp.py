@@ -73,6 +73,7 @@ class Flags:
     snr_hi: int = 30
     snr_step: int = 5               # :81
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py); static channels
+    tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 
 def parse_flags(argv=None) -> Flags:
@@ -103,11 +104,12 @@ def save_model_name(FLAGS) -> str:
 
 def load_rx_params(FLAGS) -> Dict[str, np.ndarray]:
     """the trained basic receiver written by dl_ofdm_amd.receiver (``<save_dir>/<token>.npz``)."""
-    path = os.path.join(FLAGS.save_dir, FLAGS.token) + ".npz"
-    if not os.path.exists(path):
-        raise FileNotFoundError("basic-receiver checkpoint %s not found: train it first with "
-                                "`python -m dl_ofdm_amd.receiver --token=%s ...`" % (path, FLAGS.token))
-    z = np.load(path, allow_pickle=False)
+    from .receiver import read_checkpoint_file
+    stem = os.path.join(FLAGS.save_dir, FLAGS.token)
+    if not os.path.exists(stem + ".npz") and not os.path.exists(stem + ".index"):
+        raise FileNotFoundError("basic-receiver checkpoint %s(.npz|.index) not found: train it first with "
+                                "`python -m dl_ofdm_amd.receiver --token=%s ...`" % (stem, FLAGS.token))
+    z = read_checkpoint_file(stem)
     return {n: z[n] for n in PARAM_NAMES}
 
 
@@ -171,13 +173,21 @@ def test_model_cross(FLAGS, trainer, ofdmobj, rank: int = 0, world: int = 1, out
 def save_checkpoint(path: str, trainer, FLAGS):
     os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
     out = trainer.state_dict_tf()
+    if getattr(FLAGS, "tf_checkpoint", False):
+        from . import tf_bundle
+        tf_bundle.write_checkpoint(path[:-4] if path.endswith(".npz") else path, tf_bundle.eq_to_tf(out))
     out["__flags__"] = np.array(repr(asdict(FLAGS)))
     np.savez(path if path.endswith(".npz") else path + ".npz", **out)
     return path
 
 
 def load_checkpoint(path: str, trainer, with_optimizer: bool = True):
-    z = np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False)
+    stem = path[:-4] if path.endswith(".npz") else path
+    if not os.path.exists(stem + ".npz") and os.path.exists(stem + ".index"):
+        from . import tf_bundle
+        z = tf_bundle.eq_from_tf(tf_bundle.read_checkpoint(stem))
+    else:
+        z = np.load(stem + ".npz", allow_pickle=False)
     trainer.load_state_dict_tf(z, with_optimizer)
 
 

@@ -342,6 +342,11 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
                       float* noise_power, int frames, int T, unsigned long long seed, unsigned offset,
                       void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 
+/* ==== host utility: CRC32C (Castagnoli), the checksum of TensorFlow's tensor-bundle checkpoints =========
+ * (tf.train.Saver files the reference writes at dev/py/ofdmreceiver_np.py:271).
+ * Returns the CRC of (previous data ++ data) given the CRC of the previous data (0 to start).  Host code. */
+uint32_t dccn_crc32c(uint32_t crc, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

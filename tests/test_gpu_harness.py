@@ -122,3 +122,30 @@ def test_checkpoint_round_trip(tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(a.params, b.params) and torch.equal(a.adam_v, b.adam_v)
     assert a.adam() == b.adam()
+
+
+def test_tf_bundle_checkpoint_roundtrip_through_the_harness(tmp_path):
+    """--tf_checkpoint writes the tf.train.Saver files next to the .npz; a directory holding ONLY the TF bundle
+    (as a reference-trained model would) loads into the engine with identical parameters and Adam state."""
+    from dl_ofdm_amd import ofdm, receiver, tf_bundle
+    from dl_ofdm_amd.engine import PARAM_NAMES, RxEngine
+    F = flags(nbits=2, tf_checkpoint=True, token="TFCK", save_dir=str(tmp_path) + "/")
+    o = ofdm.ofdm_tx(F)
+    dims = receiver.rx_dims(F, o)
+    eng = RxEngine(dims, 16, train=True, seed=4)
+    rng = np.random.RandomState(2)
+    for _ in range(3):
+        eng.train_step(rng.standard_normal((16, 7, 80, 2)).astype(np.float32), rng.randint(0, 2, (16, o.frame_size, 2)))
+    stem = os.path.join(F.save_dir, F.token)
+    receiver.save_checkpoint(stem, eng, F)
+    ent = tf_bundle.read_index(stem + ".index")
+    assert len(ent) == 3 * 8 + 3 and ent["fft_like/conv3d/kernel"]["shape"] == [1, 80, 1, 80, 128]
+    assert ent["demodulation/conv2d/kernel/Adam_1"]["shape"] == [1, 1, 2, 4]
+    os.remove(stem + ".npz")                                            # only the TensorFlow files remain
+    eng2 = RxEngine(dims, 16, train=True, seed=99)
+    receiver.load_checkpoint(stem, eng2)
+    import torch
+    assert torch.equal(eng.params, eng2.params) and torch.equal(eng.adam_m, eng2.adam_m)
+    assert torch.equal(eng.adam_v, eng2.adam_v) and eng2.adam()["global_step"] == 3.0
+    z = receiver.read_checkpoint_file(stem)
+    assert all(np.array_equal(z[n], eng.get_params()[n]) for n in PARAM_NAMES)
