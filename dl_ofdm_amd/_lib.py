@@ -130,6 +130,9 @@ SIGNATURES = {
     "dccn_ofdm_tx_frames": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_ulonglong,
                                  C.c_uint, _vp]),
     "dccn_channel_awgn_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_channel_doppler_awgn_workspace_size": (_sz, [_i, _i, _i, _i]),
+    "dccn_channel_doppler_awgn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i,
+                                       C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
     "dccn_crc32c": (C.c_uint32, [C.c_uint32, _vp, _sz]),
     "dccn_channel_awgn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, C.c_ulonglong,
                                C.c_uint, _vp, _sz, _vp]),

@@ -11,7 +11,7 @@
 namespace dccn {
 
 constexpr unsigned kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u, kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
-constexpr int kStreamBits = 0, kStreamTaps = 1, kStreamNoise = 2;
+constexpr int kStreamBits = 0, kStreamTaps = 1, kStreamNoise = 2, kStreamDoppler = 3;
 
 struct Philox4 {
     unsigned v[4];
@@ -201,6 +201,108 @@ __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y,
     __syncthreads();
     if (threadIdx.x == 0 && noise_partial)
         noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// radio.py:376-407 Jakes sum-of-sinusoids Doppler: per OFDM symbol s (t = s * n_sc / Fs) and tap k
+//   mu_re = sqrt(1/48) sum_n cos(2 pi t Fd cos(a_n + a0_k) + th_re[n,k]),  a_n = (n - 0.5) pi / (4*48), a0_k = k pi/(4*48)
+//   mu_im likewise with cos(a_n - a0_k) and th_im;  tap = (mu_re + i mu_im) coeff_k;  g[s] = taps[s] . alpha;  H[s] = fft(g[s])
+// theta_in [frames, 2, 48, n_taps] (uniform phases in [0, 2 pi)) == nullptr: draw them.  One block per frame.
+constexpr int kSinusoids = 48;
+__global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restrict__ theta_in,
+                                                          const float* __restrict__ coeff,
+                                                          const float* __restrict__ alpha, float2* __restrict__ g,
+                                                          float2* __restrict__ H, int n_taps, int L, int nfft, int S,
+                                                          float Fd, float t_sym, unsigned offset,
+                                                          unsigned long long seed) {
+    __shared__ float2 tap[16 * 16];          // [S][n_taps], S <= 16
+    __shared__ float2 gs[16 * 64];           // [S][L]
+    const int fr = blockIdx.x;
+    const float step = 3.14159265358979323846f / (4.0f * kSinusoids);
+    for (int e = threadIdx.x; e < S * n_taps; e += 64) {
+        const int sym = e / n_taps, k = e % n_taps;
+        const float t = (float)sym * t_sym, a0 = (float)(k + 1) * step;
+        float sr = 0.f, si = 0.f;
+        for (int n = 0; n < kSinusoids; ++n) {
+            const float an = ((float)(n + 1) - 0.5f) * step;
+            float thr, thi;
+            if (theta_in) {
+                thr = theta_in[(((size_t)fr * 2 + 0) * kSinusoids + n) * n_taps + k];
+                thi = theta_in[(((size_t)fr * 2 + 1) * kSinusoids + n) * n_taps + k];
+            } else {
+                const unsigned long long base = ((unsigned long long)fr * 2 * kSinusoids + n) * n_taps + k;
+                thr = 6.2831853071795864769f *
+                      uniform01(philox4x32_10(base, kStreamDoppler, offset, seed).v[0]);
+                thi = 6.2831853071795864769f *
+                      uniform01(philox4x32_10(base + (unsigned long long)kSinusoids * n_taps, kStreamDoppler, offset, seed).v[0]);
+            }
+            sr += cosf(6.2831853071795864769f * t * (Fd * cosf(an + a0)) + thr);
+            si += cosf(6.2831853071795864769f * t * (Fd * cosf(an - a0)) + thi);
+        }
+        const float c = coeff[k] * 0.14433756729740644113f;          // sqrt(1/48)
+        tap[sym * n_taps + k] = make_float2(sr * c, si * c);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * L; e += 64) {
+        const int sym = e / L, l = e % L;
+        float2 a = make_float2(0.f, 0.f);
+        for (int k = 0; k < n_taps; ++k) {
+            const float w = alpha[k * L + l];
+            a.x += tap[sym * n_taps + k].x * w;
+            a.y += tap[sym * n_taps + k].y * w;
+        }
+        gs[e] = a;
+        g[((size_t)fr * S + sym) * L + l] = a;
+    }
+    __syncthreads();
+    if (H) {
+        for (int e = threadIdx.x; e < S * nfft; e += 64) {
+            const int sym = e / nfft, f = e % nfft;
+            float2 a = make_float2(0.f, 0.f);
+            for (int l = 0; l < L; ++l) {
+                float sn, cs;
+                sincosf(-6.2831853071795864769f * (float)((f * l) % nfft) / (float)nfft, &sn, &cs);
+                const float2 v = gs[sym * L + l];
+                a.x += v.x * cs - v.y * sn;
+                a.y += v.x * sn + v.y * cs;
+            }
+            H[((size_t)fr * S + sym) * nfft + f] = a;
+        }
+    }
+}
+
+// radio.py:385-407 per-symbol impulse response with n_taps samples of history: symbol s filters the segment
+// x[s*n_sc - n_taps .. (s+1)*n_sc) with np.convolve(., g_s, 'same') and keeps its last n_sc outputs, i.e.
+// y[s*n_sc + t] = sum_l g_s[l] x[s*n_sc + t + off - l] over t + off - l in [-n_taps, n_sc) (nothing beyond the
+// symbol's own end, nothing before the frame).  grid = (ceil(T/256), frames); + partial sums of |y|^2.
+__global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
+                                                          float2* __restrict__ y, double* __restrict__ partial, int T,
+                                                          int L, int n_sc, int n_taps) {
+    __shared__ double sh[4];
+    const int fr = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int off = (L - 1) / 2;
+    const int S = T / n_sc;
+    double pw = 0.0;
+    if (t < T) {
+        const int sym = t / n_sc, tl = t - sym * n_sc;
+        const float2* xf = x + (size_t)fr * T;
+        const float2* gf = g + ((size_t)fr * S + sym) * L;
+        float2 a = make_float2(0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const int r = tl + off - l;                     // position relative to the symbol start
+            const int u = sym * n_sc + r;
+            if (r < -n_taps || r >= n_sc || u < 0) continue;
+            const float2 v = xf[u], c = gf[l];
+            a.x += c.x * v.x - c.y * v.y;
+            a.y += c.x * v.y + c.y * v.x;
+        }
+        y[(size_t)fr * T + t] = a;
+        pw = (double)a.x * a.x + (double)a.y * a.y;
+    }
+    pw = wave_sum(pw);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 }  // namespace dccn

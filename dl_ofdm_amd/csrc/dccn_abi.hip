@@ -917,6 +917,50 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
     return DCCN_OK;
 }
 
+size_t dccn_channel_doppler_awgn_workspace_size(int frames, int T, int L, int S) {
+    if (frames <= 0 || T <= 0 || L <= 0 || S <= 0) return 0;
+    return dccn_channel_awgn_workspace_size(frames, T, L * S);
+}
+int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const float* coeff, const float* alpha,
+                              int n_taps, int L, float Fd, float t_sym, int S, int n_sc, const float* snr_db,
+                              const float* noise_in, float* out, float* H, int nfft, float* noise_power, int frames,
+                              unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
+                              dccn_stream_t stream) {
+    if (!tx || !coeff || !alpha || !snr_db || !out || frames <= 0 || frames > 65535 || S <= 0 || S > 16 || n_sc <= 0 ||
+        L <= 0 || L > 64 || n_taps <= 0 || n_taps > 16 || (H && nfft <= 0))
+        return DCCN_ERR_INVALID_ARG;
+    const int T = S * n_sc;
+    if (!workspace || workspace_bytes < dccn_channel_doppler_awgn_workspace_size(frames, T, L, S))
+        return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    float* g = c.take<float>((size_t)frames * S * L * 2);
+    float* y = c.take<float>((size_t)frames * T * 2);
+    const int bx = chan_blocks_x(T);
+    double* partial = c.take<double>((size_t)frames * bx);
+    double* npartial = c.take<double>((size_t)frames * bx);
+    float* mean_power = c.take<float>(4);
+    hipLaunchKernelGGL(doppler_taps_kernel, dim3(frames), dim3(64), 0, s, theta_in, coeff, alpha, (float2*)g, (float2*)H,
+                       n_taps, L, nfft, S, Fd, t_sym, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fir_doppler_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                       (float2*)y, partial, T, L, n_sc, n_taps);
+    DCCN_LAUNCH_CHECK();
+    const double total = (double)frames * (double)T;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
+                       mean_power);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
+                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    if (noise_power) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
+                           noise_power);
+        DCCN_LAUNCH_CHECK();
+    }
+    return DCCN_OK;
+}
+
 // ---- CRC32C (host) --------------------------------------------------------------------------------------
 static uint32_t g_crc32c_table[8][256];
 static bool g_crc32c_ready = false;

@@ -10,9 +10,9 @@ generator"): same constellation tables, grid layout, ifft + cyclic prefix (as on
 Mersenne Twister, so agreement with the host path is exact for the deterministic stages (given the same
 bits / tap draws / noise draws -- tests/test_gpu_datagen.py) and statistical for the draws themselves.
 
-Scope: the static single-profile channels of the reference's sweep driver ('AWGN', 'Flat', 'EPA', 'EVA',
-'ETU', 'Custom', mobile=False).  Doppler (mobile=True) and the frame-interleaved 'mix*' channels stay on the
-host path.
+Scope: the single-profile channels of the reference's drivers ('AWGN', 'Flat', 'EPA', 'EVA', 'ETU', 'Custom'),
+static or mobile (Jakes Doppler, radio.py:376-407: per-symbol taps, per-symbol FIR with n_taps samples of history).
+The frame-interleaved 'mix*' channels stay on the host path.
 """
 from __future__ import annotations
 
@@ -34,9 +34,9 @@ class DeviceDataGen:
             raise _lib.DccnError("DeviceDataGen needs a CUDA (ROCm) device; use ofdm.py/radio.py on the host")
         self.FLAGS, self.o = FLAGS, ofdmobj or ofdm.ofdm_tx(FLAGS)
         chan = FLAGS.channel.lower()
-        if mobile or chan in ("mixrayleigh", "mixall"):
-            raise NotImplementedError("device generator covers static single-profile channels; "
-                                      "use radio.rayleigh_chan_lte for mobile / mix channels")
+        if chan in ("mixrayleigh", "mixall"):
+            raise NotImplementedError("device generator covers single-profile channels; "
+                                      "use radio.rayleigh_chan_lte for the frame-interleaved mix channels")
         o = self.o
         self.S, self.K, self.CP, self.D, self.nbits = o.nSymbol, o.K, o.CP, o.frame_size, int(FLAGS.nbits)
         self.n_sc, self.T = o.K + o.CP, o.nSymbol * (o.K + o.CP)
@@ -51,7 +51,10 @@ class DeviceDataGen:
         self.pilot = complex(o.pilotValue)
         self.idft = torch.from_numpy(self.idft_cp_matrix(self.K, self.CP)).to(dev)
         self.identity = chan == "awgn"
-        prof = radio._Profile(chan, False, radio._alpha_matrices())
+        prof = radio._Profile(chan, bool(mobile), radio._alpha_matrices())
+        self.Fd = float(prof.Fd)
+        self.doppler = (not self.identity) and self.Fd > 0.1          # radio.py: `doppler = prof.Fd > 0.1`
+        self.t_sym = float(self.n_sc) / float(o.Fs)
         self.n_taps, self.L = int(prof.n_taps), int(prof.alpha.shape[1])
         self.coeff = torch.from_numpy(np.asarray(prof.ch_coeff, dtype=np.float32)).to(dev)
         self.alpha = torch.from_numpy(np.ascontiguousarray(prof.alpha, dtype=np.float32)).to(dev)
@@ -77,7 +80,7 @@ class DeviceDataGen:
     def _workspace(self, n: int):
         if n not in self._ws:
             f32 = dict(dtype=torch.float32, device=self.device)
-            nws = self.lib.dccn_channel_awgn_workspace_size(n, self.T, self.L)
+            nws = self.lib.dccn_channel_doppler_awgn_workspace_size(n, self.T, self.L, self.S)
             self._ws[n] = dict(grid=torch.empty(n, self.S, self.K, 2, **f32), tx=torch.empty(n, self.S, self.n_sc, 2, **f32),
                                ws=torch.empty(nws, dtype=torch.uint8, device=self.device), nws=nws,
                                snr=torch.empty(n, **f32), npow=torch.zeros(1, **f32))
@@ -106,7 +109,9 @@ class DeviceDataGen:
 
     def channel(self, tx: torch.Tensor, snr_db, out_x: Optional[torch.Tensor] = None, taps: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None, want_H: bool = False, offset: Optional[int] = None):
-        """fading + AWGN on [n,S,n_sc,2] frames; ``taps`` / ``noise``: external standard normals instead of draws."""
+        """fading + AWGN on [n,S,n_sc,2] frames; ``taps`` / ``noise``: external draws instead of the Philox streams
+        (static: standard normals [n,n_taps,2]; mobile: uniform phases [n,2,48,n_taps]; noise: normals [n,T,2]).
+        H: complex [n,K] (static) or [n,S,K] (mobile)."""
         n = tx.shape[0]
         w = self._workspace(n)
         off = self.offset if offset is None else int(offset)
@@ -118,11 +123,19 @@ class DeviceDataGen:
             w["snr"].copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)))
         if out_x is None:
             out_x = torch.empty(n, self.S, self.n_sc, 2, dtype=torch.float32, device=self.device)
-        H = torch.empty(n, self.K, 2, dtype=torch.float32, device=self.device) if want_H else None
+        hshape = (n, self.S, self.K, 2) if self.doppler else (n, self.K, 2)
+        H = torch.empty(*hshape, dtype=torch.float32, device=self.device) if want_H else None
         if taps is not None:
             taps = torch.as_tensor(taps, dtype=torch.float32).to(self.device).contiguous()
         if noise is not None:
             noise = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()
+        if self.doppler:
+            check(self.lib.dccn_channel_doppler_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
+                                                     self.n_taps, self.L, self.Fd, self.t_sym, self.S, self.n_sc,
+                                                     self._p(w["snr"]), self._p(noise), self._p(out_x), self._p(H),
+                                                     self.K, self._p(w["npow"]), n, self.seed, off, self._p(w["ws"]),
+                                                     w["nws"], self._stream()), "dccn_channel_doppler_awgn")
+            return out_x, w["npow"], (torch.view_as_complex(H) if want_H else None)
         check(self.lib.dccn_channel_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
                                          self.n_taps, self.L, 1 if self.identity else 0, self._p(w["snr"]),
                                          self._p(noise), self._p(out_x), self._p(H), self.K, self._p(w["npow"]), n,

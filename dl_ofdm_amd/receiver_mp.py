@@ -72,7 +72,7 @@ class Flags:
     snr_lo: int = -10
     snr_hi: int = 30
     snr_step: int = 5               # :81
-    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py); static channels
+    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py); single-profile channels
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 
@@ -130,7 +130,7 @@ def test_model_cross(FLAGS, trainer, ofdmobj, rank: int = 0, world: int = 1, out
     pts = sweep.make_points([FLAGS.nbits], list(channels), snrs, base_seed=FLAGS.seed)
     fadings = {}
 
-    on_device = bool(getattr(FLAGS, "device_data", False)) and not FLAGS.mobile and trainer.fused_ok
+    on_device = bool(getattr(FLAGS, "device_data", False)) and trainer.fused_ok
 
     def evaluate(p):
         if p.channel not in fadings:
@@ -138,7 +138,8 @@ def test_model_cross(FLAGS, trainer, ofdmobj, rank: int = 0, world: int = 1, out
             fl.channel = p.channel
             if on_device:
                 from .datagen import DeviceDataGen
-                fadings[p.channel] = DeviceDataGen(fl, ofdmobj, device=trainer.device, seed=p.seed)
+                fadings[p.channel] = DeviceDataGen(fl, ofdmobj, device=trainer.device, seed=p.seed,
+                                                   mobile=FLAGS.mobile)
             else:
                 fadings[p.channel] = RayleighChanParallel(fl, ofdmobj.Fs, mobile=FLAGS.mobile)
         if on_device:
@@ -203,7 +204,7 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
     fading1 = RayleighChanParallel(FLAGS, ofdmobj.Fs, mobile=True, mix=True) if FLAGS.mobile else None
     phase2 = True                                                      # :393
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
-    on_device = bool(FLAGS.device_data) and not FLAGS.mobile and trainer.fused_ok
+    on_device = bool(FLAGS.device_data) and trainer.fused_ok and not FLAGS.channel.lower().startswith("mix")
     if on_device:
         return _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, run_test)
     for epoch in range(FLAGS.max_epoch_num):
@@ -249,7 +250,7 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     plan's buffers; per-step scalars are accumulated on the device and fetched once per epoch."""
     import torch
     from .datagen import DeviceDataGen
-    gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed)
+    gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed, mobile=FLAGS.mobile)
     pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
     mview = pl.metrics_buf.view(torch.float32)                      # dccn_metrics: [12] ce_mean, [13] berlin
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
@@ -263,7 +264,8 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
             _, npow, H = gen.channel(tx, snr, out_x=pl.x, want_H=True)
             gen.offset += 1
             pl.run(True)
-            rms = trainer.chan_rms(torch.view_as_complex(pl.chest), H[:, None, :].expand(-1, FLAGS.nsymbol, -1))
+            chan_gt = H if H.dim() == 3 else H[:, None, :].expand(-1, FLAGS.nsymbol, -1)
+            rms = trainer.chan_rms(torch.view_as_complex(pl.chest), chan_gt)
             acc[0:2].add_(mview[12:14]); acc[2:3].add_(pl.tx_power); acc[3:4].add_(npow); acc[4:5].add_(rms)
         a = acc.cpu().numpy() / max(steps, 1)
         train_loss_epoch = float(a[0])

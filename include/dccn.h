@@ -342,6 +342,17 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
                       float* noise_power, int frames, int T, unsigned long long seed, unsigned offset,
                       void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 
+/* dev/py/radio.py:376-407 mobile (Doppler) variant: per OFDM symbol the taps follow Jakes' sum of 48
+ * sinusoids (maximum Doppler Fd [Hz], symbol period t_sym = n_sc / Fs [s]) and each symbol is filtered with its own
+ * impulse response over [n_taps samples of history | the symbol].  theta_in [frames,2,48,n_taps] uniform phases,
+ * nullable (null: draw, stream 3).  H [frames,S,nfft,2] nullable.  Other arguments as dccn_channel_awgn; T = S*n_sc. */
+size_t dccn_channel_doppler_awgn_workspace_size(int frames, int T, int L, int S);
+int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const float* coeff, const float* alpha,
+                              int n_taps, int L, float Fd, float t_sym, int S, int n_sc, const float* snr_db,
+                              const float* noise_in, float* out, float* H, int nfft, float* noise_power, int frames,
+                              unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
+                              dccn_stream_t stream);
+
 /* ==== host utility: CRC32C (Castagnoli), the checksum of TensorFlow's tensor-bundle checkpoints =========
  * (tf.train.Saver files the reference writes at dev/py/ofdmreceiver_np.py:271).
  * Returns the CRC of (previous data ++ data) given the CRC of the previous data (0 to start).  Host code. */

@@ -18,7 +18,7 @@ import numpy as np
 
 PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
 PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
-STREAM_BITS, STREAM_TAPS, STREAM_NOISE = 0, 1, 2
+STREAM_BITS, STREAM_TAPS, STREAM_NOISE, STREAM_DOPPLER = 0, 1, 2, 3
 
 # Random123 kat_vectors, philox4x32-10: (counter, key) -> output
 KAT = [
@@ -96,3 +96,10 @@ def noise_normals(seed: int, offset: int, n_pairs: int) -> np.ndarray:
     w = philox4x32_10(counters(idx, STREAM_NOISE, offset), key_of(seed))
     z0, z1 = box_muller(w[:, 0], w[:, 1])
     return np.stack([z0, z1], -1)
+
+
+def doppler_thetas(seed: int, offset: int, n_frames: int, n_taps: int, ss: int = 48) -> np.ndarray:
+    """uniform phases [n, 2, ss, n_taps] in (0, 2 pi) of the Jakes taps (host: two np.random.uniform draws per frame)"""
+    idx = np.arange(n_frames * 2 * ss * n_taps, dtype=np.uint64)
+    w = philox4x32_10(counters(idx, STREAM_DOPPLER, offset), key_of(seed))[:, 0]
+    return (np.float32(2.0 * np.pi) * uniform01(w)).reshape(n_frames, 2, ss, n_taps)

@@ -152,7 +152,41 @@ def test_unsupported_channels_raise():
     with pytest.raises(NotImplementedError):
         DeviceDataGen(flags(channel="mixRayleigh"))
     with pytest.raises(NotImplementedError):
-        DeviceDataGen(flags(channel="EPA"), mobile=True)
+        DeviceDataGen(flags(channel="mixAll"))
+
+
+@pytest.mark.parametrize("chan", ["ETU", "EVA", "EPA", "Flat", "Custom"])
+def test_doppler_channel_matches_host_given_the_same_phases(chan):
+    """mobile=True (radio.py:376-407): Jakes taps per symbol + per-symbol FIR with history, fed numpy's own draws"""
+    from dl_ofdm_amd import ofdm, radio, util
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(channel=chan)
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=9, mobile=True)
+    assert gen.doppler
+    n = 9
+    np.random.seed(5)
+    bits = util.bit_source(2, o.frame_size, n)
+    iq, _, _ = o.ofdm_tx_frame_np(bits)
+    fading = radio.rayleigh_chan_lte(F, o.Fs, mobile=True)
+    snr = np.linspace(0, 20, n).reshape(n, 1)
+    np.random.seed(321)
+    y_host, H_host = fading.run(iq)
+    out_host, npow_host = radio.AWGN_channel_np(y_host, snr)
+    np.random.seed(321)                                             # replay: per frame th_re then th_im
+    th = np.stack([np.stack([np.random.uniform(0, 2 * np.pi, size=(48, gen.n_taps)) for _ in range(2)])
+                   for _ in range(n)])
+    noise = np.random.randn(n, 7, 80, 2)
+    tx, _ = gen.transmit(n, bits=bits)
+    out, npow, H = gen.channel(tx, snr, taps=th, noise=noise.reshape(n, -1, 2), want_H=True)
+    assert np.abs(out.cpu().numpy() - out_host).max() <= 5e-5 * np.abs(out_host).max()
+    assert abs(float(npow) - npow_host) <= 1e-5 * npow_host
+    assert H.shape == (n, 7, 64) and np.abs(H.cpu().numpy() - H_host).max() <= 5e-5 * max(np.abs(H_host).max(), 1.0)
+    # drawn phases are the oracle's stream: the channel built from them equals the channel given them explicitly
+    th_dev = G.doppler_thetas(9, 4, n, gen.n_taps)
+    a = gen.channel(tx, snr, noise=noise.reshape(n, -1, 2), offset=4)[0].clone()
+    b = gen.channel(tx, snr, taps=th_dev, noise=noise.reshape(n, -1, 2), offset=4)[0]
+    assert np.abs((a - b).cpu().numpy()).max() <= 5e-5 * float(b.abs().max())
 
 
 def test_harness_trains_on_device_generated_data(tmp_path):
