@@ -231,8 +231,22 @@ static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int ro
     return launch_gemm<OP_KCONTIG, OP_CCONV_WT, 0, TAG_CCONV_BWD_X>(p, 1, s);
 }
 
+// C-Conv fold and the tail's slab reduction in one launch: both are tiny, and the reduction has no consumer
+// before the optimizer, so it rides on the fold instead of sitting on the critical path after the tail kernel
+__global__ __launch_bounds__(256) void cconv_fold_finalize_kernel(const float* __restrict__ partial, int splits,
+                                                                  long long slab, const float* __restrict__ colsum,
+                                                                  float* __restrict__ dw, float* __restrict__ dbias,
+                                                                  int kin, int F, int fold_blocks, TailFinalizeArgs a) {
+    if ((int)blockIdx.x < fold_blocks) {
+        cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x);
+    } else {
+        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
+                                 a.power_partial, a.n_power, a.power_denom, a.power_out, (int)blockIdx.x - fold_blocks);
+    }
+}
+
 static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
-                            void* ws, size_t ws_bytes, hipStream_t s) {
+                            void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin = nullptr) {
     if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(2 * kin, 2 * F, rows)) return DCCN_ERR_WORKSPACE;
     const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
@@ -249,8 +263,13 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     p.vecB = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);
     DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     const int nthreads = kin * F + F;
-    hipLaunchKernelGGL(cconv_fold_kernel, dim3(ceil_div(nthreads, kRedLanes)), dim3(256), 0, s, slabs, sp.splits, p.slab,
-                       cs, dw, dbias, kin, F);
+    const int fold_blocks = ceil_div(nthreads, kRedLanes);
+    if (fin)
+        hipLaunchKernelGGL(cconv_fold_finalize_kernel, dim3(fold_blocks + tail_finalize_blocks(fin->P)), dim3(256), 0, s,
+                           slabs, sp.splits, p.slab, cs, dw, dbias, kin, F, fold_blocks, *fin);
+    else
+        hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, slabs, sp.splits, p.slab, cs, dw, dbias,
+                           kin, F);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -287,9 +306,11 @@ static int tail_launch(bool bwd, const float* z, const int32_t* bits, const floa
 }
 
 // pp/power_out: optional R8 finish riding on the slab-reduction kernel (fused receiver step)
+// defer != nullptr: do not launch the slab reduction; hand its arguments to the caller (fused receiver step)
 static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob,
                      dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits,
-                     const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes, hipStream_t s) {
+                     const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes, hipStream_t s,
+                     TailFinalizeArgs* defer = nullptr) {
     if (!z || !bits || !tailp || !metrics || cells <= 0 || nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < tail_ws_bytes(cells, nbits)) return DCCN_ERR_WORKSPACE;
@@ -307,9 +328,15 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     DCCN_TRY(st);
     const int P = bwd ? tail_param_count(nbits) : 0;
     const bool pw = pp != nullptr && power_out != nullptr;
-    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(ceil_div(P + 2, 4)), dim3(256), 0, s, bm, bwd ? bg : nullptr,
-                       nblk, P, cells * nbits, metrics, bwd ? dtailp : nullptr, pw ? pp->partial : nullptr,
-                       pw ? pp->n : 0, pw ? pp->denom : 1.0, pw ? power_out : nullptr);
+    TailFinalizeArgs fa;
+    fa.blk_metrics = bm; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
+    fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
+    fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
+    if (defer) {
+        *defer = fa;
+        return DCCN_OK;
+    }
+    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(P)), dim3(256), 0, s, fa);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -401,8 +428,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     // R2
     DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
     // R3-R6 (+ tail backward)
+    TailFinalizeArgs fin;
     DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
-                       L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s));
+                       L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
     if (!train) return DCCN_OK;
 
     DeferredSlabs ds;
@@ -420,8 +448,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                                         sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds));
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
+    // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
     DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
-                              L.ws_conv_bw, s));
+                              L.ws_conv_bw, s, &fin));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     AdamRxArgs aa;

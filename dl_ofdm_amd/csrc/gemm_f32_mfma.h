@@ -570,13 +570,12 @@ static int launch_splitk_reduce(const float* partial, int splits, long long slab
 //   dWb[n,f] = dWeff[2n,2f+1] - dWeff[2n+1,2f]
 //   dba[f] = sum_r(dRe - dIm) = cs[2f] - cs[2f+1],  dbb = -dba     
 // element index e in [0, kin*F) -> (n,f); e in [kin*F, kin*F+F) -> bias f
-__global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict__ partial, int splits,
-                                                         long long slab, const float* __restrict__ colsum,
-                                                         float* __restrict__ dw, float* __restrict__ dbias,
-                                                         int kin, int F) {
+__device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partial, int splits, long long slab,
+                                                const float* __restrict__ colsum, float* __restrict__ dw,
+                                                float* __restrict__ dbias, int kin, int F, int block) {
     __shared__ float2 red[kRedGroups][kRedLanes];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int e = blockIdx.x * kRedLanes + lane;
+    const int e = block * kRedLanes + lane;
     const int total = kin * F, N2 = 2 * F;
     const bool is_w = e < total, is_b = (!is_w) && (e < total + F) && (dbias != nullptr);
     const int n = is_w ? e / F : 0, f = is_w ? e % F : (e - total);
@@ -620,6 +619,13 @@ __global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict
             dbias[F + f] = -t.x;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict__ partial, int splits,
+                                                         long long slab, const float* __restrict__ colsum,
+                                                         float* __restrict__ dw, float* __restrict__ dbias,
+                                                         int kin, int F) {
+    cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x);
 }
 
 }  // namespace dccn

@@ -191,16 +191,29 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
 // l, l+64, ...), wave g == P builds the metrics record, wave g == P+1 (fused receiver step
 // only) finishes the mean clipped power of R8 from the normalise kernel's per-block partial sums.
 // grid = ceil((P+2)/4) blocks.
-__global__ __launch_bounds__(256) void demod_tail_finalize_kernel(const TailBlockMetrics* __restrict__ blk_metrics,
-                                                                  const float* __restrict__ blk_grads, int nblocks,
-                                                                  int P, long long count,
-                                                                  dccn_metrics* __restrict__ metrics,
-                                                                  float* __restrict__ dtailp,
-                                                                  const double* __restrict__ power_partial,
-                                                                  int n_power, double power_denom,
-                                                                  float* __restrict__ power_out) {
+struct TailFinalizeArgs {
+    const TailBlockMetrics* blk_metrics;
+    const float* blk_grads;
+    int nblocks, P;
+    long long count;
+    dccn_metrics* metrics;
+    float* dtailp;
+    const double* power_partial;
+    int n_power;
+    double power_denom;
+    float* power_out;
+};
+static inline int tail_finalize_blocks(int P) { return (P + 2 + 3) / 4; }
+
+__device__ __forceinline__ void demod_tail_finalize_body(const TailBlockMetrics* __restrict__ blk_metrics,
+                                                         const float* __restrict__ blk_grads, int nblocks, int P,
+                                                         long long count, dccn_metrics* __restrict__ metrics,
+                                                         float* __restrict__ dtailp,
+                                                         const double* __restrict__ power_partial, int n_power,
+                                                         double power_denom, float* __restrict__ power_out,
+                                                         int block) {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = block * 4 + (threadIdx.x >> 6);
     if (g < P) {
         float v[kTailBlocks / 64];
 #pragma unroll
@@ -244,6 +257,11 @@ __global__ __launch_bounds__(256) void demod_tail_finalize_kernel(const TailBloc
         s = wave_sum(s);
         if (lane == 0) power_out[0] = (float)(s / power_denom);
     }
+}
+
+__global__ __launch_bounds__(256) void demod_tail_finalize_kernel(TailFinalizeArgs a) {
+    demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp, a.power_partial,
+                             a.n_power, a.power_denom, a.power_out, blockIdx.x);
 }
 
 }  // namespace dccn
