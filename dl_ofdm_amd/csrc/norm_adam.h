@@ -188,6 +188,122 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
     }
 }
 
+// ---- R0 in ONE pass for batches that fit in registers -----------------------------------------------
+// A block owns CG float4 column groups (4*CG columns) for ALL rows: thread t = (row slot t/CG, group t%CG)
+// keeps its rows slot, slot+128, ... (at most RPT of them) in registers, so x is read once and the two-pass
+// moments (mean, then mean of squared differences -- what tf.nn.moments computes) cost no second trip to HBM.
+// Column sums: xor-shuffles over the row slots of a wave, then one LDS stage over the waves (fixed order).
+// grid = ceil(cols / (4*CG)), block = 128*CG threads; needs cols % 4 == 0 and batch <= 128*RPT.
+// power_partial[blockIdx.x] = sum over the block of |clip(y)|^2; adam: see moments_kernel.
+template <int CG, int RPT>
+__global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int batch, int cols, float eps, float peak,
+                                                              double* __restrict__ power_partial,
+                                                              float* __restrict__ mean_out,
+                                                              float* __restrict__ var_out,
+                                                              dccn_adam_state* __restrict__ adam,
+                                                              dccn_adam_hparams hp) {
+    constexpr int NW = 2 * CG;                        // waves per block
+    constexpr int RS = 64 / CG;                       // row slots per wave
+    __shared__ double red[NW][CG][8];
+    __shared__ double stat[CG][8];
+    __shared__ double pred[NW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (adam != nullptr && blockIdx.x == 0 && t == 0) {
+        adam->alpha = adam_alpha(adam, hp);
+        adam->beta1_power = adam->beta1_power * hp.beta1;
+        adam->beta2_power = adam->beta2_power * hp.beta2;
+        adam->global_step = adam->global_step + 1.0f;
+    }
+    const int cg = t % CG, slot = t / CG;
+    const int c4 = (blockIdx.x * CG + cg) * 4;
+    const bool live = c4 < cols;
+    float4 v[RPT];
+    const int c4c = live ? c4 : 0;                    // clamped addresses: every load issues, none branches
+#pragma unroll
+    for (int p = 0; p < RPT; ++p)
+        v[p] = *reinterpret_cast<const float4*>(x + (size_t)min(slot + 128 * p, batch - 1) * cols + c4c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < RPT; ++p)
+        if (!live || slot + 128 * p >= batch) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-thread sum and sum of squares in fp64 (var = E[x^2] - mean^2 is safe in double), then ONE reduction
+    // over the block's rows: xor-shuffles over the row slots of a wave, LDS over the waves, fixed order
+    double sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < RPT; ++p) {
+        const double d0 = v[p].x, d1 = v[p].y, d2 = v[p].z, d3 = v[p].w;      // rows past the batch hold zeros
+        sq[0] += d0; sq[1] += d1; sq[2] += d2; sq[3] += d3;
+        sq[4] += d0 * d0; sq[5] += d1 * d1; sq[6] += d2 * d2; sq[7] += d3 * d3;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int m = CG; m < 64; m <<= 1) sq[e] += __shfl_xor(sq[e], m, 64);
+    if (lane < CG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][cg][e] = sq[e];
+    }
+    __syncthreads();
+    if (t < 8 * CG) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += red[w][t >> 3][t & 7];
+        stat[t >> 3][t & 7] = a;
+    }
+    __syncthreads();
+    double mean[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        mean[e] = stat[cg][e] / (double)batch;
+        double var = stat[cg][4 + e] / (double)batch - mean[e] * mean[e];
+        q[e] = (var < 0.0 ? 0.0 : var) * (double)batch;
+    }
+    (void)RS;
+    float inv[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float meanf = (float)mean[e], varf = (float)(q[e] / (double)batch);
+        inv[e] = 1.0f / sqrtf(varf + eps);
+        sh[e] = -meanf * inv[e];
+        if (slot == 0 && live) {
+            if (mean_out) mean_out[c4 + e] = meanf;
+            if (var_out) var_out[c4 + e] = varf;
+        }
+    }
+    const float rs2 = 1.41421356237309515f;            // float32(np.sqrt(2))
+    double pw = 0.0;
+#pragma unroll
+    for (int p = 0; p < RPT; ++p) {
+        const int r = slot + 128 * p;
+        if (live && r < batch) {
+            float o[4] = {(v[p].x * inv[0] + sh[0]) / rs2, (v[p].y * inv[1] + sh[1]) / rs2,
+                          (v[p].z * inv[2] + sh[2]) / rs2, (v[p].w * inv[3] + sh[3]) / rs2};
+            *reinterpret_cast<float4*>(y + (size_t)r * cols + c4) = make_float4(o[0], o[1], o[2], o[3]);
+            if (power_partial != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float l2 = sqrtf(o[e] * o[e] + o[e + 1] * o[e + 1]);
+                    const float sc = peak / fmaxf(l2, peak);
+                    const float ci = o[e] * sc, cq = o[e + 1] * sc;
+                    pw += (double)(ci * ci + cq * cq);
+                }
+            }
+        }
+    }
+    if (power_partial != nullptr) {
+        pw = wave_sum(pw);
+        if (lane == 0) pred[wave] = pw;
+        __syncthreads();
+        if (t == 0) {
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += pred[w];
+            power_partial[blockIdx.x] = a;
+        }
+    }
+}
+
 // out[0] = (float)(sum(partial[0..n)) / denom)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double denom,
                                                            float* __restrict__ out) {
