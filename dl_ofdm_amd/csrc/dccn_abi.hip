@@ -46,7 +46,7 @@ static size_t norm_ws_bytes(int batch, int cols) {
 constexpr int kNormFusedCG = 2, kNormFusedRPT = 12;
 static bool norm_fused_ok(const float* x, const float* y, int batch, int cols) {
     return (cols % 4 == 0) && batch <= 128 * kNormFusedRPT && aligned16(x) && aligned16(y) &&
-           ceil_div(cols, 4 * kNormFusedCG) <= norm_grid_x(cols) * norm_grid_y(batch);   // partial buffer large enough
+           ceil_div(cols, 4 * kNormFusedCG) + 8 <= norm_grid_x(cols) * norm_grid_y(batch);   // partial buffer large enough
 }
 
 struct PowerPartials {      // where normalise left the R8 partial sums (finished by a later kernel)
@@ -68,7 +68,7 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
     double* pw = c.take<double>((size_t)gx * gy);
     if (norm_fused_ok(x, y, batch, cols)) {
         // the whole batch of a column strip fits in one block's registers: single pass, single launch
-        const int blocks = ceil_div(cols, 4 * kNormFusedCG);
+        const int blocks = ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8;
         hipLaunchKernelGGL((norm_fused_kernel<kNormFusedCG, kNormFusedRPT>), dim3(blocks), dim3(128 * kNormFusedCG), 0, s,
                            x, y, batch, cols, eps, peak, want_power ? pw : nullptr, mean, var, adam, hp);
         DCCN_LAUNCH_CHECK();

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
 // keeps its rows slot, slot+128, ... (at most RPT of them) in registers, so x is read once and the two-pass
 // moments (mean, then mean of squared differences -- what tf.nn.moments computes) cost no second trip to HBM.
 // Column sums: xor-shuffles over the row slots of a wave, then one LDS stage over the waves (fixed order).
-// grid = ceil(cols / (4*CG)), block = 128*CG threads; needs cols % 4 == 0 and batch <= 128*RPT.
+// grid = ceil(cols / (4*CG)) rounded up to a multiple of 8, block = 128*CG threads; needs cols % 4 == 0 and
+// batch <= 128*RPT.
 // power_partial[blockIdx.x] = sum over the block of |clip(y)|^2; adam: see moments_kernel.
 template <int CG, int RPT>
 __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -215,8 +216,12 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __res
         adam->beta2_power = adam->beta2_power * hp.beta2;
         adam->global_step = adam->global_step + 1.0f;
     }
+    // XCD-aware strip order: workgroups go round-robin over the 8 XCDs (each with its own L2), and strips that
+    // share 128-byte lines of x are neighbours -- so XCD k takes the k-th run of consecutive strips
+    const int per_xcd = gridDim.x / 8;
+    const int strip = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     const int cg = t % CG, slot = t / CG;
-    const int c4 = (blockIdx.x * CG + cg) * 4;
+    const int c4 = (strip * CG + cg) * 4;
     const bool live = c4 < cols;
     float4 v[RPT];
     const int c4c = live ? c4 : 0;                    // clamped addresses: every load issues, none branches
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __res
             double a = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) a += pred[w];
-            power_partial[blockIdx.x] = a;
+            power_partial[blockIdx.x] = a;              // (idle strips past the last column contribute 0)
         }
     }
 }

@@ -43,6 +43,8 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps(dict(mode="device-generated", channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
                           symbols_per_s=round(a.frames * 7 / dt), final_ce=round(eng.metrics()["ce_mean"], 4))))
+    if a.host_steps <= 0:
+        return
     fading = radio.rayleigh_chan_lte(F, o.Fs)
     np.random.seed(1)
     t0 = time.perf_counter()

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--frames", type=int, nargs="+", default=[73, 1170])
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--paths", nargs="+", default=["fused-graph", "fused-eager", "composed-autograd"])
     a = ap.parse_args()
     F = H.Flags(nbits=2, nfilter=64, channel="EPA")
     tx = ofdm.ofdm_tx(F)
@@ -56,6 +57,8 @@ def main():
 
         for name, fn in (("fused-graph", lambda: pl.run(True, True)), ("fused-eager", lambda: pl.run(True, False)),
                          ("composed-autograd", composed)):
+            if name not in a.paths:
+                continue
             for _ in range(a.warmup):
                 fn()
             torch.cuda.synchronize()
