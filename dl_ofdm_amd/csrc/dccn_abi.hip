@@ -36,17 +36,21 @@ static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) +
 static int norm_grid_x(int cols) { return ceil_div(ceil_div(cols, 4), 64); }
 static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
 
+constexpr int kNormFusedCG = 2, kNormFusedRPT = 12;
+static int norm_fused_blocks(int cols) { return ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8; }
+static size_t norm_power_slots(int batch, int cols) {
+    const size_t a = (size_t)norm_grid_x(cols) * norm_grid_y(batch), b = (size_t)norm_fused_blocks(cols);
+    return a > b ? a : b;
+}
 static size_t norm_ws_bytes(int batch, int cols) {
     size_t o = 0;
     o = carve_size(o, (size_t)kNormRowChunks * cols * 2 * sizeof(double));
-    o = carve_size(o, (size_t)norm_grid_x(cols) * norm_grid_y(batch) * sizeof(double));
+    o = carve_size(o, norm_power_slots(batch, cols) * sizeof(double));
     return align_up(o, 256);
 }
 
-constexpr int kNormFusedCG = 2, kNormFusedRPT = 12;
 static bool norm_fused_ok(const float* x, const float* y, int batch, int cols) {
-    return (cols % 4 == 0) && batch <= 128 * kNormFusedRPT && aligned16(x) && aligned16(y) &&
-           ceil_div(cols, 4 * kNormFusedCG) + 8 <= norm_grid_x(cols) * norm_grid_y(batch);   // partial buffer large enough
+    return (cols % 4 == 0) && batch <= 128 * kNormFusedRPT && aligned16(x) && aligned16(y);
 }
 
 struct PowerPartials {      // where normalise left the R8 partial sums (finished by a later kernel)
@@ -65,10 +69,10 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
     Carver c(ws, ws_bytes);
     double* partial = c.take<double>((size_t)kNormRowChunks * cols * 2);
     const int gx = norm_grid_x(cols), gy = norm_grid_y(batch);
-    double* pw = c.take<double>((size_t)gx * gy);
+    double* pw = c.take<double>(norm_power_slots(batch, cols));
     if (norm_fused_ok(x, y, batch, cols)) {
         // the whole batch of a column strip fits in one block's registers: single pass, single launch
-        const int blocks = ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8;
+        const int blocks = norm_fused_blocks(cols);
         hipLaunchKernelGGL((norm_fused_kernel<kNormFusedCG, kNormFusedRPT>), dim3(blocks), dim3(128 * kNormFusedCG), 0, s,
                            x, y, batch, cols, eps, peak, want_power ? pw : nullptr, mean, var, adam, hp);
         DCCN_LAUNCH_CHECK();
