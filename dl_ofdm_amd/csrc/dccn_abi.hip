@@ -108,15 +108,17 @@ static int round_k(int K) { return ceil_div(K, 64) * 64; }
 // the fast GEMM loaders use 32-bit byte offsets from a uniform base: operand must be < 2 GiB
 static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < (1LL << 31); }
 
+// ldx > 0: x is a column window of a wider row-major matrix (row stride ldx)
 static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                          hipStream_t s) {
+                          hipStream_t s, int ldx = 0) {
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    const int lda = ldx > 0 ? ldx : K;
     GemmParams p = gp_zero();
     p.A = x; p.B = w; p.C = y; p.bias = bias;
     p.M = M; p.N = N; p.K = K;
-    p.lda = K; p.ldb = N; p.ldc = N;
+    p.lda = lda; p.ldb = N; p.ldc = N;
     p.klen = round_k(K);
-    p.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);     // KCONTIG: ld = K, k extent K
+    p.vecA = (K % 4 == 0) && (lda % 4 == 0) && aligned16(x) && small_enough(M, lda);     // KCONTIG: k extent K
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
@@ -159,7 +161,7 @@ struct DeferredSlabs {
     int splits;
 };
 static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
-                            size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr) {
+                            size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr, int ldx = 0) {
     if (!x || !dy || !dw || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
     const SplitPlan sp = plan_splitk(K, N, M);
@@ -169,10 +171,10 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     GemmParams p = gp_zero();                 // dw[K,N] = x[M,K]^T . dy[M,N]
     p.A = x; p.B = dy;
     p.M = K; p.N = N; p.K = M;
-    p.lda = K; p.ldb = N; p.ldc = N;
+    p.lda = ldx > 0 ? ldx : K; p.ldb = N; p.ldc = N;
     p.klen = sp.klen;
     p.slab = (long long)K * N;
-    p.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
+    p.vecA = (K % 4 == 0) && (p.lda % 4 == 0) && aligned16(x) && small_enough(M, p.lda);
     p.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     if (defer) { defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1; }
     if (sp.splits == 1) {
@@ -228,25 +230,26 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
 }
 
 static int cconv_fwd_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
-                          hipStream_t s) {
+                          hipStream_t s, int ldx = 0) {
     if (!x || !w || !out || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // out[rows,2F] = x[rows,2kin] . Weff[2kin,2F]
     p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
     p.M = rows; p.N = 2 * F; p.K = 2 * kin;
-    p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
+    p.lda = ldx > 0 ? ldx : 2 * kin; p.ldb = 2 * F; p.ldc = 2 * F;
     p.klen = round_k(2 * kin);
     p.cF = F;
-    p.vecA = (kin % 2 == 0) && aligned16(x) && small_enough(rows, 2LL * kin);
+    p.vecA = (kin % 2 == 0) && (p.lda % 4 == 0) && aligned16(x) && small_enough(rows, (long long)p.lda);
     p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);      // float2 loads of [Wa|Wb] rows
     return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
 }
 
-static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int rows, int kin, int F, hipStream_t s) {
+static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int rows, int kin, int F, hipStream_t s,
+                            int ldc = 0) {
     if (!dout || !w || !dx || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // dx[rows,2kin] = dout[rows,2F] . Weff^T
     p.A = dout; p.B = w; p.C = dx;
     p.M = rows; p.N = 2 * kin; p.K = 2 * F;
-    p.lda = 2 * F; p.ldb = 2 * F; p.ldc = 2 * kin;
+    p.lda = 2 * F; p.ldb = 2 * F; p.ldc = ldc > 0 ? ldc : 2 * kin;
     p.klen = round_k(2 * F);
     p.cF = F;
     p.vecA = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);

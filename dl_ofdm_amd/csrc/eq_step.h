@@ -3,23 +3,25 @@
 //   R0 normalise -> equalizer_ofdm (model.py:349-478) -> frozen basic receiver -> loss/BER
 //   -> backward to the Equalizer/* variables only -> TF Adam on the equaliser arena.
 // Included inside namespace dccn of dccn_abi.hip, after the *_impl helpers it is built from.
-// Only FLAGS.cp=True is planned here (the composable layer API covers cp=False).
+// FLAGS.cp=False (model.py:364-366, 1236-1240): the equaliser's first dense layer and the receiver's C-Conv read
+// the K-sample window behind the cyclic prefix of [.., n_sc, 2] rows -- a column window of the same buffers.
 
 static bool eq_shape_ok(const dccn_eq_shape* sh) {
     return sh && sh->batch > 0 && sh->S > 0 && sh->K > 0 && sh->CP >= 0 && sh->F > 0 && sh->D > 0 && sh->nbits >= 1 &&
-           sh->nbits <= 4 && sh->pilot_size > 0 && sh->cp == 1;
+           sh->nbits <= 4 && sh->pilot_size > 0 && (sh->cp == 0 || sh->cp == 1);
 }
 
 struct EqDims {
-    int B, S, K, nsc, R, SK2, Pp, F, D;
+    int B, S, K, nsc, R, SK2, Pp, F, D, cp, win;     // win: float offset of the post-CP window inside a row
     long long o[21];        // parameter offsets, TF creation order (dense, conv3d, dense_1..4, conv3d_1..3, dense_5)
 };
 static EqDims eq_dims(const dccn_eq_shape* sh) {
     EqDims d;
     d.B = sh->batch; d.S = sh->S; d.K = sh->K; d.nsc = sh->K + sh->CP; d.R = d.B * d.S;
     d.SK2 = d.S * d.K * 2; d.Pp = 2 * sh->pilot_size; d.F = sh->F; d.D = sh->D;
+    d.cp = sh->cp; d.win = sh->cp ? 0 : 2 * sh->CP;
     const long long K2 = 2LL * d.K, N2 = 2LL * d.nsc, SK2 = d.SK2;
-    const long long sizes[20] = {N2 * K2, K2,                 // dense
+    const long long sizes[20] = {(sh->cp ? N2 : K2) * K2, K2,   // dense (input: whole row, or the window)
                                  (long long)d.K * K2, K2,     // conv3d     (1,K) -> K filters
                                  SK2 * d.Pp, d.Pp,            // dense_1    pilot extraction
                                  d.Pp * SK2, SK2,             // dense_2
@@ -45,7 +47,7 @@ struct EqWs {
 static size_t eq_split_ws(const EqDims& d) {
     size_t m = 0;
     auto upd = [&](int Mo, int No, int Kr) { const size_t v = splitk_ws_bytes(Mo, No, Kr); if (v > m) m = v; };
-    upd(2 * d.nsc, 2 * d.K, d.R);          // dense
+    upd(d.cp ? 2 * d.nsc : 2 * d.K, 2 * d.K, d.R);   // dense
     upd(2 * d.K, 2 * d.K, d.R);            // the three (1,K) C-Convs
     upd(d.SK2, d.Pp, d.B);
     upd(d.Pp, d.SK2, d.B);
@@ -138,7 +140,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     const int B = d.B, R = d.R, K = d.K, SK2 = d.SK2, K2 = 2 * d.K, N2 = 2 * d.nsc;
     const long long nBK = (long long)B * SK2;          // floats in a [B,S,K,2] tensor
     dccn_rx_shape rsh;
-    rsh.batch = B; rsh.S = d.S; rsh.kin = d.nsc; rsh.F = d.F; rsh.D = d.D; rsh.nbits = sh->nbits;
+    rsh.batch = B; rsh.S = d.S; rsh.kin = d.cp ? d.nsc : K; rsh.F = d.F; rsh.D = d.D; rsh.nbits = sh->nbits;
+    const int kin0 = d.cp ? N2 : K2;                   // K extent of the first dense layer
     const RxLayout L = rx_layout(&rsh);
     const float* Q = b->rx_params;
     float* h = b->chest;
@@ -151,7 +154,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
                        (float*)nullptr, d.S * N2, 1e-12f);
     DCCN_LAUNCH_CHECK();
-    DCCN_TRY(dense_fwd_impl(w.ln, P + d.o[0], P + d.o[1], w.t1, R, N2, K2, s));
+    DCCN_TRY(dense_fwd_impl(w.ln + d.win, P + d.o[0], P + d.o[1], w.t1, R, kin0, K2, s, N2));
     DCCN_TRY(cconv_fwd_impl(w.t1, P + d.o[2], P + d.o[3], w.y, R, K, K, s));
     // :394-426 pilot bottleneck
     DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
@@ -182,7 +185,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_LAUNCH_CHECK();
     DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
     // frozen basic receiver (model.py:1222-1292) + loss/BER
-    DCCN_TRY(cconv_fwd_impl(b->out_eq, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, d.nsc, d.F, s));
+    DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
     DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
     DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
                        train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s));
@@ -190,7 +193,12 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
 
     // ---- backward: through the frozen receiver to its input ...
     DCCN_TRY(dense_bwd_x_impl(w.dz, Q + L.o_dense_w, w.dfft, B, L.dK, L.dN, s));
-    DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout, R, d.nsc, d.F, s));
+    if (!d.cp) {                                        // nothing flows back into the cyclic-prefix samples
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(ew_blocks_n((long long)R * N2)), dim3(256), 0, s, w.dout,
+                           (long long)R * N2);
+        DCCN_LAUNCH_CHECK();
+    }
+    DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout + d.win, R, rsh.kin, d.F, s, N2));
     // ... then the equaliser, last layer first
     DCCN_TRY(dense_bwd_full_impl(w.cat, w.dout, P + d.o[18], w.dcat, G + d.o[18], G + d.o[19], R, 4 * K, N2, w.ws_split,
                                  w.n_split, s));
@@ -224,7 +232,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_LAUNCH_CHECK();
     DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
     DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_split, w.n_split, s));
-    DCCN_TRY(dense_bwd_w_impl(w.ln, w.dt1, G + d.o[0], G + d.o[1], R, N2, K2, w.ws_split, w.n_split, s));
+    DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_split, w.n_split, s, nullptr,
+                              N2));
     // optimizer: Equalizer/* only (ofdmreceiver_np_mp.py:330), L2 terms enter through reg_coef
     return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s);
 }

@@ -245,6 +245,11 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restri
         b[i] = make_float2(v.z, v.w);
     }
 }
+// plain zero fill (a kernel rather than hipMemsetAsync so that graph capture sees an ordinary launch)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ a, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a[i] = 0.f;
+}
 // a += b  (the two gradient paths into the frequency-domain input, model.py:383 and :392)
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b,
                                                           long long n) {

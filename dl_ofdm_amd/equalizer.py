@@ -38,7 +38,7 @@ class _FusedPlan:
     def __init__(self, tr: "EqualizerTrainer", batch: int):
         F, o, dev = tr.FLAGS, tr.ofdmobj, tr.device
         self.tr, self.batch = tr, int(batch)
-        self.shape = EqShape(self.batch, F.nsymbol, o.K, o.CP, 1, F.nfilter, o.frame_size, F.nbits, o.pilot_size,
+        self.shape = EqShape(self.batch, F.nsymbol, o.K, o.CP, 1 if F.cp else 0, F.nfilter, o.frame_size, F.nbits, o.pilot_size,
                              len(o.pilotCarriers))
         offs = (C.c_longlong * 21)()
         check(tr.lib.dccn_eq_param_offsets(C.byref(self.shape), offs), "dccn_eq_param_offsets")
@@ -132,7 +132,7 @@ class EqualizerTrainer:
             self.rx_arena[o_:o_ + int(np.prod(shp))] = torch.as_tensor(
                 np.asarray(rx_params[n], dtype=np.float32).reshape(-1)).to(self.device)
         self.pilot_carriers = torch.as_tensor(np.asarray(ofdmobj.pilotCarriers, dtype=np.int32)).to(self.device)
-        self.fused_ok = bool(FLAGS.cp)               # the planned step covers cp=True (include/dccn.h)
+        self.fused_ok = True
         self._plans: Dict[int, _FusedPlan] = {}
 
     # ---- arena ---------------------------------------------------------------------------------
@@ -230,8 +230,6 @@ class EqualizerTrainer:
         """the fused plan of this batch size: fill ``.x`` / ``.bits`` in place (e.g. from
         :class:`~dl_ofdm_amd.datagen.DeviceDataGen`), then ``.run(train)``; ``.metrics_buf`` / ``.tx_power`` /
         ``.chest`` / ``.out_eq`` / ``.snr_db`` hold the step's outputs on the device."""
-        if not self.fused_ok:
-            raise _lib.DccnError("the planned step covers FLAGS.cp=True only")
         return self._plan(batch)
 
     def __del__(self):
@@ -243,7 +241,7 @@ class EqualizerTrainer:
 
     def train_step(self, x, bits, chan_gt=None, fused: bool = True, graph: bool = True) -> dict:
         """fused=True: the pre-planned ``dccn_eq_train_step`` sequence (hipGraph replay); fused=False: the
-        same kernels composed through the layer API and the autograd tape (the only path for cp=False)."""
+        same kernels composed through the layer API and the autograd tape."""
         if fused and self.fused_ok:
             return self._fused_step(x, bits, True, graph, chan_gt)
         self.grads.zero_()

@@ -268,12 +268,13 @@ int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw,
 /* ---- the fused equaliser transfer-learning step ------------------------------------------------------
  * dev/py/ofdmreceiver_np_mp.py:283-330,414 (session.run(train_op...)) and :87 (evaluation run) as ONE
  * pre-planned launch sequence: R0 normalise -> equalizer_ofdm -> frozen basic receiver -> loss/BER ->
- * backward to the Equalizer/ variables only -> TF Adam on the equaliser arena.  cp must be 1 (the
- * composable operators above cover cp=0).  Equaliser parameter arena, TF creation order (floats):
- *   dense k[2n_sc,2K] b | conv3d k[K,2K] b | dense_1 k[S*K*2,2*pilot_size] b | dense_2 | dense_3 |
+ * backward to the Equalizer/ variables only -> TF Adam on the equaliser arena.  cp = 0: the first dense layer and
+ * the receiver read the K samples behind the cyclic prefix (model.py:364-366, 1236-1240).
+ * Equaliser parameter arena, TF creation order (floats):
+ *   dense k[2n_sc (cp=1) or 2K (cp=0), 2K] b | conv3d k[K,2K] b | dense_1 k[S*K*2,2*pilot_size] b | dense_2 | dense_3 |
  *   dense_4 | conv3d_1 k[S,K,2] b[2] | conv3d_2 k[K,2K] b | conv3d_3 | dense_5 k[4K,2n_sc] b
  * (offsets[0..19] = start of each tensor, offsets[20] = total).  rx_params: the frozen receiver in the
- * dccn_rx_param_offsets layout with kin = n_sc = K + CP. */
+ * dccn_rx_param_offsets layout with kin = K + CP (cp=1) or K (cp=0). */
 typedef struct dccn_eq_shape {
     int batch, S, K, CP, cp;      /* frames, OFDM symbols per frame, nfft, cyclic prefix, FLAGS.cp */
     int F, D, nbits;              /* receiver: nfilter, data cells per frame, bits per cell */

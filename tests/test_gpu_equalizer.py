@@ -230,19 +230,20 @@ def test_equalizer_without_cp():
 
 
 # ---- the transfer-learning step (ofdmreceiver_np_mp.py:319-330) -----------------------------------------
-def _trainer(nbits=2, seed=21):
+def _trainer(nbits=2, seed=21, cp=True):
     from dl_ofdm_amd.equalizer import EqualizerTrainer
     from dl_ofdm_amd.ofdm import ofdm_tx
     F = _Flags()
-    F.nbits, F.opt, F.init_learning = nbits, 0, 1e-3
+    F.nbits, F.opt, F.init_learning, F.cp = nbits, 0, 1e-3, cp
     tx = ofdm_tx(F)
-    ecfg = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=True, pilot_size=tx.pilot_size,
+    ecfg = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=cp, pilot_size=tx.pilot_size,
                       pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
-    rcfg = O.RxConfig(S=7, kin=80, F=64, D=tx.frame_size, nbits=nbits)
+    rcfg = O.RxConfig(S=7, kin=80 if cp else 64, F=64, D=tx.frame_size, nbits=nbits)
     pe = E.init_params(ecfg, seed=seed, bias_scale=0.05)
     pr = O.init_params(rcfg, seed=seed + 1)
     tr = EqualizerTrainer(F, tx, pr, seed=3)
-    assert tr.names == list(E.param_shapes(ecfg).keys()) and tr.n_params == 1_753_282
+    assert tr.names == list(E.param_shapes(ecfg).keys())
+    assert tr.n_params == (1_753_282 if cp else 1_753_282 - 32 * 128)
     tr.load_params(pe)
     return F, tx, ecfg, rcfg, pe, pr, tr
 
@@ -352,10 +353,12 @@ def test_equalizer_learns_a_flat_fading_channel():
     assert len(sw["Flat"][1]) == 3
 
 
-def test_fused_step_equals_composed_step():
-    """the planned launch sequence and the autograd-composed one run the same kernels on the same arenas"""
-    F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=31)
-    _, _, _, _, _, _, tr_b = _trainer(seed=31)
+@pytest.mark.parametrize("cp", [True, False])
+def test_fused_step_equals_composed_step(cp):
+    """the planned launch sequence and the autograd-composed one run the same kernels on the same arenas
+    (cp=False: both read the post-CP window, model.py:364-366 / 1236-1240)"""
+    F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=31, cp=cp)
+    _, _, _, _, _, _, tr_b = _trainer(seed=31, cp=cp)
     rng = np.random.RandomState(9)
     for step in range(4):
         x = (rng.standard_normal((12, 7, 80, 2)) * 2).astype(np.float32)
@@ -394,3 +397,33 @@ def test_equalizer_harness_on_device_generated_data():
     sw = out["sweep"]
     assert set(sw) == set(H.TEST_CHANNELS) and all(len(v[1]) == 3 for v in sw.values())
     assert sw["Flat"][1][-1] < sw["Flat"][1][0]                 # BER falls with SNR on the training channel
+
+
+def test_fused_step_without_cp_matches_oracle():
+    """cp=False through the planned step against the fp64 autograd oracle (window reads, zero gradient into the CP)"""
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer(cp=False, seed=41)
+    rng = np.random.RandomState(17)
+    x = (rng.standard_normal((7, 7, 80, 2)) * 2).astype(np.float32)
+    bits = rng.randint(0, 2, (7, tx.frame_size, 2)).astype(np.int32)
+    lit_rx = LiteralRx({k: v.astype(np.float64) for k, v in pr.items()}, rcfg, dtype=torch.float64, literal_conv=False)
+
+    class _Win(LiteralEqualizer):                       # the frozen receiver crops the prefix itself (model.py:1236-1240)
+        def forward_backward(self, x_raw, bits_):
+            rec = self.rx.receiver
+            self.rx.receiver = lambda v: rec(v[:, :, 16:80, :])
+            try:
+                return super().forward_backward(x_raw, bits_)
+            finally:
+                self.rx.receiver = rec
+    g_ref, info = _Win({k: v.astype(np.float64) for k, v in pe.items()}, lit_rx, ecfg).forward_backward(x.astype(np.float64), bits)
+    m = tr.train_step(x, bits, fused=True, graph=False)
+    assert abs(m["ce_mean"] - info["ce_mean"]) <= 3e-6 * abs(info["ce_mean"])
+    assert np.array_equal(np.asarray(m["conf"]).reshape(2, 2), info["conf"])
+    g = tr.get_grads()
+    p0 = {k: v for k, v in pe.items()}
+    for n in tr.names:
+        reg = E.EQ_REG_COEFF * 2 * O.REG_L2 * p0[n].astype(np.float64).ravel() if "/dense" in n else 0.0
+        got, want = g[n].astype(np.float64).ravel() + reg, g_ref[n].ravel()
+        cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+        assert cos >= 1 - 1e-6, (n, cos)
+        assert np.abs(got - want).max() <= 3e-4 * np.abs(want).max(), n
