@@ -67,6 +67,12 @@ class EqBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
+class ChannelGroup(C.Structure):
+    """dccn_channel_group"""
+    _fields_ = [("frames", c_void_p), ("n_frames", c_int), ("coeff", c_void_p), ("alpha", c_void_p),
+                ("n_taps", c_int), ("L", c_int), ("identity", c_int), ("Fd", c_float)]
+
+
 METRICS_BYTES = C.sizeof(Metrics)
 ADAM_STATE_BYTES = C.sizeof(AdamState)
 
@@ -133,6 +139,9 @@ SIGNATURES = {
     "dccn_channel_doppler_awgn_workspace_size": (_sz, [_i, _i, _i, _i]),
     "dccn_channel_doppler_awgn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i,
                                        C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
+    "dccn_channel_groups_awgn_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_channel_groups_awgn": (_i, [_vp, POINTER(ChannelGroup), _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                                      _i, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
     "dccn_crc32c": (C.c_uint32, [C.c_uint32, _vp, _sz]),
     "dccn_channel_awgn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, C.c_ulonglong,
                                C.c_uint, _vp, _sz, _vp]),

@@ -85,23 +85,28 @@ __global__ __launch_bounds__(256) void tx_grid_kernel(const int* __restrict__ bi
 // radio.py:352-372 static taps: tap_k = (z0 + i z1)/sqrt(2) * coeff_k, impulse response g = taps . alpha
 // ([n_taps, L] sinc-interpolation matrix), H = fft(g, nfft).  One block (64 threads) per frame.
 // taps_in (standard normals [n, n_taps, 2]) == nullptr: draw them.  identity != 0: g = [1] (AWGN channel).
+// frames (nullable): the frame indices this launch covers (frame-interleaved 'mix' channels run one launch per
+// profile); tap_stride: taps per frame in taps_in and in the Philox index; g_stride: float2 per frame in g;
+// h_rep: copies of H per frame (the mix channels report H per symbol for static frames too).
 __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restrict__ taps_in,
                                                           const float* __restrict__ coeff,
                                                           const float* __restrict__ alpha, float2* __restrict__ g,
                                                           float2* __restrict__ H, int n_taps, int L, int nfft,
-                                                          int identity, unsigned offset, unsigned long long seed) {
+                                                          int identity, unsigned offset, unsigned long long seed,
+                                                          const int* __restrict__ frames, int tap_stride, int g_stride,
+                                                          int h_rep) {
     __shared__ float2 tap[16];
     __shared__ float2 gs[64];
-    const int fr = blockIdx.x, t = threadIdx.x;
+    const int fr = frames ? frames[blockIdx.x] : (int)blockIdx.x, t = threadIdx.x;
     if (identity) {
         if (t < L) gs[t] = make_float2(t == 0 ? 1.f : 0.f, 0.f);
     } else {
         if (t < n_taps) {
             float2 z;
             if (taps_in) {
-                z = make_float2(taps_in[((size_t)fr * n_taps + t) * 2], taps_in[((size_t)fr * n_taps + t) * 2 + 1]);
+                z = make_float2(taps_in[((size_t)fr * tap_stride + t) * 2], taps_in[((size_t)fr * tap_stride + t) * 2 + 1]);
             } else {
-                const Philox4 p = philox4x32_10((unsigned long long)fr * n_taps + t, kStreamTaps, offset, seed);
+                const Philox4 p = philox4x32_10((unsigned long long)fr * tap_stride + t, kStreamTaps, offset, seed);
                 z = box_muller(p.v[0], p.v[1]);
             }
             const float c = coeff[t] * 0.70710678118654752440f;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
         }
     }
     __syncthreads();
-    if (t < L) g[(size_t)fr * L + t] = gs[t];
+    if (t < L) g[(size_t)fr * g_stride + t] = gs[t];
     if (H) {
         for (int f = t; f < nfft; f += 64) {
             float2 a = make_float2(0.f, 0.f);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
                 a.x += gs[l].x * cs - gs[l].y * sn;
                 a.y += gs[l].x * sn + gs[l].y * cs;
             }
-            H[(size_t)fr * nfft + f] = a;
+            for (int r = 0; r < h_rep; ++r) H[((size_t)fr * h_rep + r) * nfft + f] = a;
         }
     }
 }
@@ -139,11 +144,11 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
 // |y|^2 for the AWGN stage's power normalisation.  grid = (ceil(T/256), frames).
 __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                        float2* __restrict__ y, double* __restrict__ partial, int T,
-                                                       int L) {
+                                                       int L, const int* __restrict__ frames, int g_stride) {
     __shared__ double sh[4];
     __shared__ float2 gs[64];
-    const int fr = blockIdx.y;
-    if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * L + threadIdx.x];
+    const int fr = frames ? frames[blockIdx.y] : (int)blockIdx.y;
+    if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int off = (L - 1) / 2;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict_
     pw = wave_sum(pw);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[(size_t)fr * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // radio.py:513-526 AWGN_channel_np: out = y / sqrt(mean |y|^2 over the batch) + noise * sqrt(0.5) 10^(-SNR/20),
@@ -213,10 +218,11 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
                                                           const float* __restrict__ alpha, float2* __restrict__ g,
                                                           float2* __restrict__ H, int n_taps, int L, int nfft, int S,
                                                           float Fd, float t_sym, unsigned offset,
-                                                          unsigned long long seed) {
+                                                          unsigned long long seed, const int* __restrict__ frames,
+                                                          int tap_stride, int g_stride) {
     __shared__ float2 tap[16 * 16];          // [S][n_taps], S <= 16
     __shared__ float2 gs[16 * 64];           // [S][L]
-    const int fr = blockIdx.x;
+    const int fr = frames ? frames[blockIdx.x] : (int)blockIdx.x;
     const float step = 3.14159265358979323846f / (4.0f * kSinusoids);
     for (int e = threadIdx.x; e < S * n_taps; e += 64) {
         const int sym = e / n_taps, k = e % n_taps;
@@ -226,14 +232,14 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
             const float an = ((float)(n + 1) - 0.5f) * step;
             float thr, thi;
             if (theta_in) {
-                thr = theta_in[(((size_t)fr * 2 + 0) * kSinusoids + n) * n_taps + k];
-                thi = theta_in[(((size_t)fr * 2 + 1) * kSinusoids + n) * n_taps + k];
+                thr = theta_in[(((size_t)fr * 2 + 0) * kSinusoids + n) * tap_stride + k];
+                thi = theta_in[(((size_t)fr * 2 + 1) * kSinusoids + n) * tap_stride + k];
             } else {
-                const unsigned long long base = ((unsigned long long)fr * 2 * kSinusoids + n) * n_taps + k;
+                const unsigned long long base = ((unsigned long long)fr * 2 * kSinusoids + n) * tap_stride + k;
                 thr = 6.2831853071795864769f *
                       uniform01(philox4x32_10(base, kStreamDoppler, offset, seed).v[0]);
                 thi = 6.2831853071795864769f *
-                      uniform01(philox4x32_10(base + (unsigned long long)kSinusoids * n_taps, kStreamDoppler, offset, seed).v[0]);
+                      uniform01(philox4x32_10(base + (unsigned long long)kSinusoids * tap_stride, kStreamDoppler, offset, seed).v[0]);
             }
             sr += cosf(6.2831853071795864769f * t * (Fd * cosf(an + a0)) + thr);
             si += cosf(6.2831853071795864769f * t * (Fd * cosf(an - a0)) + thi);
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
             a.y += tap[sym * n_taps + k].y * w;
         }
         gs[e] = a;
-        g[((size_t)fr * S + sym) * L + l] = a;
+        g[(size_t)fr * g_stride + sym * L + l] = a;
     }
     __syncthreads();
     if (H) {
@@ -276,17 +282,17 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
 // symbol's own end, nothing before the frame).  grid = (ceil(T/256), frames); + partial sums of |y|^2.
 __global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                           float2* __restrict__ y, double* __restrict__ partial, int T,
-                                                          int L, int n_sc, int n_taps) {
+                                                          int L, int n_sc, int n_taps, const int* __restrict__ frames,
+                                                          int g_stride) {
     __shared__ double sh[4];
-    const int fr = blockIdx.y;
+    const int fr = frames ? frames[blockIdx.y] : (int)blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int off = (L - 1) / 2;
-    const int S = T / n_sc;
     double pw = 0.0;
     if (t < T) {
         const int sym = t / n_sc, tl = t - sym * n_sc;
         const float2* xf = x + (size_t)fr * T;
-        const float2* gf = g + ((size_t)fr * S + sym) * L;
+        const float2* gf = g + (size_t)fr * g_stride + sym * L;
         float2 a = make_float2(0.f, 0.f);
         for (int l = 0; l < L; ++l) {
             const int r = tl + off - l;                     // position relative to the symbol start
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restri
     pw = wave_sum(pw);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[(size_t)fr * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 }  // namespace dccn

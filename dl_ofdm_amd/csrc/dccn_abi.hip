@@ -952,10 +952,10 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
     double* npartial = c.take<double>((size_t)frames * bx);
     float* mean_power = c.take<float>(4);
     hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
-                       n_taps, L, nfft, identity, offset, seed);
+                       n_taps, L, nfft, identity, offset, seed, (const int*)nullptr, n_taps, L, 1);
     DCCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(fir_same_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L);
+                       (float2*)y, partial, T, L, (const int*)nullptr, L);
     DCCN_LAUNCH_CHECK();
     const double total = (double)frames * (double)T;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
@@ -996,11 +996,78 @@ int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const floa
     double* npartial = c.take<double>((size_t)frames * bx);
     float* mean_power = c.take<float>(4);
     hipLaunchKernelGGL(doppler_taps_kernel, dim3(frames), dim3(64), 0, s, theta_in, coeff, alpha, (float2*)g, (float2*)H,
-                       n_taps, L, nfft, S, Fd, t_sym, offset, seed);
+                       n_taps, L, nfft, S, Fd, t_sym, offset, seed, (const int*)nullptr, n_taps, S * L);
     DCCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(fir_doppler_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, n_sc, n_taps);
+                       (float2*)y, partial, T, L, n_sc, n_taps, (const int*)nullptr, S * L);
     DCCN_LAUNCH_CHECK();
+    const double total = (double)frames * (double)T;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
+                       mean_power);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
+                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    if (noise_power) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
+                           noise_power);
+        DCCN_LAUNCH_CHECK();
+    }
+    return DCCN_OK;
+}
+
+size_t dccn_channel_groups_awgn_workspace_size(int frames, int T, int S) {
+    if (frames <= 0 || T <= 0 || S <= 0) return 0;
+    return dccn_channel_awgn_workspace_size(frames, T, 64 * S);
+}
+int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, int n_groups, const float* taps_in,
+                             const float* theta_in, float t_sym, int S, int n_sc, const float* snr_db,
+                             const float* noise_in, float* out, float* H, int nfft, float* noise_power, int frames,
+                             unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
+                             dccn_stream_t stream) {
+    if (!tx || !groups || n_groups <= 0 || !snr_db || !out || frames <= 0 || frames > 65535 || S <= 0 || S > 16 ||
+        n_sc <= 0 || (H && nfft <= 0))
+        return DCCN_ERR_INVALID_ARG;
+    const int T = S * n_sc;
+    int covered = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const dccn_channel_group& g = groups[i];
+        if (g.n_frames < 0 || (g.n_frames > 0 && !g.frames && n_groups > 1)) return DCCN_ERR_INVALID_ARG;
+        if (!g.identity && (!g.coeff || !g.alpha || g.n_taps <= 0 || g.n_taps > 16 || g.L <= 0 || g.L > 64))
+            return DCCN_ERR_INVALID_ARG;
+        covered += g.n_frames;
+    }
+    if (covered != frames) return DCCN_ERR_INVALID_ARG;        // every frame belongs to exactly one group
+    if (!workspace || workspace_bytes < dccn_channel_groups_awgn_workspace_size(frames, T, S)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    const int gstride = 64 * S;
+    float* g = c.take<float>((size_t)frames * gstride * 2);
+    float* y = c.take<float>((size_t)frames * T * 2);
+    const int bx = chan_blocks_x(T);
+    double* partial = c.take<double>((size_t)frames * bx);
+    double* npartial = c.take<double>((size_t)frames * bx);
+    float* mean_power = c.take<float>(4);
+    for (int i = 0; i < n_groups; ++i) {
+        const dccn_channel_group& q = groups[i];
+        if (q.n_frames == 0) continue;
+        if (q.identity || q.Fd <= 0.f) {
+            const int L = q.identity ? 1 : q.L;
+            hipLaunchKernelGGL(channel_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, taps_in, q.coeff, q.alpha, (float2*)g,
+                               (float2*)H, q.n_taps, L, nfft, q.identity, offset, seed, q.frames, 16, gstride, S);
+            DCCN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(fir_same_kernel, dim3(bx, q.n_frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                               (float2*)y, partial, T, L, q.frames, gstride);
+            DCCN_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(doppler_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, theta_in, q.coeff, q.alpha, (float2*)g,
+                               (float2*)H, q.n_taps, q.L, nfft, S, q.Fd, t_sym, offset, seed, q.frames, 16, gstride);
+            DCCN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(fir_doppler_kernel, dim3(bx, q.n_frames), dim3(256), 0, s, (const float2*)tx,
+                               (const float2*)g, (float2*)y, partial, T, q.L, n_sc, q.n_taps, q.frames, gstride);
+            DCCN_LAUNCH_CHECK();
+        }
+    }
     const double total = (double)frames * (double)T;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
                        mean_power);

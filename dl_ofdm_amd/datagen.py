@@ -10,9 +10,11 @@ generator"): same constellation tables, grid layout, ifft + cyclic prefix (as on
 Mersenne Twister, so agreement with the host path is exact for the deterministic stages (given the same
 bits / tap draws / noise draws -- tests/test_gpu_datagen.py) and statistical for the draws themselves.
 
-Scope: the single-profile channels of the reference's drivers ('AWGN', 'Flat', 'EPA', 'EVA', 'ETU', 'Custom'),
-static or mobile (Jakes Doppler, radio.py:376-407: per-symbol taps, per-symbol FIR with n_taps samples of history).
-The frame-interleaved 'mix*' channels stay on the host path.
+Scope: every channel of ``rayleigh_chan_lte``: the single-profile ones ('AWGN', 'Flat', 'EPA', 'EVA', 'ETU',
+'Custom'), static or mobile (Jakes Doppler, radio.py:376-407: per-symbol taps, per-symbol FIR with n_taps samples
+of history), and the frame-interleaved 'mixRayleigh' / 'mixAll' (radio.py:438-470: profile = frame index modulo 4
+or 5, Doppler on every 3rd / 4th frame when ``mix``) -- those run one launch pair per (profile, static|Doppler)
+group over a frame-index list.
 """
 from __future__ import annotations
 
@@ -27,16 +29,15 @@ from ._lib import check
 
 
 class DeviceDataGen:
-    def __init__(self, FLAGS, ofdmobj=None, device="cuda", seed: int = 1, mobile: bool = False):
+    def __init__(self, FLAGS, ofdmobj=None, device="cuda", seed: int = 1, mobile: bool = False, mix: bool = False):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DccnError("DeviceDataGen needs a CUDA (ROCm) device; use ofdm.py/radio.py on the host")
         self.FLAGS, self.o = FLAGS, ofdmobj or ofdm.ofdm_tx(FLAGS)
         chan = FLAGS.channel.lower()
-        if chan in ("mixrayleigh", "mixall"):
-            raise NotImplementedError("device generator covers single-profile channels; "
-                                      "use radio.rayleigh_chan_lte for the frame-interleaved mix channels")
+        self.mixed = chan in ("mixrayleigh", "mixall")
+        self.mix = bool(mix)
         o = self.o
         self.S, self.K, self.CP, self.D, self.nbits = o.nSymbol, o.K, o.CP, o.frame_size, int(FLAGS.nbits)
         self.n_sc, self.T = o.K + o.CP, o.nSymbol * (o.K + o.CP)
@@ -51,7 +52,19 @@ class DeviceDataGen:
         self.pilot = complex(o.pilotValue)
         self.idft = torch.from_numpy(self.idft_cp_matrix(self.K, self.CP)).to(dev)
         self.identity = chan == "awgn"
-        prof = radio._Profile(chan, bool(mobile), radio._alpha_matrices())
+        if self.mixed:                                               # radio.py:438-446 profile rotation
+            names = ("flat", "etu", "eva", "epa") if chan == "mixrayleigh" else ("awgn", "flat", "etu", "eva", "epa")
+            alphas = radio._alpha_matrices()
+            self.period = 3 if chan == "mixrayleigh" else 4
+            self.profiles = []
+            for nm in names:
+                pr = radio._Profile(nm, bool(mobile), alphas)
+                self.profiles.append(dict(identity=(nm == "awgn"), Fd=float(pr.Fd), n_taps=int(pr.n_taps),
+                                          L=int(pr.alpha.shape[1]),
+                                          coeff=torch.from_numpy(np.asarray(pr.ch_coeff, dtype=np.float32)).to(dev),
+                                          alpha=torch.from_numpy(np.ascontiguousarray(pr.alpha, dtype=np.float32)).to(dev)))
+            self._groups = {}
+        prof = radio._Profile("flat" if self.mixed else chan, bool(mobile), radio._alpha_matrices())
         self.Fd = float(prof.Fd)
         self.doppler = (not self.identity) and self.Fd > 0.1          # radio.py: `doppler = prof.Fd > 0.1`
         self.t_sym = float(self.n_sc) / float(o.Fs)
@@ -80,7 +93,8 @@ class DeviceDataGen:
     def _workspace(self, n: int):
         if n not in self._ws:
             f32 = dict(dtype=torch.float32, device=self.device)
-            nws = self.lib.dccn_channel_doppler_awgn_workspace_size(n, self.T, self.L, self.S)
+            nws = max(self.lib.dccn_channel_doppler_awgn_workspace_size(n, self.T, self.L, self.S),
+                      self.lib.dccn_channel_groups_awgn_workspace_size(n, self.T, self.S) if self.mixed else 0)
             self._ws[n] = dict(grid=torch.empty(n, self.S, self.K, 2, **f32), tx=torch.empty(n, self.S, self.n_sc, 2, **f32),
                                ws=torch.empty(nws, dtype=torch.uint8, device=self.device), nws=nws,
                                snr=torch.empty(n, **f32), npow=torch.zeros(1, **f32))
@@ -123,12 +137,25 @@ class DeviceDataGen:
             w["snr"].copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)))
         if out_x is None:
             out_x = torch.empty(n, self.S, self.n_sc, 2, dtype=torch.float32, device=self.device)
-        hshape = (n, self.S, self.K, 2) if self.doppler else (n, self.K, 2)
+        hshape = (n, self.S, self.K, 2) if (self.doppler or self.mixed) else (n, self.K, 2)
         H = torch.empty(*hshape, dtype=torch.float32, device=self.device) if want_H else None
-        if taps is not None:
+        if taps is not None and not self.mixed:
             taps = torch.as_tensor(taps, dtype=torch.float32).to(self.device).contiguous()
         if noise is not None:
             noise = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()
+        if self.mixed:
+            # taps: (normals [n,16,2] for the static frames, phases [n,2,48,16] for the Doppler frames), or None
+            tn, th = (None, None) if taps is None else taps
+            if tn is not None:
+                tn = torch.as_tensor(tn, dtype=torch.float32).to(self.device).contiguous()
+            if th is not None:
+                th = torch.as_tensor(th, dtype=torch.float32).to(self.device).contiguous()
+            arr, keep = self._frame_groups(n)
+            check(self.lib.dccn_channel_groups_awgn(self._p(tx), arr, len(arr), self._p(tn), self._p(th), self.t_sym,
+                                                    self.S, self.n_sc, self._p(w["snr"]), self._p(noise), self._p(out_x),
+                                                    self._p(H), self.K, self._p(w["npow"]), n, self.seed, off,
+                                                    self._p(w["ws"]), w["nws"], self._stream()), "dccn_channel_groups_awgn")
+            return out_x, w["npow"], (torch.view_as_complex(H) if want_H else None)
         if self.doppler:
             check(self.lib.dccn_channel_doppler_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
                                                      self.n_taps, self.L, self.Fd, self.t_sym, self.S, self.n_sc,
@@ -142,6 +169,33 @@ class DeviceDataGen:
                                          self.T, self.seed, off, self._p(w["ws"]), w["nws"], self._stream()),
               "dccn_channel_awgn")
         return out_x, w["npow"], (torch.view_as_complex(H) if want_H else None)
+
+    def frame_plan(self, n: int):
+        """per frame (profile index, doppler?) exactly as radio.py:438-452 decides it"""
+        n_prof = len(self.profiles)
+        plan = []
+        for fr in range(n):
+            pi = fr % n_prof
+            pr = self.profiles[pi]
+            dop = (fr % self.period == 0) and pr["Fd"] > 0.1 and self.mix and not pr["identity"]
+            plan.append((pi, bool(dop)))
+        return plan
+
+    def _frame_groups(self, n: int):
+        if n not in self._groups:
+            from ._lib import ChannelGroup
+            plan = self.frame_plan(n)
+            keys = sorted(set(plan))
+            arr = (ChannelGroup * len(keys))()
+            keep = []
+            for i, (pi, dop) in enumerate(keys):
+                ids = torch.as_tensor(np.asarray([f for f, k in enumerate(plan) if k == (pi, dop)], dtype=np.int32)).to(self.device)
+                pr = self.profiles[pi]
+                keep.append(ids)
+                arr[i] = ChannelGroup(ids.data_ptr(), int(ids.numel()), pr["coeff"].data_ptr(), pr["alpha"].data_ptr(),
+                                      pr["n_taps"], pr["L"], 1 if pr["identity"] else 0, pr["Fd"] if dop else 0.0)
+            self._groups[n] = (arr, keep)
+        return self._groups[n]
 
     def make_batch(self, n_frames: int, snr_db, out_x: Optional[torch.Tensor] = None,
                    out_bits: Optional[torch.Tensor] = None, want_H: bool = False):

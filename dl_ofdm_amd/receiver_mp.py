@@ -72,7 +72,7 @@ class Flags:
     snr_lo: int = -10
     snr_hi: int = 30
     snr_step: int = 5               # :81
-    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py); single-profile channels
+    device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py)
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 
@@ -204,7 +204,7 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
     fading1 = RayleighChanParallel(FLAGS, ofdmobj.Fs, mobile=True, mix=True) if FLAGS.mobile else None
     phase2 = True                                                      # :393
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
-    on_device = bool(FLAGS.device_data) and trainer.fused_ok and not FLAGS.channel.lower().startswith("mix")
+    on_device = bool(FLAGS.device_data) and trainer.fused_ok
     if on_device:
         return _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, run_test)
     for epoch in range(FLAGS.max_epoch_num):
@@ -250,7 +250,8 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     plan's buffers; per-step scalars are accumulated on the device and fetched once per epoch."""
     import torch
     from .datagen import DeviceDataGen
-    gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed, mobile=FLAGS.mobile)
+    # :389-392,409: fading0 (static) unless --mobile, then the mixed-Doppler simulator (mobile=True, mix=True)
+    gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed, mobile=FLAGS.mobile, mix=FLAGS.mobile)
     pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
     mview = pl.metrics_buf.view(torch.float32)                      # dccn_metrics: [12] ce_mean, [13] berlin
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []

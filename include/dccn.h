@@ -354,6 +354,26 @@ int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const floa
                               unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
                               dccn_stream_t stream);
 
+/* Frame-interleaved channels (dev/py/radio.py:438-470 'mixRayleigh' / 'mixAll'): every frame belongs to one group =
+ * (profile, static | Doppler); a group lists its frame indices.  taps_in [frames,16,2] / theta_in [frames,2,48,16]
+ * (padded to 16 taps; the Philox tap index also uses stride 16 here), H [frames,S,nfft,2] (static frames repeat
+ * their response per symbol, as the reference does).  Fd > 0 selects the Doppler model for the group. */
+typedef struct dccn_channel_group {
+    const int* frames;      /* device int32[n_frames] */
+    int n_frames;
+    const float* coeff;     /* device [n_taps] */
+    const float* alpha;     /* device [n_taps, L] */
+    int n_taps, L;
+    int identity;           /* pass-through slot ('mixAll' frame % 5 == 0) */
+    float Fd;               /* maximum Doppler [Hz]; 0 = static taps */
+} dccn_channel_group;
+size_t dccn_channel_groups_awgn_workspace_size(int frames, int T, int S);
+int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups /* host array */, int n_groups,
+                             const float* taps_in, const float* theta_in, float t_sym, int S, int n_sc,
+                             const float* snr_db, const float* noise_in, float* out, float* H, int nfft,
+                             float* noise_power, int frames, unsigned long long seed, unsigned offset,
+                             void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 /* ==== host utility: CRC32C (Castagnoli), the checksum of TensorFlow's tensor-bundle checkpoints =========
  * (tf.train.Saver files the reference writes at dev/py/ofdmreceiver_np.py:271).
  * Returns the CRC of (previous data ++ data) given the CRC of the previous data (0 to start).  Host code. */

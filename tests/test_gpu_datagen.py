@@ -147,12 +147,47 @@ def test_awgn_ber_closed_form_with_device_generated_data(nbits, snr_db):
     assert abs(m["berlin"] - theory) <= tol, (m["berlin"], theory)
 
 
-def test_unsupported_channels_raise():
+@pytest.mark.parametrize("chan,mobile,mix", [("mixRayleigh", False, False), ("mixRayleigh", True, True),
+                                             ("mixAll", True, True), ("mixAll", False, False)])
+def test_mix_channels_match_host_given_the_same_draws(chan, mobile, mix):
+    """frame-interleaved profiles (radio.py:438-470): profile = frame % 4 (or 5), Doppler every 3rd (4th) frame"""
+    from dl_ofdm_amd import ofdm, radio, util
     from dl_ofdm_amd.datagen import DeviceDataGen
-    with pytest.raises(NotImplementedError):
-        DeviceDataGen(flags(channel="mixRayleigh"))
-    with pytest.raises(NotImplementedError):
-        DeviceDataGen(flags(channel="mixAll"))
+    F = flags(channel=chan)
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=13, mobile=mobile, mix=mix)
+    n = 27
+    np.random.seed(8)
+    bits = util.bit_source(2, o.frame_size, n)
+    iq, _, _ = o.ofdm_tx_frame_np(bits)
+    fading = radio.rayleigh_chan_lte(F, o.Fs, mobile=mobile, mix=mix)
+    snr = np.linspace(2, 22, n).reshape(n, 1)
+    np.random.seed(99)
+    y_host, H_host = fading.run(iq)
+    out_host, npow_host = radio.AWGN_channel_np(y_host, snr)
+    np.random.seed(99)                                              # replay numpy's draws frame by frame
+    tn = np.zeros((n, 16, 2), np.float32)
+    th = np.zeros((n, 2, 48, 16), np.float32)
+    plan = gen.frame_plan(n)
+    assert any(d for _, d in plan) == (mobile and mix)
+    for fr, (pi, dop) in enumerate(plan):
+        pr = gen.profiles[pi]
+        if pr["identity"]:
+            continue
+        if dop:
+            for c in range(2):
+                th[fr, c, :, :pr["n_taps"]] = np.random.uniform(0, 2 * np.pi, size=(48, pr["n_taps"]))
+        else:
+            tn[fr, :pr["n_taps"]] = np.random.normal(loc=0.0, scale=1.0, size=[pr["n_taps"], 2])
+    noise = np.random.randn(n, 7, 80, 2)
+    tx, _ = gen.transmit(n, bits=bits)
+    out, npow, H = gen.channel(tx, snr, taps=(tn, th), noise=noise.reshape(n, -1, 2), want_H=True)
+    assert np.abs(out.cpu().numpy() - out_host).max() <= 5e-5 * np.abs(out_host).max()
+    assert abs(float(npow) - npow_host) <= 1e-5 * npow_host
+    assert H.shape == (n, 7, 64) and np.abs(H.cpu().numpy() - H_host).max() <= 5e-5 * max(np.abs(H_host).max(), 1.0)
+    # drawn path: finite, unit output power + noise, different profiles give different responses
+    x, b, npw, Hd = gen.make_batch(400, 15.0, want_H=True)
+    assert torch.isfinite(x).all() and abs(float((x ** 2).sum(-1).mean()) - (1 + 10 ** -1.5)) < 0.05
 
 
 @pytest.mark.parametrize("chan", ["ETU", "EVA", "EPA", "Flat", "Custom"])
