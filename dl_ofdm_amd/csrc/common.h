@@ -99,30 +99,4 @@ __device__ __forceinline__ long long wave_sum(long long v) {
     return r;
 }
 
-// ---- "last block finalizes" hand-off (guide section 6, Guideline 16, counter form) -----------
-// Every block publishes its partial results with plain stores, then calls this.  Exactly one
-// block -- the last to arrive -- gets `true`, with every other block's stores visible to it
-// (agent-scope release on the producers, agent-scope acquire on the consumer; placement
-// independent).  The counter must be zero at kernel start (the launch sequence memsets its
-// counter words); the last block re-zeroes it, so back-to-back replays stay consistent.
-__device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned expected) {
-    __shared__ int s_is_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left the CU
-    __syncthreads();
-    const bool leader = (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0);
-    if (leader) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (prev == expected - 1u);
-        if (last) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        s_is_last = last;
-    }
-    __syncthreads();
-    return s_is_last != 0;
-}
-
 }  // namespace dccn
