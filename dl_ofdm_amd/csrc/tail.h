@@ -15,7 +15,7 @@
 namespace dccn {
 
 constexpr float kLeaky = 0.2f;
-constexpr int kTailBlocks = 256;      // one block per CU (two per CU measured 7 % slower: the reduction tail doubles)
+constexpr int kTailBlocks = 256;      // one block per CU (two per CU measured no better for nbits<=2 and worse for nbits>=3: 256 VGPRs)
 constexpr int kTailThreads = 256;
 
 __host__ __device__ constexpr int tail_param_count(int nb) {
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     constexpr int O = 2 * NB;
     constexpr int P = tail_param_count(NB);
     constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
-    __shared__ float sred[BWD ? 4 * P : 1];
+    constexpr int PS = P | 1;                                  // odd row stride: column reads spread over the banks
+    __shared__ float smat[BWD ? 64 * PS : 1];                  // [quad][param] partial gradient sums
     __shared__ double sce[4];
     __shared__ int sconf[4][4];
 
@@ -167,10 +168,15 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
         sconf[wid][0] = c00; sconf[wid][1] = c01; sconf[wid][2] = c10; sconf[wid][3] = c11;
     }
     if constexpr (BWD) {
+        // gradients: sum over the 4 lanes of a quad on the DPP crossbar (2 adds per value instead of a full wave
+        // reduction per value), park the 64 quad sums per parameter in LDS ...
+        const int quad = threadIdx.x >> 2;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const float s = wave_sum(gacc[i]);
-            if (lane == 0) sred[wid * P + i] = s;
+            float v = gacc[i];
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+            if ((lane & 3) == 0) smat[quad * PS + i] = v;
         }
     }
     __syncthreads();
@@ -182,8 +188,18 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
         blk_metrics[blockIdx.x] = bm;
     }
     if constexpr (BWD) {
-        for (int i = threadIdx.x; i < P; i += kTailThreads)
-            blk_grads[(size_t)blockIdx.x * P + i] = (sred[i] + sred[P + i]) + (sred[2 * P + i] + sred[3 * P + i]);
+        // ... then 4 threads per parameter column add 16 quad sums each (fixed order) and combine on the crossbar
+        const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
+        for (int col0 = 0; col0 < P; col0 += 64) {
+            const int col = col0 + slot;
+            const int cc = col < P ? col : P - 1;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += smat[(part * 16 + r) * PS + cc];
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+            if (part == 0 && col < P) blk_grads[(size_t)blockIdx.x * P + col] = v;
+        }
     }
 }
 
