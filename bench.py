@@ -51,10 +51,28 @@ def step_flops(c):
     return c["frames"] * (2 * L1 + 3 * (L2 + L3 + L4))
 
 
+def effective_cpus():
+    """CPUs this process may really use: affinity mask and cgroup v2 quota (a container can expose 128 cores while
+    granting 16 CPUs of run time; running 128 threads on those only thrashes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(c, budget_s=20.0):
     """Time the literal torch-CPU restatement of the reference graph (oracle; checker only) on the host."""
     import numpy as np
     import torch
+    torch.set_num_threads(effective_cpus())
     from oracle import dccn_oracle as O
     from oracle.torch_ref import LiteralRx
     S, kin = 7, c["nfft"] + c["cp"]
