@@ -282,8 +282,15 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __res
     for (int p = 0; p < RPT; ++p) {
         const int r = slot + 128 * p;
         if (live && r < batch) {
-            float o[4] = {(v[p].x * inv[0] + sh[0]) / rs2, (v[p].y * inv[1] + sh[1]) / rs2,
-                          (v[p].z * inv[2] + sh[2]) / rs2, (v[p].w * inv[3] + sh[3]) / rs2};
+            // t / sqrt(2) as q = t*r, then one FMA residual correction (q + fma(-q, c, t)*r): the correctly rounded
+            // quotient for a constant divisor at a third of the instructions of the generic IEEE division sequence
+            auto div_rs2 = [&](float t) {
+                const float r = 0.70710678118654752440f;
+                const float q = t * r;
+                return __builtin_fmaf(__builtin_fmaf(-q, rs2, t), r, q);
+            };
+            float o[4] = {div_rs2(v[p].x * inv[0] + sh[0]), div_rs2(v[p].y * inv[1] + sh[1]),
+                          div_rs2(v[p].z * inv[2] + sh[2]), div_rs2(v[p].w * inv[3] + sh[3])};
             *reinterpret_cast<float4*>(y + (size_t)r * cols + c4) = make_float4(o[0], o[1], o[2], o[3]);
             if (power_partial != nullptr) {
 #pragma unroll

@@ -136,8 +136,10 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
                 float s = 0.f;
 #pragma unroll
                 for (int o = 0; o < O; ++o) {
-                    gacc[oW2 + i * O + o] += c[i] * dpre2[o];
-                    s += dpre2[o] * sw[oW2 + i * O + o];
+                    // backward-only sums use fused multiply-adds (one rounding, half the VALU instructions); the
+                    // forward stays unfused so that training and evaluation produce identical probabilities
+                    gacc[oW2 + i * O + o] = __builtin_fmaf(c[i], dpre2[o], gacc[oW2 + i * O + o]);
+                    s = __builtin_fmaf(dpre2[o], sw[oW2 + i * O + o], s);
                 }
                 dc[i] = s;
             }
@@ -147,11 +149,11 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const float dp = dc[j] * (pre1[j] > 0.f ? 1.f : kLeaky);
-                gacc[oW1 + j] += z0 * dp;
-                gacc[oW1 + M + j] += z1 * dp;
+                gacc[oW1 + j] = __builtin_fmaf(z0, dp, gacc[oW1 + j]);
+                gacc[oW1 + M + j] = __builtin_fmaf(z1, dp, gacc[oW1 + M + j]);
                 gacc[oB1 + j] += dp;
-                d0 += dp * sw[oW1 + j];
-                d1 += dp * sw[oW1 + M + j];
+                d0 = __builtin_fmaf(dp, sw[oW1 + j], d0);
+                d1 = __builtin_fmaf(dp, sw[oW1 + M + j], d1);
             }
             *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
         }
