@@ -271,8 +271,27 @@ __global__ __launch_bounds__(256) void cconv_fold_finalize_kernel(const float* _
     }
 }
 
+// the split-K C-Conv weight-gradient GEMM with the tail's slab reduction riding on extra blocks of the same launch
+template <bool VEC>
+__global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_finalize_kernel(const GemmParams p, int tiles, int gemm_blocks,
+                                                                            TailFinalizeArgs a) {
+    const int b = (int)blockIdx.x;
+    if (b < gemm_blocks) {
+        gemm_block<OP_ICONTIG, OP_ICONTIG, 64, 64, 64, 1, VEC>(p, b % tiles, tiles, b / tiles);
+    } else {
+        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
+                                 a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
+    }
+}
+
+struct FoldDefer {          // the fold left to the optimizer kernel (fused training step)
+    const float* slabs; const float* colsum;
+    int splits; long long slab;
+};
+
 static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
-                            void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin = nullptr) {
+                            void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin = nullptr,
+                            FoldDefer* defer = nullptr) {
     if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(2 * kin, 2 * F, rows)) return DCCN_ERR_WORKSPACE;
     const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
@@ -287,6 +306,25 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     p.slab = (long long)4 * kin * F;
     p.vecA = (kin % 2 == 0) && aligned16(x) && small_enough(rows, 2LL * kin);
     p.vecB = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);
+    if (defer && fin && p.vecA && p.vecB && (F % 2 == 0)) {
+        // fused step: GEMM + tail finalize in one launch; the fold happens inside the optimizer kernel
+        auto kern = cconv_bwd_w_finalize_kernel<true>;
+        constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 64>();
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (smem > 48 * 1024)
+                DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_done = true;
+        }
+        const int tiles = ceil_div(p.N, 64) * ceil_div(p.M, 64), gemm_blocks = tiles * sp.splits;
+        hipLaunchKernelGGL(kern, dim3(gemm_blocks + tail_finalize_blocks(fin->P)), dim3(kGemmThreads), smem, s, p, tiles,
+                           gemm_blocks, *fin);
+        DCCN_LAUNCH_CHECK();
+        defer->slabs = slabs; defer->colsum = cs; defer->splits = sp.splits; defer->slab = p.slab;
+        return DCCN_OK;
+    }
+    if (defer) defer->slabs = nullptr;
     DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     const int nthreads = kin * F + F;
     const int fold_blocks = ceil_div(nthreads, kRedLanes);
@@ -475,8 +513,11 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
+    FoldDefer fd;
+    fd.slabs = nullptr;
+    const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
     DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
-                              L.ws_conv_bw, s, &fin));
+                              L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     AdamRxArgs aa;
@@ -485,8 +526,14 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.state = b->adam; aa.n = L.total;
     aa.dw_slabs = ds.dw_slabs; aa.db_slabs = ds.db_slabs; aa.splits = ds.splits;
     aa.o_dw = L.o_dense_w; aa.n_dw = (long long)L.dK * L.dN; aa.o_db = L.o_dense_b; aa.n_db = L.dN;
-    long long blocks = ceil_div_ll(ceil_div_ll(L.total, 4), 256);
+    aa.cw_slabs = fd.slabs; aa.cw_colsum = fd.slabs ? fd.colsum : nullptr;
+    aa.cw_splits = fd.slabs ? fd.splits : 0; aa.cw_slab = fd.slabs ? fd.slab : 0;
+    aa.kin = sh->kin; aa.F = sh->F; aa.o_cw = L.o_conv_w;
+    aa.n_conv = L.o_dense_w;                      // C-Conv kernel + bias come first in the arena
+    aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, kRedLanes) : 0;
+    long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
     if (blocks > 8 * kCUs) blocks = 8 * kCUs;
+    blocks += aa.fold_blocks;
     switch (ds.splits) {
         case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         case 3: hipLaunchKernelGGL(adam_rx_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;

@@ -570,9 +570,13 @@ static int launch_splitk_reduce(const float* partial, int splits, long long slab
 //   dWb[n,f] = dWeff[2n,2f+1] - dWeff[2n+1,2f]
 //   dba[f] = sum_r(dRe - dIm) = cs[2f] - cs[2f+1],  dbb = -dba     
 // element index e in [0, kin*F) -> (n,f); e in [kin*F, kin*F+F) -> bias f
+// out2/gout (optional, per thread): the two element offsets (relative to dw; the bias follows the kernel) and
+// gradient values this thread produced, -1 when none -- lets a caller apply the optimizer update in the same pass
 __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partial, int splits, long long slab,
                                                 const float* __restrict__ colsum, float* __restrict__ dw,
-                                                float* __restrict__ dbias, int kin, int F, int block) {
+                                                float* __restrict__ dbias, int kin, int F, int block,
+                                                long long* out2 = nullptr, float* gout = nullptr) {
+    if (out2) { out2[0] = -1; out2[1] = -1; }
     __shared__ float2 red[kRedGroups][kRedLanes];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = block * kRedLanes + lane;
@@ -614,9 +618,11 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
         if (is_w) {
             dw[(size_t)n * N2 + f] = t.x;
             dw[(size_t)n * N2 + F + f] = t.y;
+            if (out2) { out2[0] = (long long)n * N2 + f; out2[1] = (long long)n * N2 + F + f; gout[0] = t.x; gout[1] = t.y; }
         } else if (is_b) {
             dbias[f] = t.x;
             dbias[F + f] = -t.x;
+            if (out2) { out2[0] = (long long)kin * N2 + f; out2[1] = (long long)kin * N2 + F + f; gout[0] = t.x; gout[1] = -t.x; }
         }
     }
 }

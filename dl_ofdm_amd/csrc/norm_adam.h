@@ -427,6 +427,11 @@ struct AdamRxArgs {
     const float* dw_slabs; const float* db_slabs;
     int splits;
     long long o_dw, n_dw, o_db, n_db;      // arena segments of dense kernel / bias
+    // C-Conv weight gradient still in split-K slabs of dWeff (fold_blocks > 0): the first fold_blocks blocks fold
+    // them (cconv_fold_body) and update those parameters; the other blocks start at element n_conv
+    const float* cw_slabs; const float* cw_colsum;
+    int cw_splits, kin, F, fold_blocks;
+    long long cw_slab, o_cw, n_conv;       // o_cw: arena offset of the C-Conv kernel (its bias follows)
 };
 
 template <int SPLITS>     // 0: runtime count
@@ -436,8 +441,29 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
     const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
     const bool seg4 = ((a.o_dw | a.n_dw | a.o_db | a.n_db) & 3) == 0;
     const int splits = SPLITS > 0 ? SPLITS : a.splits;
-    const long long stride = (long long)gridDim.x * blockDim.x * 4;
-    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < a.n; i += stride) {
+    if ((int)blockIdx.x < a.fold_blocks) {
+        // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here
+        long long idx[2];
+        float gv[2];
+        cconv_fold_body(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
+                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, (int)blockIdx.x, idx, gv);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (idx[e] < 0) continue;
+            const long long j = a.o_cw + idx[e];
+            float p = a.param[j], mm = a.m[j], vv = a.v[j];
+            const float ge = gv[e] + (gate * (a.reg_coef ? a.reg_coef[j] : 0.f)) * p;
+            mm += (ge - mm) * omb1;
+            vv += (ge * ge - vv) * omb2;
+            p -= (mm * alpha) / (sqrtf(vv) + hp.eps);
+            a.param[j] = p; a.m[j] = mm; a.v[j] = vv;
+        }
+        return;
+    }
+    const long long first = a.fold_blocks > 0 ? a.n_conv : 0;
+    const long long stride = (long long)(gridDim.x - a.fold_blocks) * blockDim.x * 4;
+    for (long long i = first + ((long long)((int)blockIdx.x - a.fold_blocks) * blockDim.x + threadIdx.x) * 4; i < a.n;
+         i += stride) {
         const int cnt = (int)((a.n - i) < 4 ? (a.n - i) : 4);
         float g[4] = {0.f, 0.f, 0.f, 0.f}, p[4], mm[4], vv[4], cc[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = cnt == 4;
