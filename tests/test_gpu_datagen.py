@@ -236,3 +236,28 @@ def test_harness_trains_on_device_generated_data(tmp_path):
     assert h[-1]["test_ber"] < 0.2, h
     snrs, ber, loss, csv = res["sweep"]
     assert ber[-1] < ber[0] and len(snrs) == 11
+
+
+@pytest.mark.parametrize("nfft,longcp", [(1024, False), (128, True)])
+def test_transmitter_and_awgn_at_other_fft_sizes(nfft, longcp):
+    """config-4 geometry (N=1024, CP=72) and N=128: grid tables, IDFT+CP GEMM and the AWGN stage vs the host chain"""
+    from dl_ofdm_amd import ofdm, radio
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(channel="AWGN", nfft=nfft, longcp=longcp, nfilter=nfft)
+    o = ofdm.ofdm_tx(F)
+    gen = DeviceDataGen(F, o, seed=5)
+    rng = np.random.RandomState(nfft)
+    n = 6
+    bits = rng.randint(0, 2, (n, o.frame_size, 2))
+    iq, want, _ = o.ofdm_tx_frame_np(bits)
+    tx, _ = gen.transmit(n, bits=bits)
+    assert tx.shape == want.shape and np.abs(tx.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    np.random.seed(3)
+    y_host, H_host = radio.rayleigh_chan_lte(F, o.Fs).run(iq)
+    out_host, npow_host = radio.AWGN_channel_np(y_host, 7.0 * np.ones((n, 1)))
+    np.random.seed(3)
+    noise = np.random.randn(*want.shape)
+    out, npow, H = gen.channel(tx, 7.0, noise=noise.reshape(n, -1, 2), want_H=True)
+    assert np.abs(out.cpu().numpy() - out_host).max() <= 3e-5 * np.abs(out_host).max()
+    assert abs(float(npow) - npow_host) <= 1e-5 * npow_host
+    assert np.abs(H.cpu().numpy() - H_host[:, 0, :]).max() <= 1e-5

@@ -427,3 +427,24 @@ def test_fused_step_without_cp_matches_oracle():
         cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
         assert cos >= 1 - 1e-6, (n, cos)
         assert np.abs(got - want).max() <= 3e-4 * np.abs(want).max(), n
+
+
+def test_equalizer_forward_at_nfft_128():
+    """the stage is not tied to N=64: K=128 (7x128 smoothing kernel -> a 1792x1792 Toeplitz layer) vs the oracle"""
+    from dl_ofdm_amd.complex import VariableStore
+    from dl_ofdm_amd.model import equalizer_ofdm
+    from dl_ofdm_amd.ofdm import ofdm_tx
+    F = _Flags()
+    F.nfft, F.nfilter = 128, 128
+    tx = ofdm_tx(F)
+    st = VariableStore(seed=6)
+    x = torch.randn(3, 7, tx.K + tx.CP, 2, device="cuda") * 1.3
+    with st.scope("Equalizer"):
+        out, snr, chest = equalizer_ofdm(x, F, tx, scope=st)
+    c = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=True, pilot_size=tx.pilot_size,
+                   pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
+    p = {n: st.tensor(n).detach().cpu().numpy().astype(np.float64).reshape(s) for n, s in E.param_shapes(c).items()}
+    o_out, o_snr, o_h = E.equalizer_forward(p, x.cpu().numpy().astype(np.float64), c)
+    close(out, o_out, 5e-5, "equalized (N=128)")
+    close(torch.view_as_real(chest), o_h, 5e-5, "chest (N=128)")
+    close(snr, o_snr, 2e-4, "snr (N=128)")
