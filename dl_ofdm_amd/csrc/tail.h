@@ -60,7 +60,17 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     __shared__ double sce[4];
     __shared__ int sconf[4][4];
 
-    const float* __restrict__ sw = tailp;   // uniform addresses -> scalar (SGPR) loads
+    // nbits <= 2: the <= 40 weights are read through uniform addresses -> scalar (SGPR) loads.  nbits >= 3: 90 / 200
+    // weights do not fit the SGPR file (the compiler spilled hundreds of them into VGPR lanes); they are staged in
+    // LDS once and re-read each cell as broadcast loads (the per-iteration compiler barrier keeps them from being
+    // hoisted into 200 live VGPRs).
+    constexpr bool LDSW = NB >= 3;
+    __shared__ float swl[LDSW ? P : 1];
+    if constexpr (LDSW) {
+        for (int i = threadIdx.x; i < P; i += kTailThreads) swl[i] = tailp[i];
+        __syncthreads();
+    }
+    const float* __restrict__ sw = LDSW ? swl : tailp;
 
     float gacc[BWD ? P : 1];
     if constexpr (BWD) {
@@ -75,6 +85,7 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     long long cell = (long long)blockIdx.x * kTailThreads + threadIdx.x;
     TailCellIn<NB> cur = tail_load_cell<NB>(z, bits, cell, cells);
     while (cell < cells) {
+        if constexpr (LDSW) asm volatile("" ::: "memory");
         const TailCellIn<NB> nxt = tail_load_cell<NB>(z, bits, cell + stride, cells);     // prefetch
         const float z0 = cur.z.x, z1 = cur.z.y;
         float c[M + 2], pre1[M];
