@@ -127,8 +127,11 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
             const float lse = logf(fs) + mx2;
             ce_acc += (double)(lse - (label ? p1 : p0));
             const int pred = (p1 > p0) ? 1 : 0;          // argmax, first index on ties
-            if (label == 0) { if (pred == 0) ++c00; else ++c01; }
-            else            { if (pred == 0) ++c10; else ++c11; }
+            const int l1 = label != 0 ? 1 : 0;           // branch-free tallies (divergent ifs cost exec-mask regions)
+            c00 += (1 - l1) & (1 - pred);
+            c01 += (1 - l1) & pred;
+            c10 += l1 & (1 - pred);
+            c11 += l1 & pred;
             if constexpr (BWD) {
                 const float rfs = 1.0f / fs;
                 const float q0 = f0 * rfs, q1 = f1 * rfs;
