@@ -486,6 +486,12 @@ template <int KA, int KB, int COLSUM, int TAG>
 static int launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * splits;
     if (big >= 2 * kCUs) return launch_gemm_cfg<KA, KB, 128, 128, 32, COLSUM, TAG>(p, splits, s);
+    // short k ranges that are a multiple of 32 but not of 64 (the C-Conv: K = 2*(N+CP) = 160): 32-deep k-tiles keep
+    // every tile on the fast unmasked loaders and do not multiply zeros in a half-empty last tile
+    if constexpr (KA != OP_ICONTIG && KB != OP_ICONTIG) {
+        if (splits == 1 && p.K % 64 != 0 && p.K % 32 == 0 && p.K <= 512)
+            return launch_gemm_cfg<KA, KB, 64, 64, 32, COLSUM, TAG>(p, splits, s);
+    }
     return launch_gemm_cfg<KA, KB, 64, 64, 64, COLSUM, TAG>(p, splits, s);
 }
 
