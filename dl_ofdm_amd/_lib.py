@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCCN_LIB_PATH") or os.path.join(_HERE, "lib", "libdccn.so")     # override: kernel experiments

@@ -18,7 +18,6 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as Fnn
 
 from . import ops
 

@@ -16,8 +16,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamHParams, AdamState, RxBuffers, RxShape, check
-from .ops import read_metrics, tail_param_count
+from ._lib import AdamHParams, RxBuffers, RxShape, check
+from .ops import read_metrics
 
 # checkpoint variable names -> (arena segment, live shape)
 PARAM_NAMES = ("fft_like/conv3d/kernel", "fft_like/conv3d/bias",

@@ -1,6 +1,6 @@
 """Diagnostic: us/step of the captured training step over time (500 replays per sample).
    python tools/clock_ramp.py [samples] [prob(0/1)] [devrand(0/1)]"""
-import sys, os, time, torch
+import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl_ofdm_amd.engine import RxEngine, RxDims, HipTimer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
