@@ -15,7 +15,7 @@ from collections import defaultdict
 OP_OF_KERNEL = [  # kernel-name substring -> bench.py operator key (C2 shapes)
     ("dense_bwd_grouped_kernel", "dense_bwd_slabs"),
     ("gemm_f32_mfma_kernel<1, 0,", "dense_fwd"),
-    ("gemm_f32_mfma_kernel<1, 2,", "cconv_fwd"),
+    ("gemm_f32_mfma_kernel<1, 2,", "cconv_fwd"),        # any tile configuration of the C-Conv forward
     ("gemm_f32_mfma_kernel<0, 0,", "cconv_bwd_w"),
     ("cconv_bwd_w_finalize_kernel", "cconv_bwd_w"),
 ]
