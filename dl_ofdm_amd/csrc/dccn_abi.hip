@@ -341,16 +341,18 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
 // ---------------------------------------------------------------------------------------
 // tail
 // ---------------------------------------------------------------------------------------
-static int tail_blocks(long long cells) {
-    long long b = ceil_div_ll(cells, kTailThreads);
-    if (b > kTailBlocks) b = kTailBlocks;
+static int tail_blocks(long long cells, bool quad4 = false) {
+    // quad4 (nbits = 4 training): four lanes per cell, 194 VGPRs -> two blocks per CU
+    long long b = ceil_div_ll(quad4 ? 4 * cells : cells, kTailThreads);
+    const long long cap = quad4 ? kTailBlocksMax : kTailBlocks;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
 static size_t tail_ws_bytes(long long cells, int nbits) {
     size_t o = 0;
-    o = carve_size(o, (size_t)kTailBlocks * sizeof(TailBlockMetrics));
-    o = carve_size(o, (size_t)kTailBlocks * tail_param_count(nbits) * sizeof(float));
+    o = carve_size(o, (size_t)kTailBlocksMax * sizeof(TailBlockMetrics));
+    o = carve_size(o, (size_t)kTailBlocksMax * tail_param_count(nbits) * sizeof(float));
     (void)cells;
     return align_up(o, 256);
 }
@@ -379,15 +381,28 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < tail_ws_bytes(cells, nbits)) return DCCN_ERR_WORKSPACE;
     Carver c(ws, ws_bytes);
-    TailBlockMetrics* bm = c.take<TailBlockMetrics>(kTailBlocks);
-    float* bg = c.take<float>((size_t)kTailBlocks * tail_param_count(nbits));
-    const int nblk = tail_blocks(cells);
+    TailBlockMetrics* bm = c.take<TailBlockMetrics>(kTailBlocksMax);
+    float* bg = c.take<float>((size_t)kTailBlocksMax * tail_param_count(nbits));
+    const int nblk = tail_blocks(cells, bwd && nbits == 4);
     int st = DCCN_ERR_INVALID_ARG;
     switch (nbits) {
         case 1: st = tail_launch<1>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
         case 2: st = tail_launch<2>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
         case 3: st = tail_launch<3>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
-        case 4: st = tail_launch<4>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s); break;
+        case 4:
+            if (bwd) {                                   // four lanes per cell (tail.h): 50 accumulators per lane, not 200
+                if (prob)
+                    hipLaunchKernelGGL(demod_tail_quad4_kernel<true>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp,
+                                       prob, dz, cells, bm, bg);
+                else
+                    hipLaunchKernelGGL(demod_tail_quad4_kernel<false>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits,
+                                       tailp, prob, dz, cells, bm, bg);
+                DCCN_LAUNCH_CHECK();
+                st = DCCN_OK;
+            } else {
+                st = tail_launch<4>(bwd, z, bits, tailp, prob, dz, cells, nblk, bm, bg, s);
+            }
+            break;
     }
     DCCN_TRY(st);
     const int P = bwd ? tail_param_count(nbits) : 0;

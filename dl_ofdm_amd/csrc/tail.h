@@ -15,6 +15,7 @@
 namespace dccn {
 
 constexpr float kLeaky = 0.2f;
+constexpr int kTailBlocksMax = 512;   // slab capacity of the workspace / finalize stage
 constexpr int kTailBlocks = 256;      // one block per CU (two per CU measured no better for nbits<=2 and worse for nbits>=3: 256 VGPRs)
 constexpr int kTailThreads = 256;
 
@@ -219,6 +220,161 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     }
 }
 
+// ---- nbits = 4 training: four lanes per cell ------------------------------------------------------------
+// One thread per cell needs 200 gradient accumulators (256 VGPRs + AGPR spills, one wave per SIMD).  Here lane q of
+// a quad owns bit q of the cell: the two logits (2q, 2q+1), their softmax / cross-entropy / decision, the matching
+// two columns of the dense_1 gradient (36 + 2 accumulators) and hidden units 4q..4q+3 of the 1x1-conv gradient (12):
+// 50 accumulators per lane.  What a lane does not own it gets from its quad on the DPP crossbar (the backward into
+// the 18 concatenated features and the two dz sums).  The forward uses the same operations in the same order as
+// demod_tail_kernel, so training and evaluation probabilities stay bit-identical.
+template <bool WRITE_PROB>
+__global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
+    const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
+    float* __restrict__ prob, float* __restrict__ dz, long long cells,
+    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
+    constexpr int NB = 4, M = 16, O = 8, P = tail_param_count(4);
+    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
+    constexpr int PS = P | 1;
+    __shared__ float smat[64 * PS];
+    __shared__ float swl[P];
+    __shared__ double sce[4];
+    __shared__ int sconf[4][4];
+    for (int i = threadIdx.x; i < P; i += kTailThreads) swl[i] = tailp[i];
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    auto quad_sum = [](float v) {
+        v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+        v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+        return v;
+    };
+    auto pick4 = [&](const float* a, int u) {           // a[4*q + u] without dynamic register indexing
+        return q == 0 ? a[u] : (q == 1 ? a[4 + u] : (q == 2 ? a[8 + u] : a[12 + u]));
+    };
+    float g2[M + 2][2], gb2[2] = {0.f, 0.f}, gw1a[4], gw1b[4], gb1[4];
+#pragma unroll
+    for (int i = 0; i < M + 2; ++i) g2[i][0] = g2[i][1] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gw1a[u] = gw1b[u] = gb1[u] = 0.f;
+    double ce_acc = 0.0;
+    int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    const float inv_count = 1.0f / (float)(cells * NB);
+    const long long stride = (long long)gridDim.x * (kTailThreads / 4);
+    for (long long cell = (long long)blockIdx.x * (kTailThreads / 4) + (threadIdx.x >> 2); cell < cells; cell += stride) {
+        asm volatile("" ::: "memory");                   // keep the LDS weight reads inside the loop
+        const float2 zv = *reinterpret_cast<const float2*>(z + 2 * cell);
+        const int label = bits[cell * NB + q];
+        const float z0 = zv.x, z1 = zv.y;
+        float c[M + 2], pre1[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            pre1[j] = (z0 * swl[oW1 + j] + z1 * swl[oW1 + M + j]) + swl[oB1 + j];
+            c[j] = leaky_relu(pre1[j]);
+        }
+        c[M] = z0;
+        c[M + 1] = z1;
+        float w2[M + 2][2];                              // this lane's two columns of dense_1
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i) {
+            const float2 w = *reinterpret_cast<const float2*>(swl + oW2 + i * O + 2 * q);
+            w2[i][0] = w.x;
+            w2[i][1] = w.y;
+            s0 += c[i] * w.x;
+            s1 += c[i] * w.y;
+        }
+        const float p20 = s0 + swl[oB2 + 2 * q], p21 = s1 + swl[oB2 + 2 * q + 1];
+        const float u0 = leaky_relu(p20), u1 = leaky_relu(p21);
+        const bool u1_big = u1 > u0;
+        const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
+        const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
+        const float es = e0 + e1;
+        const float p0 = e0 / es, p1 = e1 / es;
+        if (WRITE_PROB) *reinterpret_cast<float2*>(prob + (cell * NB + q) * 2) = make_float2(p0, p1);
+        const bool p1_big = p1 > p0;
+        const float mx2 = p1_big ? p1 : p0;
+        const float fo = expf(p1_big ? (p0 - p1) : (p1 - p0));
+        const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
+        const float fs = f0 + f1;
+        const float lse = logf(fs) + mx2;
+        ce_acc += (double)(lse - (label ? p1 : p0));
+        const int pred = (p1 > p0) ? 1 : 0;
+        const int l1 = label != 0 ? 1 : 0;
+        c00 += (1 - l1) & (1 - pred);
+        c01 += (1 - l1) & pred;
+        c10 += l1 & (1 - pred);
+        c11 += l1 & pred;
+        // backward of this lane's bit
+        const float rfs = 1.0f / fs;
+        const float q0 = f0 * rfs, q1 = f1 * rfs;
+        const float ga = (q0 - (label ? 0.f : 1.f)) * inv_count;
+        const float gb = (q1 - (label ? 1.f : 0.f)) * inv_count;
+        const float dot = ga * p0 + gb * p1;
+        const float du0 = p0 * (ga - dot), du1 = p1 * (gb - dot);
+        const float d20 = du0 * (p20 > 0.f ? 1.f : kLeaky), d21 = du1 * (p21 > 0.f ? 1.f : kLeaky);
+        gb2[0] += d20;
+        gb2[1] += d21;
+        float dc[M + 2];
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i) {
+            g2[i][0] = __builtin_fmaf(c[i], d20, g2[i][0]);
+            g2[i][1] = __builtin_fmaf(c[i], d21, g2[i][1]);
+            dc[i] = quad_sum(__builtin_fmaf(d21, w2[i][1], d20 * w2[i][0]));      // all four bits' contributions
+        }
+        float d0p = 0.f, d1p = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                    // hidden units 4q .. 4q+3
+            const float dp = pick4(dc, u) * (pick4(pre1, u) > 0.f ? 1.f : kLeaky);
+            gw1a[u] = __builtin_fmaf(z0, dp, gw1a[u]);
+            gw1b[u] = __builtin_fmaf(z1, dp, gw1b[u]);
+            gb1[u] += dp;
+            d0p = __builtin_fmaf(dp, swl[oW1 + 4 * q + u], d0p);
+            d1p = __builtin_fmaf(dp, swl[oW1 + M + 4 * q + u], d1p);
+        }
+        const float d0 = dc[M] + quad_sum(d0p), d1 = dc[M + 1] + quad_sum(d1p);
+        if (q == 0) *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
+    }
+    // ---- block reduction: every quad row of the LDS matrix gets each parameter column from the lane that owns it
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    ce_acc = wave_sum(ce_acc);
+    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
+    if (lane == 0) {
+        sce[wid] = ce_acc;
+        sconf[wid][0] = c00; sconf[wid][1] = c01; sconf[wid][2] = c10; sconf[wid][3] = c11;
+    }
+    float* row = smat + (threadIdx.x >> 2) * PS;
+#pragma unroll
+    for (int i = 0; i < M + 2; ++i) {
+        row[oW2 + i * O + 2 * q] = g2[i][0];
+        row[oW2 + i * O + 2 * q + 1] = g2[i][1];
+    }
+    row[oB2 + 2 * q] = gb2[0];
+    row[oB2 + 2 * q + 1] = gb2[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        row[oW1 + 4 * q + u] = gw1a[u];
+        row[oW1 + M + 4 * q + u] = gw1b[u];
+        row[oB1 + 4 * q + u] = gb1[u];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TailBlockMetrics bm;
+        bm.ce_sum = (sce[0] + sce[1]) + (sce[2] + sce[3]);
+        for (int k = 0; k < 4; ++k)
+            bm.conf[k] = (long long)sconf[0][k] + sconf[1][k] + sconf[2][k] + sconf[3][k];
+        blk_metrics[blockIdx.x] = bm;
+    }
+    const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
+    for (int col0 = 0; col0 < P; col0 += 64) {
+        const int col = col0 + slot;
+        const int cc = col < P ? col : P - 1;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += smat[(part * 16 + r) * PS + cc];
+        v = quad_sum(v);
+        if (part == 0 && col < P) blk_grads[(size_t)blockIdx.x * P + col] = v;
+    }
+}
+
 // Slab reduction: wave g < P sums gradient column g over the per-block slabs (lane l owns slabs
 // l, l+64, ...), wave g == P builds the metrics record, wave g == P+1 (fused receiver step
 // only) finishes the mean clipped power of R8 from the normalise kernel's per-block partial sums.
@@ -247,22 +403,22 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailBlockMetrics*
     const int lane = threadIdx.x & 63;
     const int g = block * 4 + (threadIdx.x >> 6);
     if (g < P) {
-        float v[kTailBlocks / 64];
+        float v[kTailBlocksMax / 64];
 #pragma unroll
-        for (int q = 0; q < kTailBlocks / 64; ++q) {
+        for (int q = 0; q < kTailBlocksMax / 64; ++q) {
             const int b = lane + 64 * q;
             v[q] = (b < nblocks) ? blk_grads[(size_t)b * P + g] : 0.f;
         }
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < kTailBlocks / 64; ++q) acc += v[q];
+        for (int q = 0; q < kTailBlocksMax / 64; ++q) acc += v[q];
         const float s = wave_sum(acc);
         if (lane == 0) dtailp[g] = s;
     } else if (g == P) {
         double ce = 0.0;
         long long cf[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < kTailBlocks / 64; ++q) {
+        for (int q = 0; q < kTailBlocksMax / 64; ++q) {
             const int b = lane + 64 * q;
             if (b < nblocks) {
                 ce += blk_metrics[b].ce_sum;
