@@ -102,6 +102,12 @@ SIGNATURES = {
     "dccn_demod_tail_workspace_size": (_sz, [_ll, _i]),
     "dccn_demod_tail_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),
     "dccn_demod_tail_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _sz, _vp]),
+    "dccn_dense_tail_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_dense_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_dense_tail_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
+    "dccn_set_tuning": (_i, [_i, _i]),
+    "dccn_get_tuning": (_i, [_i]),
     "dccn_adam_tf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, AdamHParams, _ll, _vp]),
     "dccn_rx_param_offsets": (_i, [POINTER(RxShape), POINTER(c_longlong)]),
     "dccn_rx_workspace_size": (_sz, [POINTER(RxShape), _i]),

@@ -8,6 +8,7 @@
 #include "gemm_f32_mfma.h"
 #include "norm_adam.h"
 #include "tail.h"
+#include "gemm16.h"
 #include "equalizer.h"
 #include "datagen.h"
 
@@ -29,6 +30,21 @@ struct Carver {
     bool ok() const { return off <= cap && (base != nullptr || off == 0); }
 };
 static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) + bytes; }
+
+// Kernel-configuration knobs (dccn_set_tuning): which tile configuration the GEMM-shaped operators launch.
+// 0 = the 32x32x2 family of gemm_f32_mfma.h, > 0 = a gemm16.h configuration (see the *_impl functions).
+enum TuneKey : int {
+    TUNE_DENSE_FWD = 0,         // fused dense forward + tail (nbits <= 2)
+    TUNE_DENSE_BWD = 1,         // grouped dX + dW
+    TUNE_CCONV_FWD = 2,
+    TUNE_CCONV_BWD_W = 3,
+    TUNE_DENSE_BWD_SPLITS = 4,  // 0 = automatic
+    TUNE_CCONV_BWD_SPLITS = 5,  // 0 = automatic
+    TUNE_SMEM_MIN_KB = 6,       // minimum dynamic LDS per block of the gemm16 launches (caps resident blocks per CU)
+    TUNE_COUNT = 8
+};
+static int g_tune[TUNE_COUNT] = {2, 0, 0, 0, 0, 0, 0, 0};
+static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
 // ---------------------------------------------------------------------------------------
 // R0
@@ -146,11 +162,19 @@ static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, i
     return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
 }
 
+// slab capacity for the weight-gradient split-K plans: small outputs may be cut into up to 8 k ranges (gemm16 paths)
+static int max_splits16(int Mo, int No) {
+    const long long tiles = (long long)ceil_div(Mo, 64) * ceil_div(No, 64);
+    long long m = (1024 + tiles - 1) / tiles;
+    return (int)(m < 1 ? 1 : (m > 8 ? 8 : m));
+}
 static size_t splitk_ws_bytes(int Mo, int No, int Kr) {
     const SplitPlan sp = plan_splitk(Mo, No, Kr);
+    const int ms = max_splits16(Mo, No);
+    const int n = sp.splits > ms ? sp.splits : ms;
     size_t o = 0;
-    o = carve_size(o, (size_t)sp.splits * Mo * No * sizeof(float));
-    o = carve_size(o, (size_t)sp.splits * No * sizeof(float));
+    o = carve_size(o, (size_t)n * Mo * No * sizeof(float));
+    o = carve_size(o, (size_t)n * No * sizeof(float));
     return align_up(o, 256);
 }
 
@@ -200,24 +224,75 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
 // dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
 // (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
+static int dense_bwd16_launch(int variant, const GemmParams& px, const GemmParams& pw, int splits, hipStream_t s) {
+    const size_t sm = tune_smem_min();
+    switch (variant) {
+        case 1: return launch_dense_bwd16<2, 2, 2, 2, 32, 2, 2, 2, 2>(px, pw, splits, s, sm);     // dX 64x64, dW 64x64
+        case 2: return launch_dense_bwd16<1, 4, 3, 1, 32, 2, 2, 2, 2>(px, pw, splits, s, sm);     // dX 48x64
+        case 3: return launch_dense_bwd16<2, 2, 2, 2, 64, 2, 2, 2, 2>(px, pw, splits, s, sm);     // 64-deep k-tiles
+        case 4: return launch_dense_bwd16<2, 2, 3, 2, 32, 2, 2, 2, 2>(px, pw, splits, s, sm);     // dX 96x64
+        case 5: return launch_dense_bwd16<2, 2, 2, 4, 32, 2, 2, 2, 4>(px, pw, splits, s, sm);     // 64x128 both
+        case 6: return launch_dense_bwd16<2, 2, 2, 2, 32, 2, 2, 2, 4>(px, pw, splits, s, sm);     // dX 64x64, dW 64x128
+        default: return DCCN_ERR_INVALID_ARG;
+    }
+}
+static int dense_bwd16_bk(int variant) { return variant == 3 ? 64 : 32; }
+static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
+    xm = 64; xn = 64; wm = 64; wn = 64;
+    if (variant == 2) xm = 48;
+    if (variant == 4) xm = 96;
+    if (variant == 5) { xn = 128; wn = 128; }
+    if (variant == 6) wn = 128;
+}
+
+// dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
+// (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
+// configuration does not apply (128x128 tiles, unaligned operands, single split).
 static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                   int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer) {
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
-    const SplitPlan sp = plan_splitk(K, N, M);
     GemmParams px = dense_bwd_x_params(dy, w, dx, M, K, N);
-    Carver c(ws, ws_bytes);
-    float* slabs = c.take<float>((size_t)sp.splits * K * N);
-    float* cs = c.take<float>((size_t)sp.splits * N);
     GemmParams pw = gp_zero();                // dw[K,N] = x[M,K]^T . dy[M,N]
-    pw.A = x; pw.B = dy; pw.C = slabs; pw.colsum = dbias ? cs : nullptr;
+    pw.A = x; pw.B = dy;
     pw.M = K; pw.N = N; pw.K = M;
     pw.lda = K; pw.ldb = N; pw.ldc = N;
-    pw.klen = sp.klen;
     pw.slab = (long long)K * N;
     pw.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
     pw.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     const bool vec = px.vecA && px.vecB && pw.vecA && pw.vecB;
+    const int variant = g_tune[TUNE_DENSE_BWD];
+    const long long big = (long long)ceil_div(M, 128) * ceil_div(K, 128);
+    if (variant > 0 && vec && big < 2 * kCUs) {
+        int xm, xn, wm, wn;
+        dense_bwd16_tiles(variant, xm, xn, wm, wn);
+        const int nx = ceil_div(px.M, xm) * ceil_div(px.N, xn), tw = ceil_div(pw.M, wm) * ceil_div(pw.N, wn);
+        int want = g_tune[TUNE_DENSE_BWD_SPLITS];
+        if (want <= 0) want = (3 * kCUs - nx + tw / 2) / tw;            // about three resident blocks per CU in all
+        const int cap = max_splits16(K, N);
+        if (want > cap) want = cap;
+        const SplitPlan sp = plan_splitk_n(M, want, dense_bwd16_bk(variant));
+        Carver c(ws, ws_bytes);
+        float* slabs = c.take<float>((size_t)sp.splits * K * N);
+        float* cs = c.take<float>((size_t)sp.splits * N);
+        pw.klen = sp.klen;
+        if (sp.splits == 1) {
+            pw.C = dw; pw.colsum = dbias;
+        } else {
+            pw.C = slabs; pw.colsum = dbias ? cs : nullptr;
+        }
+        DCCN_TRY(dense_bwd16_launch(variant, px, pw, sp.splits, s));
+        defer->dw_slabs = sp.splits > 1 ? slabs : nullptr;
+        defer->db_slabs = (sp.splits > 1 && dbias) ? cs : nullptr;
+        defer->splits = sp.splits;
+        return DCCN_OK;
+    }
+    const SplitPlan sp = plan_splitk(K, N, M);
+    Carver c(ws, ws_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * K * N);
+    float* cs = c.take<float>((size_t)sp.splits * N);
+    pw.C = slabs; pw.colsum = dbias ? cs : nullptr;
+    pw.klen = sp.klen;
     if (sp.splits < 2 || !vec || !grouped_ok(px, pw, sp.splits)) {
         DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, defer));
         return dense_bwd_x_impl(dy, w, dx, M, K, N, s);
@@ -240,6 +315,20 @@ static int cconv_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.cF = F;
     p.vecA = (kin % 2 == 0) && (p.lda % 4 == 0) && aligned16(x) && small_enough(rows, (long long)p.lda);
     p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);      // float2 loads of [Wa|Wb] rows
+    const int variant = g_tune[TUNE_CCONV_FWD];
+    const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    if (variant > 0 && p.vecA && p.vecB && big < 2 * kCUs && kin % 2 == 0) {
+        const size_t sm = tune_smem_min();
+        switch (variant) {
+            case 1: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 2, 2, 1, 4, 32, 1, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 32x128
+            case 2: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 1, 4, 2, 2, 32, 1, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 32x128, wave 32x32
+            case 3: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 1, 4, 1, 2, 32, 1, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 16x128
+            case 4: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 2, 2, 2, 2, 32, 1, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 64x64
+            case 5: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 1, 4, 1, 2, 32, 2, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 16x128, 8 waves
+            case 6: return launch_gemm16<OP_KCONTIG, OP_CCONV_W, 2, 2, 1, 2, 32, 1, 0, TAG_CCONV_FWD>(p, 1, s, sm);   // 32x64
+            default: return DCCN_ERR_INVALID_ARG;
+        }
+    }
     return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
 }
 
@@ -284,6 +373,24 @@ __global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_finalize_kernel(cons
     }
 }
 
+constexpr int kCconvBwMaxSplits = 128;
+static void cconv_bw16_tiles(int variant, int& tm, int& tn) {
+    tm = 64; tn = 64;
+    if (variant == 2) tm = 32;
+    if (variant == 3) { tm = 80; tn = 128; }
+    if (variant == 4) { tm = 32; tn = 128; }
+}
+// workspace of the C-Conv weight gradient: the legacy split plan or up to kCconvBwMaxSplits slabs of a small output
+static size_t cconv_bw_ws_bytes(int rows, int kin, int F) {
+    const size_t legacy = splitk_ws_bytes(2 * kin, 2 * F, rows);
+    if (4LL * kin * F > 512 * 512) return legacy;
+    size_t o = 0;
+    o = carve_size(o, (size_t)kCconvBwMaxSplits * 4 * kin * F * sizeof(float));
+    o = carve_size(o, (size_t)kCconvBwMaxSplits * 2 * F * sizeof(float));
+    o = align_up(o, 256);
+    return o > legacy ? o : legacy;
+}
+
 struct FoldDefer {          // the fold left to the optimizer kernel (fused training step)
     const float* slabs; const float* colsum;
     int splits; long long slab;
@@ -293,8 +400,20 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
                             void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin = nullptr,
                             FoldDefer* defer = nullptr) {
     if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
-    if (!ws || ws_bytes < splitk_ws_bytes(2 * kin, 2 * F, rows)) return DCCN_ERR_WORKSPACE;
-    const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    if (!ws || ws_bytes < cconv_bw_ws_bytes(rows, kin, F)) return DCCN_ERR_WORKSPACE;
+    const int variant = g_tune[TUNE_CCONV_BWD_W];
+    const bool v16 = variant > 0 && defer && fin && (kin % 2 == 0) && (F % 2 == 0) && aligned16(x) && aligned16(dout) &&
+                     small_enough(rows, 2LL * kin) && small_enough(rows, 2LL * F) && 4LL * kin * F <= 512 * 512;
+    SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    if (v16) {
+        int want = g_tune[TUNE_CCONV_BWD_SPLITS];
+        int tm, tn;
+        cconv_bw16_tiles(variant, tm, tn);
+        const int tiles = ceil_div(2 * kin, tm) * ceil_div(2 * F, tn);
+        if (want <= 0) want = (2 * kCUs + tiles - 1) / tiles;
+        if (want > kCconvBwMaxSplits) want = kCconvBwMaxSplits;
+        sp = plan_splitk_n(rows, want, 32);
+    }
     Carver c(ws, ws_bytes);
     float* slabs = c.take<float>((size_t)sp.splits * 4 * kin * F);
     float* cs = c.take<float>((size_t)sp.splits * 2 * F);
@@ -306,6 +425,17 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     p.slab = (long long)4 * kin * F;
     p.vecA = (kin % 2 == 0) && aligned16(x) && small_enough(rows, 2LL * kin);
     p.vecB = (F % 2 == 0) && aligned16(dout) && small_enough(rows, 2LL * F);
+    if (v16) {
+        switch (variant) {
+            case 1: DCCN_TRY((launch_bwd_w16_finalize<2, 2, 2, 2, 32>(p, sp.splits, *fin, s))); break;     // 64x64
+            case 2: DCCN_TRY((launch_bwd_w16_finalize<2, 2, 1, 2, 32>(p, sp.splits, *fin, s))); break;     // 32x64
+            case 3: DCCN_TRY((launch_bwd_w16_finalize<1, 4, 5, 2, 32>(p, sp.splits, *fin, s))); break;     // 80x128
+            case 4: DCCN_TRY((launch_bwd_w16_finalize<2, 2, 1, 4, 32>(p, sp.splits, *fin, s))); break;     // 32x128
+            default: return DCCN_ERR_INVALID_ARG;
+        }
+        defer->slabs = slabs; defer->colsum = cs; defer->splits = sp.splits; defer->slab = p.slab;
+        return DCCN_OK;
+    }
     if (defer && fin && p.vecA && p.vecB && (F % 2 == 0)) {
         // fused step: GEMM + tail finalize in one launch; the fold happens inside the optimizer kernel
         auto kern = cconv_bwd_w_finalize_kernel<true>;
@@ -420,6 +550,88 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     return DCCN_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// dense forward with the tail fused into its epilogue (gemm16.h EPI_TAIL; nbits <= 2)
+// ---------------------------------------------------------------------------------------
+static void dense_tail_tiles(int variant, int& bm, int& bn) {
+    bn = 64;
+    bm = (variant == 5 || variant == 6) ? 64 : ((variant == 7 || variant == 8) ? 32 : 48);
+}
+static int dense_tail_max_blocks(int M, int N) { return ceil_div(M, 32) * ceil_div(N, 64); }
+static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
+    const size_t nb = (size_t)dense_tail_max_blocks(M, N);
+    size_t o = 0;
+    o = carve_size(o, nb * sizeof(TailBlockMetrics));
+    o = carve_size(o, nb * tail_param_count(nbits) * sizeof(float));
+    return align_up(o, 256);
+}
+static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
+    return g_tune[TUNE_DENSE_FWD] > 0 && nbits <= 2 && (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w) &&
+           small_enough(M, K) && small_enough(K, N) && (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs;
+}
+
+template <int NB, bool BWD>
+static int dense_tail_launch(int variant, const GemmParams& p, const TailEpiParams& tp, hipStream_t s) {
+    const size_t sm = tune_smem_min();
+    switch (variant) {
+        case 1: return launch_dense_tail16<1, 4, 3, 1, 32, 1, NB, BWD>(p, tp, s, sm);     // 48x64
+        case 2: return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD>(p, tp, s, sm);
+        case 3: return launch_dense_tail16<1, 4, 3, 1, 64, 2, NB, BWD>(p, tp, s, sm);     // 8 waves: two k shares
+        case 4: return launch_dense_tail16<1, 4, 3, 1, 32, 2, NB, BWD>(p, tp, s, sm);
+        case 5: return launch_dense_tail16<2, 2, 2, 2, 32, 1, NB, BWD>(p, tp, s, sm);     // 64x64
+        case 6: return launch_dense_tail16<2, 2, 2, 2, 64, 2, NB, BWD>(p, tp, s, sm);
+        case 7: return launch_dense_tail16<2, 2, 1, 2, 32, 1, NB, BWD>(p, tp, s, sm);     // 32x64
+        case 8: return launch_dense_tail16<1, 4, 2, 1, 64, 2, NB, BWD>(p, tp, s, sm);
+        default: return DCCN_ERR_INVALID_ARG;
+    }
+}
+
+// z nullable (not materialised then).  defer: as tail_impl.
+static int dense_tail_impl(bool bwd, const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+                           const float* tailp, float* prob, dccn_metrics* metrics, float* dz, float* dtailp, int M,
+                           int K, int N, int nbits, const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes,
+                           hipStream_t s, TailFinalizeArgs* defer = nullptr) {
+    if (!x || !w || !bits || !tailp || !metrics || M <= 0 || K <= 0 || N <= 0 || (N & 1) || nbits < 1 || nbits > 2)
+        return DCCN_ERR_INVALID_ARG;
+    if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
+    if (!dense_tail_ok(x, w, M, K, N, nbits)) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < dense_tail_ws_bytes(M, N, nbits)) return DCCN_ERR_WORKSPACE;
+    const int variant = g_tune[TUNE_DENSE_FWD];
+    int bm, bn;
+    dense_tail_tiles(variant, bm, bn);
+    const int nblk = ceil_div(M, bm) * ceil_div(N, bn);
+    Carver c(ws, ws_bytes);
+    TailBlockMetrics* bmx = c.take<TailBlockMetrics>((size_t)dense_tail_max_blocks(M, N));
+    float* bg = c.take<float>((size_t)dense_tail_max_blocks(M, N) * tail_param_count(nbits));
+    GemmParams p = gp_zero();
+    p.A = x; p.B = w; p.C = z; p.bias = bias;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = K; p.ldb = N; p.ldc = N;
+    p.klen = round_k(K);
+    p.vecA = 1; p.vecB = 1;
+    const long long cells = (long long)M * (N / 2);
+    TailEpiParams tp;
+    tp.bits = bits; tp.tailp = tailp; tp.prob = prob; tp.dz = dz; tp.blk_metrics = bmx; tp.blk_grads = bg;
+    tp.inv_count = 1.0f / (float)(cells * nbits);
+    int st;
+    if (nbits == 1) st = bwd ? dense_tail_launch<1, true>(variant, p, tp, s) : dense_tail_launch<1, false>(variant, p, tp, s);
+    else st = bwd ? dense_tail_launch<2, true>(variant, p, tp, s) : dense_tail_launch<2, false>(variant, p, tp, s);
+    DCCN_TRY(st);
+    const int P = bwd ? tail_param_count(nbits) : 0;
+    const bool pw = pp != nullptr && power_out != nullptr;
+    TailFinalizeArgs fa;
+    fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
+    fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
+    fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
+    if (defer) {
+        *defer = fa;
+        return DCCN_OK;
+    }
+    hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(P)), dim3(256), 0, s, fa);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
 static int adam_impl(float* param, const float* grad, float* m, float* v, const float* reg_coef,
                      const float* reg_gate, dccn_adam_state* st, dccn_adam_hparams hp, long long n, hipStream_t s) {
     if (!param || !grad || !m || !v || !st || n <= 0) return DCCN_ERR_INVALID_ARG;
@@ -463,8 +675,12 @@ static RxLayout rx_layout(const dccn_rx_shape* sh) {
     L.cells = (long long)sh->batch * sh->D;
     L.ws_norm = norm_ws_bytes(sh->batch, L.cols);
     L.ws_tail = tail_ws_bytes(L.cells, sh->nbits);
+    if (sh->nbits <= 2) {
+        const size_t f = dense_tail_ws_bytes(sh->batch, L.dN, sh->nbits);
+        if (f > L.ws_tail) L.ws_tail = f;
+    }
     L.ws_dense_bw = splitk_ws_bytes(L.dK, L.dN, sh->batch);
-    L.ws_conv_bw = splitk_ws_bytes(2 * sh->kin, 2 * sh->F, L.rows);
+    L.ws_conv_bw = cconv_bw_ws_bytes(L.rows, sh->kin, sh->F);
     return L;
 }
 static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
@@ -484,8 +700,7 @@ static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
 static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
                         hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (!shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
-    if (!b->x || !b->bits || !b->params || !b->x_norm || !b->fft_out || !b->z || !b->metrics)
-        return DCCN_ERR_INVALID_ARG;
+    if (!b->x || !b->bits || !b->params || !b->x_norm || !b->fft_out || !b->metrics) return DCCN_ERR_INVALID_ARG;
     if (train && (!b->grads || !b->adam_m || !b->adam_v || !b->adam || !b->dz || !b->dfft))
         return DCCN_ERR_INVALID_ARG;
     if (!b->workspace || b->workspace_bytes < rx_ws_bytes(sh, train ? 1 : 0)) return DCCN_ERR_WORKSPACE;
@@ -504,12 +719,20 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                        train ? b->adam : nullptr, hp, ws_norm, L.ws_norm, s));
     // R1
     DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
-    // R2
-    DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
-    // R3-R6 (+ tail backward)
     TailFinalizeArgs fin;
-    DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
-                       L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
+    if (dense_tail_ok(b->fft_out, P + L.o_dense_w, sh->batch, L.dK, L.dN, sh->nbits)) {
+        // R2 with R3-R6 (+ tail backward) in its epilogue; z is materialised only when the caller gave a buffer
+        DCCN_TRY(dense_tail_impl(train, b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, b->bits, P + L.o_tail, b->prob,
+                                 b->metrics, b->dz, train ? G + L.o_tail : nullptr, sh->batch, L.dK, L.dN, sh->nbits, &pp,
+                                 b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
+    } else {
+        if (!b->z) return DCCN_ERR_INVALID_ARG;
+        // R2
+        DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
+        // R3-R6 (+ tail backward)
+        DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
+                           L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
+    }
     if (!train) return DCCN_OK;
 
     DeferredSlabs ds;
@@ -649,7 +872,7 @@ int dccn_cconv_gemm_fwd(const float* x, const float* w, const float* bias, float
 }
 size_t dccn_cconv_gemm_bwd_w_workspace_size(int rows, int kin, int F) {
     if (rows <= 0 || kin <= 0 || F <= 0) return 0;
-    return splitk_ws_bytes(2 * kin, 2 * F, rows);
+    return cconv_bw_ws_bytes(rows, kin, F);
 }
 int dccn_cconv_gemm_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
                           void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
@@ -696,6 +919,45 @@ int dccn_dense_bwd_slabs(const float* x, const float* dy, const float* w, float*
                                     &ds));
     if (splits) *splits = ds.dw_slabs ? ds.splits : 1;
     return DCCN_OK;
+}
+
+// row[0..3] += conf, row[4] += ce_sum, row[5] += count  (one sweep-table row)
+__global__ void metrics_table_add_kernel(const dccn_metrics* __restrict__ m, double* __restrict__ row) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) row[k] += (double)m->conf[k];
+        row[4] += m->ce_sum;
+        row[5] += (double)m->count;
+    }
+}
+int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream) {
+    if (!metrics || !row6) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(metrics_table_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, metrics, row6);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+int dccn_set_tuning(int key, int value) {
+    if (key < 0 || key >= TUNE_COUNT || value < 0) return DCCN_ERR_INVALID_ARG;
+    g_tune[key] = value;
+    return DCCN_OK;
+}
+int dccn_get_tuning(int key) { return (key < 0 || key >= TUNE_COUNT) ? DCCN_ERR_INVALID_ARG : g_tune[key]; }
+
+size_t dccn_dense_tail_workspace_size(int M, int N, int nbits) {
+    if (M <= 0 || N <= 0 || nbits < 1 || nbits > 2) return 0;
+    return dense_tail_ws_bytes(M, N, nbits);
+}
+int dccn_dense_tail_fwd(const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+                        const float* tailp, float* prob, dccn_metrics* metrics, int M, int K, int N, int nbits,
+                        void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    return dense_tail_impl(false, x, w, bias, z, bits, tailp, prob, metrics, nullptr, nullptr, M, K, N, nbits, nullptr,
+                           nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int dccn_dense_tail_fwd_bwd(const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+                            const float* tailp, float* prob, dccn_metrics* metrics, float* dz, float* dtailp, int M,
+                            int K, int N, int nbits, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    return dense_tail_impl(true, x, w, bias, z, bits, tailp, prob, metrics, dz, dtailp, M, K, N, nbits, nullptr, nullptr,
+                           workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dccn_tail_param_count(int nbits) {

@@ -49,6 +49,7 @@ static size_t eq_split_ws(const EqDims& d) {
     auto upd = [&](int Mo, int No, int Kr) { const size_t v = splitk_ws_bytes(Mo, No, Kr); if (v > m) m = v; };
     upd(d.cp ? 2 * d.nsc : 2 * d.K, 2 * d.K, d.R);   // dense
     upd(2 * d.K, 2 * d.K, d.R);            // the three (1,K) C-Convs
+    { const size_t v = cconv_bw_ws_bytes(d.R, d.K, d.K); if (v > m) m = v; }
     upd(d.SK2, d.Pp, d.B);
     upd(d.Pp, d.SK2, d.B);
     upd(d.SK2, d.SK2, d.B);                // dense_3, dense_4, Toeplitz
@@ -59,6 +60,10 @@ static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool t
     const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
     w.n_norm = norm_ws_bytes(d.B, d.S * d.nsc * 2);
     w.n_tail = tail_ws_bytes((long long)d.B * d.D, sh->nbits);
+    if (sh->nbits <= 2) {
+        const size_t f = dense_tail_ws_bytes(d.B, 2 * d.D, sh->nbits);
+        if (f > w.n_tail) w.n_tail = f;
+    }
     w.n_split = train ? eq_split_ws(d) : 0;
     w.ws_norm = c.take<char>(w.n_norm);
     w.ws_tail = c.take<char>(w.n_tail);
@@ -186,9 +191,15 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
     // frozen basic receiver (model.py:1222-1292) + loss/BER
     DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
-    DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
-    DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
-                       train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+    if (dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
+        DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
+                                 b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, L.dK, L.dN, sh->nbits,
+                                 &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+    } else {
+        DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
+        DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
+                           train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+    }
     if (!train) return DCCN_OK;
 
     // ---- backward: through the frozen receiver to its input ...

@@ -47,19 +47,269 @@ __device__ __forceinline__ TailCellIn<NB> tail_load_cell(const float* __restrict
     return c;
 }
 
+// Per-lane running sums of the tail: weight gradients (training), CE sum, confusion tallies.
+template <int NB, bool BWD>
+struct TailLaneAcc {
+    static constexpr int P = tail_param_count(NB);
+    float g[BWD ? P : 1];
+    double ce;
+    int c00, c01, c10, c11;
+    __device__ __forceinline__ void clear() {
+        if constexpr (BWD) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) g[i] = 0.f;
+        } else {
+            g[0] = 0.f;
+        }
+        ce = 0.0;
+        c00 = c01 = c10 = c11 = 0;
+    }
+};
+
+// W data cells through R3-R6 (and back) in one instruction stream: z = (I,Q) of the dense output, lab = the NB label
+// bits, sw = tail weights (uniform address: scalar loads for NB <= 2, an LDS copy for NB >= 3).  Every statement is
+// written for all W cells before the next one, so the W independent dependency chains sit next to each other and the
+// long-latency steps (exp, log, reciprocal refinement) of one cell are covered by the others even with a single wave
+// per SIMD; per cell the operations and their order are those of the W = 1 form, so any W gives the same bits.
+// valid[u] == false: the cell contributes nothing to the sums (its dz is 0); prob_cell[u] (nullable) -> NB float2.
+// Shared by demod_tail_kernel and the fused dense-forward epilogue (gemm16.h).
+template <int NB, bool BWD, int W>
+__device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z1)[W], const int (&lab)[W][NB],
+                                           const bool (&valid)[W], const float* __restrict__ sw, const float inv_count,
+                                           float* const (&prob_cell)[W], TailLaneAcc<NB, BWD>& A, float2 (&dzv)[W]) {
+    constexpr int M = 1 << NB;
+    constexpr int O = 2 * NB;
+    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
+    float c[M + 2][W], pre1[M][W];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            pre1[j][u] = (z0[u] * sw[oW1 + j] + z1[u] * sw[oW1 + M + j]) + sw[oB1 + j];
+            c[j][u] = leaky_relu(pre1[j][u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        c[M][u] = z0[u];
+        c[M + 1][u] = z1[u];
+    }
+    float pre2[O][W];
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float s[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) s[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i)
+#pragma unroll
+            for (int u = 0; u < W; ++u) s[u] += c[i][u] * sw[oW2 + i * O + o];
+#pragma unroll
+        for (int u = 0; u < W; ++u) pre2[o][u] = s[u] + sw[oB2 + o];
+    }
+    float dpre2[O][W];
+    float inv_eff[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) inv_eff[u] = valid[u] ? inv_count : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        float p0[W], p1[W], f0[W], f1[W], fs[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const float u0 = leaky_relu(pre2[2 * j][u]), u1 = leaky_relu(pre2[2 * j + 1][u]);
+            // softmax over the pair: exp(u - max) is exactly 1 for the larger logit, so one expf suffices
+            // (bit-identical to evaluating both); likewise for the second softmax on the probabilities
+            const bool u1_big = u1 > u0;
+            const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
+            const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
+            const float es = e0 + e1;
+            p0[u] = e0 / es;
+            p1[u] = e1 / es;
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            if (prob_cell[u] != nullptr) *reinterpret_cast<float2*>(prob_cell[u] + 2 * j) = make_float2(p0[u], p1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const int label = lab[u][j];
+            // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
+            const bool p1_big = p1[u] > p0[u];
+            const float mx2 = p1_big ? p1[u] : p0[u];
+            const float fo = expf(p1_big ? (p0[u] - p1[u]) : (p1[u] - p0[u]));
+            f0[u] = p1_big ? fo : 1.0f;
+            f1[u] = p1_big ? 1.0f : fo;
+            fs[u] = f0[u] + f1[u];
+            const float lse = logf(fs[u]) + mx2;
+            const float ce = lse - (label ? p1[u] : p0[u]);
+            A.ce += (double)(valid[u] ? ce : 0.f);
+            const int pred = (p1[u] > p0[u]) ? 1 : 0;    // argmax, first index on ties
+            const int l1 = label != 0 ? 1 : 0;           // branch-free tallies (divergent ifs cost exec-mask regions)
+            const int vb = valid[u] ? 1 : 0;
+            A.c00 += (1 - l1) & (1 - pred) & vb;
+            A.c01 += (1 - l1) & pred & vb;
+            A.c10 += l1 & (1 - pred) & vb;
+            A.c11 += l1 & pred & vb;
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const int label = lab[u][j];
+                const float rfs = 1.0f / fs[u];
+                const float q0 = f0[u] * rfs, q1 = f1[u] * rfs;
+                const float g0 = (q0 - (label ? 0.f : 1.f)) * inv_eff[u];
+                const float g1 = (q1 - (label ? 1.f : 0.f)) * inv_eff[u];
+                const float dot = g0 * p0[u] + g1 * p1[u];
+                const float du0 = p0[u] * (g0 - dot), du1 = p1[u] * (g1 - dot);
+                dpre2[2 * j][u] = du0 * (pre2[2 * j][u] > 0.f ? 1.f : kLeaky);
+                dpre2[2 * j + 1][u] = du1 * (pre2[2 * j + 1][u] > 0.f ? 1.f : kLeaky);
+            }
+        }
+    }
+    if constexpr (BWD) {
+        float dc[M + 2][W];
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i) {
+            float s[W];
+#pragma unroll
+            for (int u = 0; u < W; ++u) s[u] = 0.f;
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                // backward-only sums use fused multiply-adds (one rounding, half the VALU instructions); the
+                // forward stays unfused so that training and evaluation produce identical probabilities
+#pragma unroll
+                for (int u = 0; u < W; ++u) {
+                    A.g[oW2 + i * O + o] = __builtin_fmaf(c[i][u], dpre2[o][u], A.g[oW2 + i * O + o]);
+                    s[u] = __builtin_fmaf(dpre2[o][u], sw[oW2 + i * O + o], s[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < W; ++u) dc[i][u] = s[u];
+        }
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+#pragma unroll
+            for (int u = 0; u < W; ++u) A.g[oB2 + o] += dpre2[o][u];
+        float d0[W], d1[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            d0[u] = dc[M][u];
+            d1[u] = dc[M + 1][u];
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const float dp = dc[j][u] * (pre1[j][u] > 0.f ? 1.f : kLeaky);
+                A.g[oW1 + j] = __builtin_fmaf(z0[u], dp, A.g[oW1 + j]);
+                A.g[oW1 + M + j] = __builtin_fmaf(z1[u], dp, A.g[oW1 + M + j]);
+                A.g[oB1 + j] += dp;
+                d0[u] = __builtin_fmaf(dp, sw[oW1 + j], d0[u]);
+                d1[u] = __builtin_fmaf(dp, sw[oW1 + M + j], d1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) dzv[u] = make_float2(d0[u], d1[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < W; ++u) dzv[u] = make_float2(0.f, 0.f);
+    }
+}
+
+// one cell (W = 1)
+template <int NB, bool BWD>
+__device__ __forceinline__ float2 tail_cell(const float z0, const float z1, const int (&lab)[NB],
+                                            const float* __restrict__ sw, const float inv_count,
+                                            float* __restrict__ prob_cell, TailLaneAcc<NB, BWD>& A) {
+    const float a0[1] = {z0}, a1[1] = {z1};
+    int l[1][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) l[0][j] = lab[j];
+    const bool v[1] = {true};
+    float* const pc[1] = {prob_cell};
+    float2 d[1];
+    tail_cells<NB, BWD, 1>(a0, a1, l, v, sw, inv_count, pc, A, d);
+    return d[0];
+}
+
+// LDS the block reduction of the lane accumulators needs (floats), for NT threads
+template <int NB, bool BWD>
+constexpr int tail_reduce_lds_floats(int nt) {
+    // smat [nt/4][P|1] floats + per-wave ce (double) + per-wave conf (4 ints)
+    return (BWD ? (nt / 4) * (tail_param_count(NB) | 1) : 0) + (nt / 64) * 2 + (nt / 64) * 4 + 2;
+}
+
+// Block reduction: DPP within the wave, LDS across the waves, fixed order (deterministic); writes the block's slab.
+// lds must hold tail_reduce_lds_floats<NB,BWD>(NT) floats, 8-byte aligned.  Starts and ends with barriers of its own.
+template <int NB, bool BWD, int NT>
+__device__ __forceinline__ void tail_block_reduce(TailLaneAcc<NB, BWD>& A, float* __restrict__ lds,
+                                                  TailBlockMetrics* __restrict__ blk_metrics,
+                                                  float* __restrict__ blk_grads, const int slab) {
+    constexpr int P = tail_param_count(NB);
+    constexpr int PS = P | 1;                                  // odd row stride: column reads spread over the banks
+    constexpr int NW = NT / 64, NQ = NT / 4;
+    double* sce = reinterpret_cast<double*>(lds);              // [NW]
+    int* sconf = reinterpret_cast<int*>(lds + 2 * NW);         // [NW][4]
+    float* smat = lds + 2 * NW + 4 * NW + 2;                   // [NQ][PS] partial gradient sums
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double ce = wave_sum(A.ce);
+    const int c00 = wave_sum(A.c00), c01 = wave_sum(A.c01), c10 = wave_sum(A.c10), c11 = wave_sum(A.c11);
+    if (lane == 0) {
+        sce[wid] = ce;
+        sconf[wid * 4 + 0] = c00; sconf[wid * 4 + 1] = c01; sconf[wid * 4 + 2] = c10; sconf[wid * 4 + 3] = c11;
+    }
+    if constexpr (BWD) {
+        // gradients: sum over the 4 lanes of a quad on the DPP crossbar (2 adds per value instead of a full wave
+        // reduction per value), park the quad sums per parameter in LDS ...
+        const int quad = threadIdx.x >> 2;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float v = A.g[i];
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+            if ((lane & 3) == 0) smat[quad * PS + i] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TailBlockMetrics bm;
+        if constexpr (NW == 4) {
+            bm.ce_sum = (sce[0] + sce[1]) + (sce[2] + sce[3]);
+        } else {
+            double t = 0.0;
+            for (int w = 0; w < NW; w += 4) t += (sce[w] + sce[w + 1]) + (sce[w + 2] + sce[w + 3]);
+            bm.ce_sum = t;
+        }
+        for (int k = 0; k < 4; ++k) {
+            long long t = 0;
+            for (int w = 0; w < NW; ++w) t += sconf[w * 4 + k];
+            bm.conf[k] = t;
+        }
+        blk_metrics[slab] = bm;
+    }
+    if constexpr (BWD) {
+        // ... then 4 threads per parameter column add NQ/4 quad sums each (fixed order) and combine on the crossbar
+        const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
+        for (int col0 = 0; col0 < P; col0 += NQ) {
+            const int col = col0 + slot;
+            const int cc = col < P ? col : P - 1;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < NQ / 4; ++r) v += smat[(part * (NQ / 4) + r) * PS + cc];
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+            if (part == 0 && col < P) blk_grads[(size_t)slab * P + col] = v;
+        }
+    }
+}
+
 template <int NB, bool BWD>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
     float* __restrict__ prob, float* __restrict__ dz, long long cells,
     TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
-    constexpr int M = 1 << NB;
-    constexpr int O = 2 * NB;
     constexpr int P = tail_param_count(NB);
-    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
-    constexpr int PS = P | 1;                                  // odd row stride: column reads spread over the banks
-    __shared__ float smat[BWD ? 64 * PS : 1];                  // [quad][param] partial gradient sums
-    __shared__ double sce[4];
-    __shared__ int sconf[4][4];
+    __shared__ __attribute__((aligned(8))) float sred[tail_reduce_lds_floats<NB, BWD>(kTailThreads)];
 
     // nbits <= 2: the <= 40 weights are read through uniform addresses -> scalar (SGPR) loads.  nbits >= 3: 90 / 200
     // weights do not fit the SGPR file (the compiler spilled hundreds of them into VGPR lanes); they are staged in
@@ -73,151 +323,48 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
     }
     const float* __restrict__ sw = LDSW ? swl : tailp;
 
-    float gacc[BWD ? P : 1];
-    if constexpr (BWD) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) gacc[i] = 0.f;
-    }
-    double ce_acc = 0.0;
-    int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    TailLaneAcc<NB, BWD> A;
+    A.clear();
     const float inv_count = 1.0f / (float)(cells * NB);
 
+    // W cells per iteration (cell, cell + stride, ...) in one interleaved instruction stream, the next W prefetched
+    constexpr int W = NB <= 2 ? 2 : 1;
     const long long stride = (long long)gridDim.x * kTailThreads;
     long long cell = (long long)blockIdx.x * kTailThreads + threadIdx.x;
-    TailCellIn<NB> cur = tail_load_cell<NB>(z, bits, cell, cells);
+    TailCellIn<NB> cur[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) cur[u] = tail_load_cell<NB>(z, bits, cell + u * stride, cells);
     while (cell < cells) {
         if constexpr (LDSW) asm volatile("" ::: "memory");
-        const TailCellIn<NB> nxt = tail_load_cell<NB>(z, bits, cell + stride, cells);     // prefetch
-        const float z0 = cur.z.x, z1 = cur.z.y;
-        float c[M + 2], pre1[M];
+        TailCellIn<NB> nxt[W];
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            pre1[j] = (z0 * sw[oW1 + j] + z1 * sw[oW1 + M + j]) + sw[oB1 + j];
-            c[j] = leaky_relu(pre1[j]);
+        for (int u = 0; u < W; ++u) nxt[u] = tail_load_cell<NB>(z, bits, cell + (W + u) * stride, cells);     // prefetch
+        float z0[W], z1[W];
+        int lab[W][NB];
+        bool valid[W];
+        float* pc[W];
+        float2 d[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const long long cu = cell + u * stride;
+            z0[u] = cur[u].z.x;
+            z1[u] = cur[u].z.y;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) lab[u][j] = cur[u].lab[j];
+            valid[u] = cu < cells;
+            pc[u] = (prob != nullptr && valid[u]) ? prob + cu * NB * 2 : nullptr;
         }
-        c[M] = z0;
-        c[M + 1] = z1;
-        float pre2[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < M + 2; ++i) s += c[i] * sw[oW2 + i * O + o];
-            pre2[o] = s + sw[oB2 + o];
-        }
-        float dpre2[O];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const float u0 = leaky_relu(pre2[2 * j]), u1 = leaky_relu(pre2[2 * j + 1]);
-            // softmax over the pair: exp(u - max) is exactly 1 for the larger logit, so one expf suffices
-            // (bit-identical to evaluating both); likewise for the second softmax on the probabilities
-            const bool u1_big = u1 > u0;
-            const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
-            const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
-            const float es = e0 + e1;
-            const float p0 = e0 / es, p1 = e1 / es;
-            if (prob != nullptr)
-                *reinterpret_cast<float2*>(prob + (cell * NB + j) * 2) = make_float2(p0, p1);
-            const int label = cur.lab[j];
-            // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
-            const bool p1_big = p1 > p0;
-            const float mx2 = p1_big ? p1 : p0;
-            const float fo = expf(p1_big ? (p0 - p1) : (p1 - p0));
-            const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
-            const float fs = f0 + f1;
-            const float lse = logf(fs) + mx2;
-            ce_acc += (double)(lse - (label ? p1 : p0));
-            const int pred = (p1 > p0) ? 1 : 0;          // argmax, first index on ties
-            const int l1 = label != 0 ? 1 : 0;           // branch-free tallies (divergent ifs cost exec-mask regions)
-            c00 += (1 - l1) & (1 - pred);
-            c01 += (1 - l1) & pred;
-            c10 += l1 & (1 - pred);
-            c11 += l1 & pred;
-            if constexpr (BWD) {
-                const float rfs = 1.0f / fs;
-                const float q0 = f0 * rfs, q1 = f1 * rfs;
-                const float g0 = (q0 - (label ? 0.f : 1.f)) * inv_count;
-                const float g1 = (q1 - (label ? 1.f : 0.f)) * inv_count;
-                const float dot = g0 * p0 + g1 * p1;
-                const float du0 = p0 * (g0 - dot), du1 = p1 * (g1 - dot);
-                dpre2[2 * j] = du0 * (pre2[2 * j] > 0.f ? 1.f : kLeaky);
-                dpre2[2 * j + 1] = du1 * (pre2[2 * j + 1] > 0.f ? 1.f : kLeaky);
-            }
-        }
+        tail_cells<NB, BWD, W>(z0, z1, lab, valid, sw, inv_count, pc, A, d);
         if constexpr (BWD) {
-            float dc[M + 2];
 #pragma unroll
-            for (int i = 0; i < M + 2; ++i) {
-                float s = 0.f;
-#pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    // backward-only sums use fused multiply-adds (one rounding, half the VALU instructions); the
-                    // forward stays unfused so that training and evaluation produce identical probabilities
-                    gacc[oW2 + i * O + o] = __builtin_fmaf(c[i], dpre2[o], gacc[oW2 + i * O + o]);
-                    s = __builtin_fmaf(dpre2[o], sw[oW2 + i * O + o], s);
-                }
-                dc[i] = s;
-            }
-#pragma unroll
-            for (int o = 0; o < O; ++o) gacc[oB2 + o] += dpre2[o];
-            float d0 = dc[M], d1 = dc[M + 1];
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                const float dp = dc[j] * (pre1[j] > 0.f ? 1.f : kLeaky);
-                gacc[oW1 + j] = __builtin_fmaf(z0, dp, gacc[oW1 + j]);
-                gacc[oW1 + M + j] = __builtin_fmaf(z1, dp, gacc[oW1 + M + j]);
-                gacc[oB1 + j] += dp;
-                d0 = __builtin_fmaf(dp, sw[oW1 + j], d0);
-                d1 = __builtin_fmaf(dp, sw[oW1 + M + j], d1);
-            }
-            *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
+            for (int u = 0; u < W; ++u)
+                if (valid[u]) *reinterpret_cast<float2*>(dz + 2 * (cell + u * stride)) = d[u];
         }
-        cur = nxt;
-        cell += stride;
-    }
-
-    // ---- block reduction: DPP within the wave, LDS across the four waves ----------------------
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    ce_acc = wave_sum(ce_acc);
-    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
-    if (lane == 0) {
-        sce[wid] = ce_acc;
-        sconf[wid][0] = c00; sconf[wid][1] = c01; sconf[wid][2] = c10; sconf[wid][3] = c11;
-    }
-    if constexpr (BWD) {
-        // gradients: sum over the 4 lanes of a quad on the DPP crossbar (2 adds per value instead of a full wave
-        // reduction per value), park the 64 quad sums per parameter in LDS ...
-        const int quad = threadIdx.x >> 2;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float v = gacc[i];
-            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
-            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
-            if ((lane & 3) == 0) smat[quad * PS + i] = v;
-        }
+        for (int u = 0; u < W; ++u) cur[u] = nxt[u];
+        cell += W * stride;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        TailBlockMetrics bm;
-        bm.ce_sum = (sce[0] + sce[1]) + (sce[2] + sce[3]);
-        for (int k = 0; k < 4; ++k)
-            bm.conf[k] = (long long)sconf[0][k] + sconf[1][k] + sconf[2][k] + sconf[3][k];
-        blk_metrics[blockIdx.x] = bm;
-    }
-    if constexpr (BWD) {
-        // ... then 4 threads per parameter column add 16 quad sums each (fixed order) and combine on the crossbar
-        const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
-        for (int col0 = 0; col0 < P; col0 += 64) {
-            const int col = col0 + slot;
-            const int cc = col < P ? col : P - 1;
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v += smat[(part * 16 + r) * PS + cc];
-            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
-            v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
-            if (part == 0 && col < P) blk_grads[(size_t)blockIdx.x * P + col] = v;
-        }
-    }
+    tail_block_reduce<NB, BWD, kTailThreads>(A, sred, blk_metrics, blk_grads, (int)blockIdx.x);
 }
 
 // ---- nbits = 4 training: four lanes per cell ------------------------------------------------------------
@@ -403,28 +550,27 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailBlockMetrics*
     const int lane = threadIdx.x & 63;
     const int g = block * 4 + (threadIdx.x >> 6);
     if (g < P) {
-        float v[kTailBlocksMax / 64];
-#pragma unroll
-        for (int q = 0; q < kTailBlocksMax / 64; ++q) {
-            const int b = lane + 64 * q;
-            v[q] = (b < nblocks) ? blk_grads[(size_t)b * P + g] : 0.f;
-        }
+        // lane l owns slabs l, l+64, ...: batches of 8 independent loads, summed in slab order
         float acc = 0.f;
+        for (int b0 = 0; b0 < nblocks; b0 += 8 * 64) {
+            float v[8];
 #pragma unroll
-        for (int q = 0; q < kTailBlocksMax / 64; ++q) acc += v[q];
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + lane + 64 * q;
+                v[q] = (b < nblocks) ? blk_grads[(size_t)b * P + g] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
         const float s = wave_sum(acc);
         if (lane == 0) dtailp[g] = s;
     } else if (g == P) {
         double ce = 0.0;
         long long cf[4] = {0, 0, 0, 0};
+        for (int b = lane; b < nblocks; b += 64) {
+            ce += blk_metrics[b].ce_sum;
 #pragma unroll
-        for (int q = 0; q < kTailBlocksMax / 64; ++q) {
-            const int b = lane + 64 * q;
-            if (b < nblocks) {
-                ce += blk_metrics[b].ce_sum;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cf[k] += blk_metrics[b].conf[k];
-            }
+            for (int k = 0; k < 4; ++k) cf[k] += blk_metrics[b].conf[k];
         }
         ce = wave_sum(ce);
 #pragma unroll

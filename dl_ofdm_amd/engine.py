@@ -86,7 +86,7 @@ class RxEngine:
 
     def __init__(self, dims: RxDims, batch: int, device="cuda", train: bool = True, seed: int = 1,
                  params: Optional[Dict[str, np.ndarray]] = None, lr0: float = 1e-3, want_prob: bool = True,
-                 want_tx_power: bool = True):
+                 want_tx_power: bool = True, want_z: bool = True):
         self.lib = _lib.load()
         self.dims, self.batch, self.train = dims, int(batch), bool(train)
         self.device = torch.device(device)
@@ -105,7 +105,9 @@ class RxEngine:
         self.bits = torch.zeros(B, d.D, d.nbits, dtype=torch.int32, device=self.device)
         self.x_norm = torch.empty(B, d.S, d.kin, 2, **f32)
         self.fft_out = torch.empty(B, d.S, d.F, 2, **f32)
-        self.z = torch.empty(B, 2 * d.D, **f32)
+        # the dense output: for nbits <= 2 the tail runs inside the dense launch and z only exists when asked for
+        fused_tail = d.nbits <= 2 and (-(-B // 128)) * (-(-2 * d.D // 128)) < 512 and self.lib.dccn_get_tuning(0) > 0
+        self.z = torch.empty(B, 2 * d.D, **f32) if (want_z or not fused_tail) else None
         self.prob = torch.empty(B, d.D, d.nbits, 2, **f32) if want_prob else None
         self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=self.device)
         self.tx_power = torch.zeros(1, **f32) if want_tx_power else None
@@ -262,8 +264,12 @@ def op_launchers(eng: RxEngine):
     nws = max(lib.dccn_dense_bwd_w_workspace_size(B, dK, dN), lib.dccn_cconv_gemm_bwd_w_workspace_size(rows, d.kin, d.F),
               lib.dccn_demod_tail_workspace_size(cells, d.nbits),
               lib.dccn_batch_moment_norm_workspace_size(B, d.S * d.kin * 2))
+    if d.nbits <= 2:
+        nws = max(nws, lib.dccn_dense_tail_workspace_size(B, dN, d.nbits))
     ws = workspace(nws, eng.device, "bench")
     s = eng._stream
+    zbuf = eng.z if eng.z is not None else torch.empty(B, dN, dtype=torch.float32, device=eng.device)
+    tail_flops = 3.0 * cells * (4.0 * d.m + 4.0 * (d.m + 2) * d.nbits)
     ops = {
         "batch_moment_norm": (lambda: lib.dccn_batch_moment_norm_fwd(
             eng.x.data_ptr(), eng.x_norm.data_ptr(), None, None, B, d.S * d.kin * 2, 1e-9, ws.data_ptr(), nws, s()),
@@ -273,12 +279,12 @@ def op_launchers(eng: RxEngine):
             eng.fft_out.data_ptr(), rows, d.kin, d.F, s()), 8.0 * rows * d.kin * d.F, "gemm<cconv_fwd>"),
         "dense_fwd": (lambda: lib.dccn_dense_fwd(
             eng.fft_out.data_ptr(), seg(P, "demodulation/dense/kernel"), seg(P, "demodulation/dense/bias"),
-            eng.z.data_ptr(), B, dK, dN, s()), 2.0 * B * dK * dN, "gemm<dense_fwd>"),
+            zbuf.data_ptr(), B, dK, dN, s()), 2.0 * B * dK * dN, "gemm<dense_fwd>"),
         "tail_fwd_bwd": (lambda: lib.dccn_demod_tail_loss_fwd_bwd(
-            eng.z.data_ptr(), eng.bits.data_ptr(), seg(P, "demodulation/conv2d/kernel"),
+            zbuf.data_ptr(), eng.bits.data_ptr(), seg(P, "demodulation/conv2d/kernel"),
             None if eng.prob is None else eng.prob.data_ptr(), eng.metrics_buf.data_ptr(), eng.dz.data_ptr(),
             seg(G, "demodulation/conv2d/kernel"), cells, d.nbits, ws.data_ptr(), nws, s()),
-            3.0 * cells * (4.0 * d.m + 4.0 * (d.m + 2) * d.nbits), "demod_tail"),
+            tail_flops, "demod_tail"),
         "dense_bwd_x": (lambda: lib.dccn_dense_bwd_x(
             eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(), B, dK, dN, s()),
             2.0 * B * dK * dN, "gemm<dense_bwd_x>"),
@@ -299,6 +305,13 @@ def op_launchers(eng: RxEngine):
             seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),
             8.0 * rows * d.kin * d.F, "gemm<cconv_bwd_w>+fold"),
     }
+    if d.nbits <= 2 and lib.dccn_get_tuning(0) > 0:
+        ops["dense_tail_fwd_bwd"] = (lambda: lib.dccn_dense_tail_fwd_bwd(
+            eng.fft_out.data_ptr(), seg(P, "demodulation/dense/kernel"), seg(P, "demodulation/dense/bias"), None,
+            eng.bits.data_ptr(), seg(P, "demodulation/conv2d/kernel"),
+            None if eng.prob is None else eng.prob.data_ptr(), eng.metrics_buf.data_ptr(), eng.dz.data_ptr(),
+            seg(G, "demodulation/conv2d/kernel"), B, dK, dN, d.nbits, ws.data_ptr(), nws, s()),
+            2.0 * B * dK * dN + tail_flops, "gemm16<dense_fwd+tail>+finalize")
     return ops
 
 

@@ -62,7 +62,10 @@ def ofdm_dense_rx(inputs: torch.Tensor, FLAGS, ofdmobj, outshape=None, *, scope:
 
     with scope.scope("demodulation"):                           # layer 2: data IQ extraction (:1266-1288)
         flat = fft_out.reshape(-1, n_sym * n_filters * m_iq)
-        z = layers_dense(flat, data_ofdm * m_iq, scope=scope)
+        dn = scope.layer_name("dense")
+        k_in = flat.shape[-1]
+        wd = scope.get(dn + "/kernel", (k_in, data_ofdm * m_iq), fan_in=k_in, fan_out=data_ofdm * m_iq)
+        bd = scope.get(dn + "/bias", (data_ofdm * m_iq,), zeros=True)
         m = 2 ** nbits
         c2 = scope.layer_name("conv2d")
         w1 = scope.get(c2 + "/kernel", (2, m), fan_in=2, fan_out=m, meta=dict(tf_shape=(1, 1, 2, m)))
@@ -72,10 +75,21 @@ def ofdm_dense_rx(inputs: torch.Tensor, FLAGS, ofdmobj, outshape=None, *, scope:
         b2 = scope.get(d1 + "/bias", (nbits * nllr,), zeros=True)
         tailp = ops.pack_tail_params(w1, b1, w2, b2)
 
-    zc = z.view(-1, data_ofdm, 2)
+    # the dense layer and the per-cell tail are ONE launch when the operands allow it (the launch the fused engine
+    # uses: the tail runs in the GEMM epilogue), else dense, then the tail kernel
+    fused = ops.dense_tail_supported(flat, wd, nbits)
+    labels = bits if bits is not None else torch.zeros(flat.shape[0], data_ofdm, nbits, dtype=torch.int32,
+                                                        device=flat.device)
+    if fused:
+        if bits is None:
+            with torch.no_grad():
+                _, prob, _ = ops.dense_demod_tail_loss(flat, wd, bd, tailp, labels, nbits)
+            return prob
+        ce, prob, mbuf = ops.dense_demod_tail_loss(flat, wd, bd, tailp, labels, nbits)
+        return prob, ce, mbuf, fft_out
+    zc = ops.dense(flat, wd, bd).view(-1, data_ofdm, 2)
     if bits is None:
-        dummy = torch.zeros(zc.shape[0], data_ofdm, nbits, dtype=torch.int32, device=z.device)
-        _, prob, _ = ops.demod_tail_eval(zc, tailp, dummy, nbits)
+        _, prob, _ = ops.demod_tail_eval(zc, tailp, labels, nbits)
         return prob
     ce, prob, mbuf = ops.demod_tail_loss(zc, tailp, bits, nbits)
     return prob, ce, mbuf, fft_out

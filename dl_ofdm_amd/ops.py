@@ -277,6 +277,75 @@ def demod_tail_loss(z: torch.Tensor, tailp: torch.Tensor, bits: torch.Tensor, nb
     return ce, prob, mbuf
 
 
+class _DenseTailLoss(torch.autograd.Function):
+    """ce_mean of dense -> demodulation tail in ONE launch (dccn_dense_tail_fwd_bwd): the tail runs in the dense
+    GEMM's epilogue, dz never leaves the kernel un-consumed; the backward finishes with the grouped dX + dW launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, tailp, bits, nbits, prob_out, metrics_buf):
+        _need_cuda(x, w, bias, tailp, bits); _f32(x, w, bias, tailp)
+        lib = _lib.load()
+        M, K = x.shape
+        N = w.shape[1]
+        nws = lib.dccn_dense_tail_workspace_size(M, N, nbits)
+        ws = workspace(nws, x.device)
+        need = any(ctx.needs_input_grad[:4])
+        if need:
+            dz = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            dt = torch.empty_like(tailp)
+            check(lib.dccn_dense_tail_fwd_bwd(_p(x), _p(w), _p(bias), None, _p(bits), _p(tailp), _p(prob_out),
+                                              _p(metrics_buf), _p(dz), _p(dt), M, K, N, nbits, _p(ws), nws, _stream()),
+                  "dccn_dense_tail_fwd_bwd")
+            ctx.save_for_backward(x, w, dz, dt)
+            ctx.has_bias = bias is not None
+        else:
+            check(lib.dccn_dense_tail_fwd(_p(x), _p(w), _p(bias), None, _p(bits), _p(tailp), _p(prob_out),
+                                          _p(metrics_buf), M, K, N, nbits, _p(ws), nws, _stream()), "dccn_dense_tail_fwd")
+        return metrics_buf[48:52].view(torch.float32).clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, dz, dt = ctx.saved_tensors
+        lib = _lib.load()
+        M, K = x.shape
+        N = w.shape[1]
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        nws = lib.dccn_dense_bwd_w_workspace_size(M, K, N)
+        ws = workspace(nws, x.device)
+        check(lib.dccn_dense_bwd(_p(x), _p(dz), _p(w), _p(dx), _p(dw), _p(db), M, K, N, _p(ws), nws, _stream()),
+              "dccn_dense_bwd")
+        return dx * g, dw * g, (db * g if db is not None else None), dt * g, None, None, None, None
+
+
+def dense_tail_supported(x: torch.Tensor, w: torch.Tensor, nbits: int) -> bool:
+    """The fused launch needs nbits <= 2 and vector-legal operands (else use dense() + demod_tail_loss())."""
+    M, K = x.shape[0], x.shape[-1]
+    N = w.shape[1]
+    return (nbits <= 2 and K % 4 == 0 and N % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and _lib.load().dccn_get_tuning(0) > 0 and (-(-M // 128)) * (-(-N // 128)) < 512)
+
+
+def dense_demod_tail_loss(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], tailp: torch.Tensor,
+                          bits: torch.Tensor, nbits: int, want_prob: bool = True):
+    """model.py:1268-1291 + ofdmreceiver_np.py:154-169 as one fused operator: x [M,K] . w [K,2D] + bias, then the
+    demodulation tail and loss per data cell.  Returns (ce_mean with grad, prob [M,D,nbits,2] or None, metrics)."""
+    if bits.dtype != torch.int32:
+        raise TypeError("bits must be int32")
+    x = x.reshape(-1, x.shape[-1]).contiguous()
+    w = w.contiguous()
+    M, N = x.shape[0], w.shape[1]
+    if bits.numel() != M * (N // 2) * nbits or tailp.numel() != tail_param_count(nbits):
+        raise ValueError("shape mismatch between x, w, bits and tail params")
+    if not dense_tail_supported(x, w, nbits):
+        raise ValueError("fused dense+tail needs nbits <= 2 and 16-byte aligned operands with K, N multiples of 4")
+    prob = torch.empty(M, N // 2, nbits, 2, dtype=torch.float32, device=x.device) if want_prob else None
+    mbuf = _new_metrics(x.device)
+    ce = _DenseTailLoss.apply(x, w, None if bias is None else bias.contiguous(), tailp.contiguous(), bits.contiguous(),
+                              nbits, prob, mbuf)
+    return ce, prob, mbuf
+
+
 def demod_tail_eval(z, tailp, bits, nbits, want_prob=True):
     with torch.no_grad():
         return demod_tail_loss(z, tailp, bits, nbits, want_prob)

@@ -47,15 +47,21 @@ def shard(points: Sequence[SweepPoint], rank: int, world: int) -> List[SweepPoin
     return [p for p in points if p.index % world == rank]
 
 
-def reduce_table(table: torch.Tensor) -> torch.Tensor:
-    """Sum the per-rank tables (rows a rank does not own are zero).  No-op outside a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+def reduce_table(table: torch.Tensor, world: int = 1, group=None) -> torch.Tensor:
+    """Sum the per-rank tables (rows a rank does not own are zero) over the ranks that SHARED this sweep.
+
+    ``world`` is the caller's sharding degree, not the size of whatever process group happens to exist: a driver
+    may hold a group open while every rank evaluates a different, unsharded configuration (world == 1) -- those
+    tables must not be summed, and ranks with unequal numbers of sweeps would dead-lock in the collective."""
+    if world > 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("sweep sharded over %d ranks but no process group is initialised" % world)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     return table
 
 
 def run_sweep(points: Sequence[SweepPoint], evaluate: Callable[[SweepPoint], Sequence[float]],
-              rank: int = 0, world: int = 1, device: Optional[torch.device] = None) -> np.ndarray:
+              rank: int = 0, world: int = 1, device: Optional[torch.device] = None, group=None) -> np.ndarray:
     """Evaluate this rank's shard and reduce.  ``evaluate(point)`` returns the six TABLE_COLS values of
     one point (confusion counts, summed cross entropy, bit count).  Returns the full float64 table on
     every rank."""
@@ -63,7 +69,7 @@ def run_sweep(points: Sequence[SweepPoint], evaluate: Callable[[SweepPoint], Seq
     for p in shard(points, rank, world):
         row = evaluate(p)
         table[p.index] = torch.as_tensor(np.asarray(row, dtype=np.float64), device=table.device)
-    reduce_table(table)
+    reduce_table(table, world, group)
     return table.cpu().numpy()
 
 

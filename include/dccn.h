@@ -139,6 +139,33 @@ int dccn_demod_tail_loss_fwd_bwd(const float* z, const int32_t* bits, const floa
                                  long long cells, int nbits,
                                  void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 
+/* R2 with R3-R6 fused into its epilogue (nbits 1..2): the demodulation tail runs on the dense output tile
+ * while it is still in registers, so z never has to exist in memory (dev/py/model.py:1268-1291 +
+ * dev/py/ofdmreceiver_np.py:154-169 in one launch, plus the metrics finalize).
+ *   x [M,K], w [K,N], bias [N], z [M,N] (nullable: not materialised), bits [M, N/2, nbits],
+ *   prob [M, N/2, nbits, 2] (nullable), metrics as above; _fwd_bwd also emits dz [M,N] and dtailp.
+ * Requires 16-byte aligned x/w and K % 4 == N % 4 == 0; returns DCCN_ERR_INVALID_ARG otherwise (use the separate
+ * dccn_dense_fwd + dccn_demod_tail_loss_* calls then). */
+size_t dccn_dense_tail_workspace_size(int M, int N, int nbits);
+int dccn_dense_tail_fwd(const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+                        const float* tailp, float* prob, dccn_metrics* metrics, int M, int K, int N, int nbits,
+                        void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+int dccn_dense_tail_fwd_bwd(const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+                            const float* tailp, float* prob, dccn_metrics* metrics, float* dz, float* dtailp,
+                            int M, int K, int N, int nbits, void* workspace, size_t workspace_bytes,
+                            dccn_stream_t stream);
+
+/* One row of the sweep table {c00,c01,c10,c11,ce_sum,count} (float64, device): row6 += the metrics record of the
+ * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
+int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
+
+/* Kernel-configuration knobs for experiments and profiling (process-wide, not thread-safe against concurrent
+ * launches): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
+ * (0 = 32x32x2 tile family, >0 = a 16x16x4 configuration), 4/5 split-K counts of the two weight gradients
+ * (0 = automatic), 6 minimum LDS per block in KiB.  Set them before workspaces are sized. */
+int dccn_set_tuning(int key, int value);
+int dccn_get_tuning(int key);
+
 /* ---- R7: optimizer -----------------------------------------------------------------
  * dev/py/ofdmreceiver_np.py:185-189  exponential_decay(1e-3, step, 500, 0.98, staircase)
  * + tf.train.AdamOptimizer (TF 1.15 ApplyAdam kernel form).  All state lives on the
@@ -194,7 +221,7 @@ typedef struct dccn_rx_buffers {
     dccn_adam_state* adam;     /* train only */
     float* x_norm;             /* [batch, S, kin, 2]  `input:0` */
     float* fft_out;            /* [batch, S, F, 2]    `receiver/fft_like/fft_out:0` */
-    float* z;                  /* [batch, 2D] */
+    float* z;                  /* [batch, 2D] (nullable for nbits <= 2: the fused dense+tail launch skips it) */
     float* prob;               /* [batch, D, nbits, 2] `output:0` (nullable) */
     float* dz;                 /* [batch, 2D] train only */
     float* dfft;               /* [batch, S, F, 2] train only */

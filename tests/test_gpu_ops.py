@@ -204,6 +204,58 @@ def test_demod_tail_loss(ops, nbits, cells):
     assert ops.read_metrics(mbuf2)["conf"] == m["conf"]
 
 
+# ---- R2 + R3-R6 in one launch (gemm16 EPI_TAIL) -----------------------------------------------------
+@pytest.mark.parametrize("nbits,M,K,N", [(2, 36, 896, 640), (1, 36, 896, 640), (2, 1170, 896, 640), (2, 53, 100, 36),
+                                         (1, 130, 64, 132), (2, 585, 128, 64)])
+def test_dense_tail_fused(ops, nbits, M, K, N):
+    """dccn_dense_tail_fwd_bwd vs the float64 oracle (dense, then tail forward/backward): prob, ce_mean, confusion
+    counts, dz through its consumers dx/dw/db, and the tail-weight gradients.  Cells whose pre-activations sit within
+    rounding of a leaky-ReLU kink (derivative jumps 1 <-> 0.2) are excluded from the element-wise dz-dependent
+    comparisons by construction of the inputs: z is re-drawn until every cell is well conditioned."""
+    rng = np.random.RandomState(100 * nbits + M)
+    D = N // 2
+    tp = {k: v.astype(np.float32).astype(np.float64) for k, v in _tail_params(nbits, rng).items()}
+    flat = np.concatenate([tp[k].reshape(-1) for k in ("w1", "b1", "w2", "b2")]).astype(np.float32)
+    w = (rng.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    b = (rng.randn(N) * 0.5).astype(np.float32)
+    x = (rng.randn(M, K) * 2.0).astype(np.float32)
+    bits = rng.randint(0, 2, (M, D, nbits)).astype(np.int32)
+    w6, b6 = w.astype(np.float64), b.astype(np.float64)
+    for _ in range(60):
+        z6 = x.astype(np.float64) @ w6 + b6
+        r = O.tail_forward_backward(z6.reshape(-1, 2), bits.reshape(-1, nbits), tp["w1"], tp["b1"], tp["w2"], tp["b2"], nbits)
+        pr = r["prob"].reshape(M * D, -1, 2)
+        bad = (np.abs(r["pre1"]).min(1) < 2e-4) | (np.abs(r["pre2"]).min(1) < 2e-4) | \
+              (np.abs(pr[..., 1] - pr[..., 0]).min(1) < 2e-5)
+        rows = np.unique(np.nonzero(bad)[0] // D)
+        if rows.size == 0:
+            break
+        x[rows] = (rng.randn(rows.size, K) * 2.0).astype(np.float32)
+    else:
+        raise AssertionError("could not build a well-conditioned case")
+    xt, wt, bt, ft = (dev(a).requires_grad_() for a in (x, w, b, flat))
+    ce, prob, mbuf = ops.dense_demod_tail_loss(xt, wt, bt, ft, dev(bits, torch.int32), nbits)
+    ce.backward()
+    m = ops.read_metrics(mbuf)
+    assert_close(prob.cpu().numpy().reshape(-1, nbits, 2), r["prob"].reshape(-1, nbits, 2), "prob")
+    assert abs(m["ce_mean"] - r["ce_mean"]) <= 1e-5 * abs(r["ce_mean"])
+    assert np.array_equal(np.array(m["conf"]), r["conf"]) and m["count"] == M * D * nbits
+    dz6 = r["dz"].reshape(M, N)
+    assert_close(xt.grad.cpu().numpy(), dz6 @ w6.T, "dx", tol=2e-5)
+    assert_close(wt.grad.cpu().numpy(), x.astype(np.float64).T @ dz6, "dw", tol=2e-5)
+    assert_close(bt.grad.cpu().numpy(), dz6.sum(0), "db", tol=2e-5)
+    gref = np.concatenate([r["grads"][k].reshape(-1) for k in ("w1", "b1", "w2", "b2")])
+    assert_close(ft.grad.cpu().numpy(), gref, "tail param grads", tol=2e-5)
+    # inference instantiation: same probabilities bit for bit
+    with torch.no_grad():
+        ce2, prob2, mbuf2 = ops.dense_demod_tail_loss(dev(x), dev(w), dev(b), dev(flat), dev(bits, torch.int32), nbits)
+    assert torch.equal(prob2, prob) and ops.read_metrics(mbuf2)["conf"] == m["conf"]
+    # and the two-launch path (dense, then tail) agrees to rounding
+    z = ops.dense(dev(x), dev(w), dev(b))
+    ce3, prob3, _ = ops.demod_tail_eval(z.view(M, D, 2), dev(flat), dev(bits, torch.int32), nbits)
+    assert_close(prob3.cpu().numpy().reshape(-1), prob.cpu().numpy().reshape(-1), "fused vs separate prob", tol=2e-6)
+
+
 # ---- R7 -------------------------------------------------------------------------------------
 def test_adam_tf_steps(ops):
     import ctypes as C

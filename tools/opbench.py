@@ -19,7 +19,12 @@ def main():
     ap.add_argument("ops", nargs="+")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--config", default="c2")
+    ap.add_argument("--tune", default="", help="dccn_set_tuning pairs, e.g. 0=2,1=1,4=3")
     args = ap.parse_args()
+    from dl_ofdm_amd import _lib
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        assert _lib.load().dccn_set_tuning(int(k), int(v)) == 0
     c = bench.CONFIGS[args.config]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
     eng = RxEngine(dims, c["frames"], train=True)
