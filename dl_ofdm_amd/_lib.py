@@ -106,6 +106,8 @@ SIGNATURES = {
     "dccn_dense_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_dense_tail_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
+    "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),
+    "dccn_ingraph_awgn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
     "dccn_set_tuning": (_i, [_i, _i]),
     "dccn_get_tuning": (_i, [_i]),
     "dccn_adam_tf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, AdamHParams, _ll, _vp]),

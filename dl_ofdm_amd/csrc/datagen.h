@@ -6,6 +6,7 @@
 // (seed, offset) and every thread draws independently.  All of it is one pass over HBM; the IFFT + cyclic
 // prefix is a dense MFMA GEMM with a constant [2K, 2(K+CP)] matrix (gemm_f32_mfma.h).
 #pragma once
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace dccn {
@@ -206,6 +207,42 @@ __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y,
     __syncthreads();
     if (threadIdx.x == 0 && noise_partial)
         noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// radio.py:62-88 AWGN_channel, the *in-graph* monitor branch of the receiver graph (ofdmreceiver_np.py:136,151-152):
+// xn = batch-normalised (eps 1e-8) clipped signal / sqrt(2) (computed by the caller with the R0 kernel),
+// level = sqrt(.5) 10^(-SNR/20) per frame, amp = level * N(0,1), phase = U(0, 2 pi),
+// noise = (|amp| sin(phase), |amp| cos(phase)); iq_rx = fp16(xn + noise), iq_tx = fp16(clipped signal),
+// noise_power = mean(noise_re^2 + noise_im^2).  The receiver never consumes this branch (`rx_iq_data = iq_tx_re`);
+// it only feeds the constellation dumps and the printed noise power.  grid = (ceil(T/256), frames).
+__global__ __launch_bounds__(256) void ingraph_awgn_kernel(const float2* __restrict__ clipped,
+                                                           const float2* __restrict__ xn,
+                                                           const float* __restrict__ snr_db, __half2* __restrict__ iq_tx,
+                                                           __half2* __restrict__ iq_rx, double* __restrict__ noise_partial,
+                                                           int T, unsigned offset, unsigned long long seed) {
+    __shared__ double sh[4];
+    const int fr = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    double pw = 0.0;
+    if (t < T) {
+        const size_t i = (size_t)fr * T + t;
+        const float level = 0.70710678118654752440f * exp10f(-snr_db[fr] * 0.05f);
+        const Philox4 p = philox4x32_10((unsigned long long)i, kStreamNoise, offset, seed);
+        const float amp = fabsf(level * box_muller(p.v[0], p.v[1]).x);
+        float sn, cs;
+        sincosf(6.2831853071795864769f * uniform01(p.v[2]), &sn, &cs);
+        const float nr = amp * sn, ni = amp * cs;
+        const float2 v = xn[i];
+        if (iq_rx) iq_rx[i] = __floats2half2_rn(v.x + nr, v.y + ni);
+        if (iq_tx) {
+            const float2 c = clipped[i];
+            iq_tx[i] = __floats2half2_rn(c.x, c.y);
+        }
+        pw = (double)nr * nr + (double)ni * ni;
+    }
+    pw = wave_sum(pw);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
+    __syncthreads();
+    if (threadIdx.x == 0) noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // radio.py:376-407 Jakes sum-of-sinusoids Doppler: per OFDM symbol s (t = s * n_sc / Fs) and tap k

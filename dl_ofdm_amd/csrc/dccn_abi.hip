@@ -1407,6 +1407,52 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
     return DCCN_OK;
 }
 
+// ---- in-graph AWGN monitor branch (`iq_tx:0`, `iq_rx:0`, `noise_power:0`) -----------------------------------
+size_t dccn_ingraph_awgn_workspace_size(int frames, int pairs_per_frame) {
+    if (frames <= 0 || pairs_per_frame <= 0) return 0;
+    size_t o = 0;
+    o = carve_size(o, (size_t)frames * pairs_per_frame * 2 * sizeof(float));                   // clipped
+    o = carve_size(o, (size_t)frames * pairs_per_frame * 2 * sizeof(float));                   // re-normalised
+    o = carve_size(o, norm_ws_bytes(frames, 2 * pairs_per_frame));
+    o = carve_size(o, dccn_clip_power_workspace_size((long long)frames * pairs_per_frame));
+    o = carve_size(o, (size_t)frames * ceil_div(pairs_per_frame, 256) * sizeof(double));
+    o = carve_size(o, 256);
+    return align_up(o, 256);
+}
+int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal, uint16_t* iq_tx_f16,
+                      uint16_t* iq_rx_f16, float* noise_power, int frames, int pairs_per_frame, float peak,
+                      unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
+                      dccn_stream_t stream) {
+    if (!x_norm || !snr_db || !noise_power || frames <= 0 || pairs_per_frame <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_ingraph_awgn_workspace_size(frames, pairs_per_frame)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_pairs = (long long)frames * pairs_per_frame;
+    Carver c(workspace, workspace_bytes);
+    float* clipped = c.take<float>((size_t)n_pairs * 2);
+    float* xn = c.take<float>((size_t)n_pairs * 2);
+    const size_t nws = norm_ws_bytes(frames, 2 * pairs_per_frame);
+    void* ws_norm = c.take<char>(nws);
+    const size_t cws = dccn_clip_power_workspace_size(n_pairs);
+    void* ws_clip = c.take<char>(cws);
+    const int gx = ceil_div(pairs_per_frame, 256);
+    double* partial = c.take<double>((size_t)frames * gx);
+    float* scratch_pw = c.take<float>(64);            // complex_clip's power output is `tx_power:0`, served elsewhere
+    float* clip_dst = tx_signal ? tx_signal : clipped;
+    DCCN_TRY(dccn_clip_power(x_norm, clip_dst, scratch_pw, n_pairs, peak, ws_clip, cws, stream));
+    dccn_adam_hparams hp;
+    memset(&hp, 0, sizeof(hp));
+    DCCN_TRY(norm_impl(clip_dst, xn, nullptr, nullptr, false, nullptr, frames, 2 * pairs_per_frame, 1e-8f, peak, nullptr, hp,
+                       ws_norm, nws, s));
+    hipLaunchKernelGGL(ingraph_awgn_kernel, dim3(gx, frames), dim3(256), 0, s, (const float2*)clip_dst, (const float2*)xn,
+                       snr_db, reinterpret_cast<__half2*>(iq_tx_f16), reinterpret_cast<__half2*>(iq_rx_f16), partial,
+                       pairs_per_frame, offset, seed);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * gx, (double)n_pairs,
+                       noise_power);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
 // ---- CRC32C (host) --------------------------------------------------------------------------------------
 static uint32_t g_crc32c_table[8][256];
 static bool g_crc32c_ready = false;

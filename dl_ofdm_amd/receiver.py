@@ -161,35 +161,52 @@ def _gen_into(gen, eng, FLAGS: Flags, ofdmobj, n_frames: int, snr_db):
 
 
 # ---- sweep (H4) ------------------------------------------------------------------------------------
-def test_model(FLAGS: Flags, params: Dict[str, np.ndarray], ofdmobj=None, rank: int = 0, world: int = 1,
-               device="cuda", out_dir: str = ".", verbose: bool = True):
+def test_model(FLAGS: Flags, model, ofdmobj=None, rank: int = 0, world: int = 1,
+               device="cuda", out_dir: str = ".", verbose: bool = True, group=None):
     """SNR sweep of a trained receiver (ofdmreceiver_np.py:59-91), sharded over ``world`` ranks; rank 0
-    writes ``Test_DCCN_<token>_<channel>.csv`` (columns SNR,BER,Loss)."""
-    from .engine import RxEngine
+    writes ``Test_DCCN_<token>_<channel>.csv`` (columns SNR,BER,Loss).
+
+    ``model``: the checkpoint path prefix, restored through the graph-name API exactly like the reference does
+    (``load_model_np(path, session)`` then ``session.run([conf_matrix, berlin, ...], {x, y, SNR})``, :60,80), or an
+    already loaded name -> array dict."""
+    from .session import Session, load_model_np
     ofdmobj = ofdmobj or ofdm.ofdm_tx(FLAGS)
     snrs = list(range(FLAGS.snr_lo, FLAGS.snr_hi + 1))
     pts = sweep.make_points([FLAGS.nbits], [FLAGS.channel], snrs, base_seed=FLAGS.seed)
-    eng = RxEngine(rx_dims(FLAGS, ofdmobj), FLAGS.test_frames, device=device, train=False, params=params,
-                   want_prob=False)
+    sess = Session(device=device, seed=FLAGS.seed)
+    if isinstance(model, str):
+        y, x, _, _, _, _, berlin, conf_matrix, power_tx, noise_pwr, _, _, ce_mean, SNR = load_model_np(model, sess, FLAGS, ofdmobj)
+    else:
+        sess.restore(model, crop=None if FLAGS.cp else (ofdmobj.CP, ofdmobj.K), nsymbol=FLAGS.nsymbol)
+        g = sess.get_tensor_by_name
+        y, x, SNR = g("bits_in:0"), g("tx_ofdm:0"), g("SNR:0")
+        berlin, conf_matrix, power_tx, noise_pwr, ce_mean = (g(n) for n in ("linear_ber:0", "conf_matrix:0", "tx_power:0",
+                                                                             "noise_power:0", "ce_mean:0"))
     fading = radio.rayleigh_chan_lte(FLAGS, ofdmobj.Fs)
     gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
 
     def evaluate(p):
         if gen is not None:
+            eng = sess.engine_for(FLAGS.test_frames)
             gen.seed, gen.offset = p.seed, 0
             _gen_into(gen, eng, FLAGS, ofdmobj, FLAGS.test_frames, p.snr_db)
             eng.eval_step()
+            confmax, berl, test_loss = sess.fetch([conf_matrix, berlin, ce_mean], eng)
         else:
             np.random.seed(p.seed)
-            xs, ys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.test_frames, p.snr_db)
-            eng.eval_step(xs, ys)
-        m = eng.metrics()
+            test_ys = util.bit_source(FLAGS.nbits, ofdmobj.frame_size, FLAGS.test_frames)
+            iq_cpx, _, _ = ofdmobj.ofdm_tx_frame_np(test_ys)
+            test_xs, _ = fading.run(iq_cpx)
+            snr_test = p.snr_db * np.ones((FLAGS.test_frames, 1))
+            test_xs, _ = radio.AWGN_channel_np(test_xs, snr_test)
+            confmax, berl, test_loss = sess.run([conf_matrix, berlin, ce_mean], {x: test_xs, y: test_ys, SNR: snr_test})
         if verbose:
-            print("SNR: %.2f, BER: %.8f, Loss: %f" % (p.snr_db, m["berlin"], m["ce_mean"]))
-        c = m["conf"]
-        return [c[0][0], c[0][1], c[1][0], c[1][1], m["ce_sum"], m["count"]]
+            print("SNR: %.2f, BER: %.8f, Loss: %f" % (p.snr_db, berl, test_loss))
+        count = float(confmax.sum())
+        return [confmax[0][0], confmax[0][1], confmax[1][0], confmax[1][1], float(test_loss) * count, count]
 
-    table = sweep.run_sweep(pts, evaluate, rank, world, device=eng.device)
+    table = sweep.run_sweep(pts, evaluate, rank, world, device=sess.device, group=group)
+    sess.close()
     ber, loss = sweep.ber_loss(table)
     csvfile = os.path.join(out_dir, "Test_DCCN_%s.csv" % (FLAGS.token + "_" + FLAGS.channel))
     if rank == 0:
@@ -265,6 +282,11 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
             ev.eval_step(txs, tys)
         em = ev.metrics()
+        # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:256,264-265): first 2048 IQ pairs, fp16
+        from .session import monitor_tensors
+        mon = monitor_tensors(ev, FLAGS.SNR * np.ones(FLAGS.eval_frames), FLAGS.seed, epoch + 1)
+        np.savetxt("%s_txiq.csv" % FLAGS.token, mon["iq_tx"][:2048].cpu().numpy(), delimiter=",")     # cwd, like the reference
+        np.savetxt("%s_rxiq.csv" % FLAGS.token, mon["iq_rx"][:2048].cpu().numpy(), delimiter=",")
         history.append(dict(epoch=epoch, train_loss=train_loss_epoch, test_loss=em["ce_mean"], test_ber=em["berlin"],
                             batch_size=batch_size))
         if verbose:
@@ -279,16 +301,14 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
         print("Training Done!, Best model saved to\n%s" % best_path)
     result = dict(history=history, best_path=best_path, params=eng.get_params())
     if run_test and best_path:
-        z = read_checkpoint_file(best_path)
-        result["sweep"] = test_model(FLAGS, {n: z[n] for n in PARAM_NAMES}, ofdmobj, device=device, verbose=verbose)
+        result["sweep"] = test_model(FLAGS, best_path, ofdmobj, device=device, verbose=verbose)
     return result
 
 
 def main(argv=None):
     FLAGS = parse_flags(argv)
     if FLAGS.test:
-        z = read_checkpoint_file(os.path.join(FLAGS.save_dir, FLAGS.token))
-        test_model(FLAGS, {n: z[n] for n in PARAM_NAMES})
+        test_model(FLAGS, os.path.join(FLAGS.save_dir, FLAGS.token))
         return
     t0 = time.time()
     train(FLAGS)

@@ -109,8 +109,18 @@ def load_rx_params(FLAGS) -> Dict[str, np.ndarray]:
     if not os.path.exists(stem + ".npz") and not os.path.exists(stem + ".index"):
         raise FileNotFoundError("basic-receiver checkpoint %s(.npz|.index) not found: train it first with "
                                 "`python -m dl_ofdm_amd.receiver --token=%s ...`" % (stem, FLAGS.token))
-    z = read_checkpoint_file(stem)
-    return {n: z[n] for n in PARAM_NAMES}
+    # the reference restores the basic receiver's graph and takes its tensors by name (:264-285); same contract here:
+    # the checkpoint goes through the graph-name API, the equaliser is then grafted in front of `input:0`
+    from .session import Session, load_model_np
+    sess = Session(device="cuda", seed=FLAGS.seed)
+    load_model_np(stem, sess)
+    for name in ("bits_in:0", "tx_ofdm:0", "SNR:0", "tx_signal:0", "tx_power:0", "iq_tx:0", "iq_rx:0", "input:0",
+                 "ce_mean:0", "noise_power:0", "log_ber:0", "linear_ber:0", "conf_matrix:0"):
+        sess.get_tensor_by_name(name)
+    if sess.dims.nbits != FLAGS.nbits or sess.dims.F != FLAGS.nfilter or sess.dims.S != FLAGS.nsymbol:
+        raise ValueError("basic receiver %s was trained with nbits=%d nfilter=%d nsymbol=%d, flags say %d/%d/%d"
+                         % (stem, sess.dims.nbits, sess.dims.F, sess.dims.S, FLAGS.nbits, FLAGS.nfilter, FLAGS.nsymbol))
+    return dict(sess.params)
 
 
 def make_batch(FLAGS, ofdmobj, fading, n_frames: int, snr_db):

@@ -324,15 +324,47 @@ def rx_to_tf(params: Dict[str, np.ndarray], kin: int) -> Dict[str, np.ndarray]:
     return out
 
 
+RX_TRAINABLES = ("fft_like/conv3d/kernel", "fft_like/conv3d/bias", "demodulation/dense/kernel", "demodulation/dense/bias",
+                 "demodulation/conv2d/kernel", "demodulation/conv2d/bias", "demodulation/dense_1/kernel",
+                 "demodulation/dense_1/bias")
+_OPT_SCALARS = ("global_step", "beta1_power", "beta2_power")
+
+
 def rx_from_tf(tensors: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """TF layouts -> engine layouts, for the model versions this implementation can run:
+
+      * the dev receiver (dev/py/model.py:1222-1292): the eight RX_TRAINABLES (+ Adam slots, step, beta powers);
+      * the archived v1 receiver (test_v1/model/*): it carries a second 1x1 convolution ``demodulation/conv2d_1``
+        directly behind the first, with no activation in between -- the two are one affine map, so they are folded
+        into ``demodulation/conv2d`` (kernel w1.w1b, bias b1.w1b + b1b) and the receiver evaluates exactly the same
+        function.  The fold is for inference / fine-tuning from fresh optimizer state: the Adam slots of the two
+        factors cannot be folded and are dropped (``load_checkpoint`` then leaves the optimizer at its initial state).
+
+    Any other variable (a different topology) raises instead of being silently ignored."""
+    known = set(RX_TRAINABLES) | {"demodulation/conv2d_1/kernel", "demodulation/conv2d_1/bias"}
+    for n in tensors:
+        base = n.split("/Adam")[0]
+        if base not in known and n not in _OPT_SCALARS:
+            raise ValueError("checkpoint variable %r does not belong to a receiver topology this implementation runs "
+                             "(dev ofdm_dense_rx, or v1 with its extra demodulation/conv2d_1)" % n)
     out = {}
     for n, a in tensors.items():
         base = n.split("/Adam")[0]
         if base == "fft_like/conv3d/kernel" and a.ndim == 5:
             a = a[0, (a.shape[1] - 1) // 2, 0]
-        elif base == "demodulation/conv2d/kernel" and a.ndim == 4:
+        elif base in ("demodulation/conv2d/kernel", "demodulation/conv2d_1/kernel") and a.ndim == 4:
             a = a[0, 0]
         out[n] = np.ascontiguousarray(a) if np.ndim(a) else np.asarray(a)
+    if "demodulation/conv2d_1/kernel" in out:
+        w1, b1 = out["demodulation/conv2d/kernel"].astype(np.float64), out["demodulation/conv2d/bias"].astype(np.float64)
+        w1b, b1b = (out["demodulation/conv2d_1/kernel"].astype(np.float64),
+                    out["demodulation/conv2d_1/bias"].astype(np.float64))
+        out["demodulation/conv2d/kernel"] = (w1 @ w1b).astype(np.float32)
+        out["demodulation/conv2d/bias"] = (b1 @ w1b + b1b).astype(np.float32)
+        for n in list(out):
+            if n.startswith("demodulation/conv2d_1/") or n.startswith("demodulation/conv2d/kernel/Adam") or \
+                    n.startswith("demodulation/conv2d/bias/Adam"):
+                del out[n]
     return out
 
 

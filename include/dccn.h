@@ -155,6 +155,18 @@ int dccn_dense_tail_fwd_bwd(const float* x, const float* w, const float* bias, f
                             int M, int K, int N, int nbits, void* workspace, size_t workspace_bytes,
                             dccn_stream_t stream);
 
+/* The in-graph AWGN monitor branch of the receiver graph (dev/py/radio.py:62-88 AWGN_channel, called at
+ * dev/py/ofdmreceiver_np.py:136; tensors `tx_signal:0`, `iq_tx:0`, `iq_rx:0`, `noise_power:0`, :151-152,172-183):
+ * tx_signal = complex_clip(x_norm, peak); xn = batch_norm(tx_signal, eps 1e-8)/sqrt(2);
+ * noise = (|a| sin p, |a| cos p), a = sqrt(.5) 10^(-SNR/20) N(0,1), p = U(0, 2 pi) (Philox stream keyed by seed/offset);
+ * iq_rx = fp16(xn + noise) [frames*pairs, 2], iq_tx = fp16(tx_signal), noise_power = mean |noise|^2.
+ * The receiver itself never consumes this branch (`rx_iq_data = iq_tx_re`, :138).  tx_signal / iq_tx / iq_rx nullable. */
+size_t dccn_ingraph_awgn_workspace_size(int frames, int pairs_per_frame);
+int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal, uint16_t* iq_tx_f16,
+                      uint16_t* iq_rx_f16, float* noise_power, int frames, int pairs_per_frame, float peak,
+                      unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
+                      dccn_stream_t stream);
+
 /* One row of the sweep table {c00,c01,c10,c11,ce_sum,count} (float64, device): row6 += the metrics record of the
  * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);

@@ -102,6 +102,11 @@ def test_short_training_run_learns_and_sweeps(tmp_path):
               "global_step", "beta1_power", "beta2_power"):
         assert n in z
     assert float(z["global_step"]) > 0
+    # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:264-265): 2048 fp16 IQ pairs each
+    for suffix in ("txiq", "rxiq"):
+        d = np.loadtxt(os.path.join(str(tmp_path), "OFDM_t_%s.csv" % suffix), delimiter=",")
+        assert d.shape == (2048, 2) and np.isfinite(d).all()
+        assert np.array_equal(d.astype(np.float16).astype(np.float64), d)            # values are fp16-representable
 
 
 def test_checkpoint_round_trip(tmp_path):

@@ -105,3 +105,33 @@ def test_receiver_layout_mapping_is_invertible():
     assert etf["Equalizer/conv3d_1/kernel"].shape == (7, 64, 1, 1, 2)
     assert etf["optimizer/Equalizer/conv3d/kernel/Adam"].shape == (1, 64, 1, 1, 128)
     assert all(np.array_equal(T.eq_from_tf(etf)[k], e[k]) for k in e)
+
+
+def test_v1_bundle_folds_its_second_1x1_conv_and_foreign_variables_raise(tmp_path):
+    """The reference's only real checkpoints (test_v1/model/*, shapes pinned in v1_index_manifest.json) hold an extra
+    demodulation/conv2d_1 layer right behind conv2d with no activation in between: rx_from_tf folds the pair into one
+    affine map (same function), drops what cannot be folded (their Adam slots) and refuses unknown variables."""
+    import json
+    man = json.load(open(os.path.join(HERE, "golden", "v1_index_manifest.json")))
+    name = sorted(k for k in man if "2mod" in k and "cpTrue" in k)[0]
+    rng = np.random.RandomState(0)
+    tensors = {}
+    for var, ent in man[name].items():
+        shp = tuple(ent["shape"])
+        tensors[var] = (rng.randn(*shp) * 0.3).astype(np.float32) if shp else np.float32(0.5)
+    assert "demodulation/conv2d_1/kernel" in tensors
+    T.write_checkpoint(str(tmp_path / "v1"), tensors)
+    got = T.rx_from_tf(T.read_checkpoint(str(tmp_path / "v1")))
+    assert not any(k.startswith("demodulation/conv2d_1") for k in got)
+    assert "demodulation/conv2d/kernel/Adam" not in got and "demodulation/dense/kernel/Adam" in got
+    w1, b1 = tensors["demodulation/conv2d/kernel"][0, 0].astype(np.float64), tensors["demodulation/conv2d/bias"].astype(np.float64)
+    w1b, b1b = tensors["demodulation/conv2d_1/kernel"][0, 0].astype(np.float64), tensors["demodulation/conv2d_1/bias"].astype(np.float64)
+    z = rng.randn(50, 2)
+    two = (z @ w1 + b1) @ w1b + b1b
+    one = z @ got["demodulation/conv2d/kernel"].astype(np.float64) + got["demodulation/conv2d/bias"].astype(np.float64)
+    assert np.abs(two - one).max() < 1e-6
+    assert got["fft_like/conv3d/kernel"].shape == (80, 128) and got["demodulation/dense/kernel"].shape == (1024, 736)
+    bad = dict(tensors)
+    bad["demodulation/dense_7/kernel"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        T.rx_from_tf(bad)
