@@ -64,11 +64,12 @@ def main(argv=None):
     ap.add_argument("--msg_length", type=int, default=100800)
     ap.add_argument("--test_frames", type=int, default=20000)
     args = ap.parse_args(argv)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    torch.cuda.set_device(local)
+    from .config5 import init_distributed
+    # one process per GPU; the process group (backend nccl = RCCL, or DCCN_DIST_BACKEND=gloo for control-flow tests on
+    # a box with fewer GPUs than ranks) is only used as a barrier between the stages: every configuration is trained
+    # and swept by ONE rank (sweeps inside run with world = 1 and never reduce across ranks)
+    rank, world, local = init_distributed()
     if args.awgn:
         for i, (flags, result_dir) in enumerate(configurations(epoch_scale=args.max_epoch_scale)):
             if i % world != rank:
@@ -83,7 +84,6 @@ def main(argv=None):
                 os.replace(res["sweep"][3], csvdest)
     if args.equalizer:
         if world > 1:
-            torch.distributed.is_initialized() or torch.distributed.init_process_group("nccl")
             torch.distributed.barrier()                               # stage 2 reads stage 1's checkpoints
         from . import receiver_mp
         for i, (flags, result_dir) in enumerate(equalizer_configurations(epoch_scale=args.max_epoch_scale,
@@ -100,6 +100,9 @@ def main(argv=None):
             for ch, (_, _, _, path) in res.get("sweep", {}).items():
                 if os.path.isfile(path):
                     os.replace(path, os.path.join(result_dir, os.path.basename(path)))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,163 @@
+"""BASELINE.json configurations as configurations (``-m gpu``): C4 at its full size, C5 scaled down but through the
+same sharded code path, and the N > 1 launch of bench.py (ranks sharing the one GPU of the test box over gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_c4_full_size_qpsk_n1024_585_frames():
+    """BASELINE config[3]: QPSK, N=1024/CP=72, batch 4096 OFDM symbols = 585 frames, F=1024, D=4000 (475 GFLOP per
+    step).  One training step at the full size against the float64 oracle -- R0 on the whole batch, every later stage on
+    a 16-frame row subset (forward) / a 64-column subset (the two weight gradients), each stage evaluated on the GPU's
+    own inputs to it -- then the size-independent properties: confusion counts add up, eager == graph replay bit for
+    bit over two steps."""
+    from dl_ofdm_amd.engine import RxEngine
+    from oracle import dccn_oracle as O
+    from test_gpu_engine import make_case, relerr
+    batch, S, kin, F, D, nb = 585, 7, 1096, 1024, 4000, 2
+    dims, cfg, x, bits, p = make_case(batch, nb, kin=kin, F=F, D=D, seed=8)
+    eng = RxEngine(dims, batch, params=p, train=True, want_prob=True)
+    eng.train_step(x, bits)
+    torch.cuda.synchronize()
+    m, g = eng.metrics(), eng.get_grads()
+    tol = 2e-5                                                     # K up to 14336: a little more fp32 rounding
+    rng = np.random.RandomState(1)
+    fr = np.sort(rng.choice(batch, 16, replace=False))
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    xn, _, _ = O.batch_moment_norm(x.reshape(batch, -1).astype(np.float64))
+    xn = xn.reshape(x.shape)
+    assert relerr(eng.x_norm.cpu().numpy(), xn) <= 1e-5                                          # R0, whole batch
+    fft = O.cconv_gemm_fwd(xn[fr].reshape(16 * S, kin, 2), p64["fft_like/conv3d/kernel"], p64["fft_like/conv3d/bias"])
+    fft_g = eng.fft_out.cpu().numpy()
+    assert relerr(fft_g[fr].reshape(16 * S, F, 2), fft) <= tol                                   # R1
+    a_g = fft_g.astype(np.float64).reshape(batch, -1)
+    z = a_g[fr] @ p64["demodulation/dense/kernel"] + p64["demodulation/dense/bias"]              # R2 on the GPU's fft_out
+    assert relerr(eng.z.cpu().numpy()[fr], z) <= tol
+    zg = eng.z.cpu().numpy().astype(np.float64)
+    tl = O.tail_forward_backward(zg[fr].reshape(16 * D, 2), bits[fr].reshape(16 * D, nb), p64["demodulation/conv2d/kernel"],
+                                 p64["demodulation/conv2d/bias"], p64["demodulation/dense_1/kernel"],
+                                 p64["demodulation/dense_1/bias"], nb)                            # R3-R6 on the GPU's z
+    prob_g = eng.prob.cpu().numpy()
+    assert relerr(prob_g[fr].reshape(-1, 2), tl["prob"].reshape(-1, 2)) <= 1e-5
+    kink = (np.abs(tl["pre1"]).min(1) < 2e-6) | (np.abs(tl["pre2"]).min(1) < 2e-6)
+    dz_g = eng.dz.cpu().numpy().astype(np.float64)
+    dz_sub = tl["dz"] * (16.0 / batch)                             # the oracle averaged over its 16 frames only
+    assert relerr(dz_g[fr].reshape(-1, 2)[~kink], dz_sub[~kink]) <= tol
+    # loss / decisions over ALL cells from the GPU's probabilities (float64 restatement of ofdmreceiver_np.py:154-169)
+    lb = O.loss_ber(prob_g.astype(np.float64), bits)
+    assert abs(m["ce_mean"] - float(lb["ce_mean"])) <= 1e-5 * float(lb["ce_mean"])
+    assert np.array_equal(np.array(m["conf"]), lb["conf"]) and int(np.sum(m["conf"])) == batch * D * nb == m["count"]
+    # backward GEMMs on the GPU's dz / fft_out / x_norm / dfft
+    dfft_g = eng.dfft.cpu().numpy().astype(np.float64)
+    assert relerr(dfft_g[fr].reshape(16, -1), dz_g[fr] @ p64["demodulation/dense/kernel"].T) <= tol
+    cols = np.sort(rng.choice(2 * D, 64, replace=False))
+    assert relerr(g["demodulation/dense/kernel"][:, cols], a_g.T @ dz_g[:, cols]) <= tol
+    assert relerr(g["demodulation/dense/bias"], dz_g.sum(0)) <= tol
+    fsel = np.sort(rng.choice(F, 32, replace=False))
+    xr = eng.x_norm.cpu().numpy().astype(np.float64).reshape(batch * S, kin, 2)
+    d3 = dfft_g.reshape(batch * S, F, 2)[:, fsel, :]
+    xi, xq, dre, dim = xr[..., 0], xr[..., 1], d3[..., 0], d3[..., 1]
+    gk = g["fft_like/conv3d/kernel"]
+    assert relerr(gk[:, fsel], xi.T @ dre - xq.T @ dim) <= tol                                   # dWa (Appendix A.2)
+    assert relerr(gk[:, F + fsel], xi.T @ dim - xq.T @ dre) <= tol                               # dWb
+    assert relerr(g["fft_like/conv3d/bias"][:F], (dfft_g.reshape(-1, F, 2)[..., 0] - dfft_g.reshape(-1, F, 2)[..., 1]).sum(0)) <= tol
+    del eng, g, a_g, zg, dz_g, dfft_g, xr
+    outs = []
+    for graph in (False, True):
+        e = RxEngine(dims, batch, params=p, train=True, want_prob=True)
+        for _ in range(2):
+            e.train_step(x, bits, graph=graph)
+        torch.cuda.synchronize()
+        outs.append((e.params.clone(), e.prob.clone(), e.metrics()["conf"]))
+        del e
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+def test_bench_two_ranks_over_gloo_one_json_line():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (the driver's N > 1 launch) with
+    DCCN_BENCH_BACKEND=gloo so that both ranks may share this box's GPU: one JSON line from rank 0, n_gpus == 2, the
+    reduced BER table holds the bits of both ranks' batches."""
+    env = dict(os.environ, DCCN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--no-kernel-times"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["unit"] == "OFDM symbols/s"
+    t = out["step"]["ber_table"]
+    bits_per_rank = 1170 * 320 * 2
+    assert t[5] == 2 * bits_per_rank and sum(t[:4]) == 2 * bits_per_rank
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-kernel-times"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert o1["n_gpus"] == 1 and o1["step"]["ber_table"][5] == bits_per_rank
+    # whole-job value: both ranks' symbols over the slower rank's time
+    assert out["value"] > 0 and abs(out["value"] - 2 * 6 * 8190 / (out["ms_per_step"] * 6e-3)) <= 1e-6 * out["value"]
+
+
+def _c5_worker(rank, world, port, out_dir, q, kw):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from dl_ofdm_amd import config5
+    r, w, local = config5.init_distributed("gloo")
+    try:
+        trainers = config5.train_models(out_dir, kw["nbits"], kw["frames"], kw["eq_epochs"], kw["scale"], rank=r,
+                                        device="cuda:%d" % local)
+        pts, table = config5.sweep_dccn(trainers, kw["nbits"], kw["channels"], kw["snrs"], kw["frames"], r, w)
+        q.put((r, table))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_c5_scaled_sharded_equals_serial_and_ber_falls_with_snr(tmp_path):
+    """BASELINE config[4] (4 modulations x {EPA, EVA, ETU} x SNRs, DCCN receiver + equaliser) through
+    dl_ofdm_amd.config5 at reduced training length and 4 SNRs: the table sharded over 2 ranks equals the serial one
+    (models are re-trained per rank from the same seeds: the whole pipeline is bitwise reproducible), BER is monotone."""
+    import torch.multiprocessing as mp
+    from dl_ofdm_amd import config5, sweep
+    kw = dict(nbits=(1, 2, 3, 4), channels=config5.CHANNELS, snrs=(-5, 5, 15, 29), frames=2000, eq_epochs=6, scale=0.01)
+    trainers = config5.train_models(str(tmp_path / "serial"), kw["nbits"], kw["frames"], kw["eq_epochs"], kw["scale"])
+    pts, serial = config5.sweep_dccn(trainers, kw["nbits"], kw["channels"], kw["snrs"], kw["frames"])
+    assert len(pts) == 4 * 3 * 4 and serial.shape == (48, 6)
+    del trainers
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 2, port, str(tmp_path / "sharded"), q, kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert np.array_equal(results[r][:, :4], serial[:, :4]) and np.array_equal(results[r][:, 5], serial[:, 5])
+        np.testing.assert_allclose(results[r][:, 4], serial[:, 4], rtol=1e-9)
+    ber, _ = sweep.ber_loss(serial)
+    assert np.all(serial[:, 5] == np.array([kw["frames"] * 320 * p.nbits for p in pts]))
+    for b in range(4):
+        for c in range(3):
+            cur = ber[(b * 3 + c) * 4:(b * 3 + c) * 4 + 4]
+            assert cur[0] > cur[-1] and np.all(np.diff(cur) <= 0.02), (b + 1, config5.CHANNELS[c], cur)
+    assert ber[0] < 0.45 and ber[3] < ber[0]

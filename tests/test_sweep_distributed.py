@@ -85,6 +85,45 @@ def test_world2_gloo_matches_serial():
     assert ber.shape == (20,) and np.all((ber >= 0) & (ber <= 1)) and np.all(loss > 0)
 
 
+def _worker_unshared(rank, world, port, q):
+    """Each rank runs its OWN, different, unsharded sweeps while a process group exists (the experiment driver's stage 2:
+    one configuration per rank) -- rank 1 even runs one sweep more than rank 0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tables = []
+        for k in range(1 + rank):
+            pts = sweep.make_points([1 + rank], ["AWGN"], range(-1 - k, 2), base_seed=50 + 7 * rank + k)
+            tables.append((len(pts), sweep.run_sweep(pts, _evaluate)))          # world defaults to 1: no collective
+        dist.barrier()
+        q.put((rank, tables))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unsharded_sweeps_do_not_reduce_across_an_existing_process_group():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unshared, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0                                             # unequal sweep counts must not dead-lock
+    for rank in (0, 1):
+        assert len(results[rank]) == 1 + rank
+        for k, (n, table) in enumerate(results[rank]):
+            pts = sweep.make_points([1 + rank], ["AWGN"], range(-1 - k, 2), base_seed=50 + 7 * rank + k)
+            serial = sweep.run_sweep(pts, _evaluate)
+            assert n == len(pts) and np.array_equal(table, serial)         # exactly this rank's own numbers
+    import pytest
+    with pytest.raises(RuntimeError):
+        sweep.reduce_table(torch.zeros(2, 6, dtype=torch.float64), world=2)   # sharded but no group: loud
+
+
 def test_csv_and_harness_helpers(tmp_path):
     from dl_ofdm_amd import receiver
     path = tmp_path / "Test_DCCN_tok_AWGN.csv"

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25
+timeout 1700 python -m pytest tests/test_gpu_configs.py -m gpu -q -x --durations=5 2>&1 | tail -30
