@@ -41,9 +41,10 @@ enum TuneKey : int {
     TUNE_DENSE_BWD_SPLITS = 4,  // 0 = automatic
     TUNE_CCONV_BWD_SPLITS = 5,  // 0 = automatic
     TUNE_SMEM_MIN_KB = 6,       // minimum dynamic LDS per block of the gemm16 launches (caps resident blocks per CU)
+    TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_COUNT = 8
 };
-static int g_tune[TUNE_COUNT] = {2, 0, 0, 0, 0, 0, 0, 0};
+static int g_tune[TUNE_COUNT] = {2, 0, 0, 0, 0, 0, 0, 1};
 static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
 // ---------------------------------------------------------------------------------------
@@ -361,12 +362,12 @@ __global__ __launch_bounds__(256) void cconv_fold_finalize_kernel(const float* _
 }
 
 // the split-K C-Conv weight-gradient GEMM with the tail's slab reduction riding on extra blocks of the same launch
-template <bool VEC>
+template <bool VEC, int BK = 64, int NBUF = 2>
 __global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_finalize_kernel(const GemmParams p, int tiles, int gemm_blocks,
                                                                             TailFinalizeArgs a) {
     const int b = (int)blockIdx.x;
     if (b < gemm_blocks) {
-        gemm_block<OP_ICONTIG, OP_ICONTIG, 64, 64, 64, 1, VEC>(p, b % tiles, tiles, b / tiles);
+        gemm_block<OP_ICONTIG, OP_ICONTIG, 64, 64, BK, 1, VEC, NBUF>(p, b % tiles, tiles, b / tiles);
     } else {
         demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
                                  a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
@@ -438,18 +439,31 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     }
     if (defer && fin && p.vecA && p.vecB && (F % 2 == 0)) {
         // fused step: GEMM + tail finalize in one launch; the fold happens inside the optimizer kernel
-        auto kern = cconv_bwd_w_finalize_kernel<true>;
-        constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 64>();
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (smem > 48 * 1024)
+        const int tiles = ceil_div(p.N, 64) * ceil_div(p.M, 64), gemm_blocks = tiles * sp.splits;
+        const dim3 grid(gemm_blocks + tail_finalize_blocks(fin->P));
+        if (sp.klen == 128 && g_whole_k) {
+            // 128 rows per split: the whole k range of a block as one tile (all loads in flight at once, no k-tile barrier)
+            auto kern = cconv_bwd_w_finalize_kernel<true, 128, 1>;
+            constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 128, 1>();
+            static bool attr_done = false;
+            if (!attr_done) {
                 DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_done = true;
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
+        } else {
+            auto kern = cconv_bwd_w_finalize_kernel<true>;
+            constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 64>();
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (smem > 48 * 1024)
+                    DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
         }
-        const int tiles = ceil_div(p.N, 64) * ceil_div(p.M, 64), gemm_blocks = tiles * sp.splits;
-        hipLaunchKernelGGL(kern, dim3(gemm_blocks + tail_finalize_blocks(fin->P)), dim3(kGemmThreads), smem, s, p, tiles,
-                           gemm_blocks, *fin);
         DCCN_LAUNCH_CHECK();
         defer->slabs = slabs; defer->colsum = cs; defer->splits = sp.splits; defer->slab = p.slab;
         return DCCN_OK;
@@ -939,6 +953,7 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
 int dccn_set_tuning(int key, int value) {
     if (key < 0 || key >= TUNE_COUNT || value < 0) return DCCN_ERR_INVALID_ARG;
     g_tune[key] = value;
+    if (key == TUNE_WHOLE_K) g_whole_k = value;
     return DCCN_OK;
 }
 int dccn_get_tuning(int key) { return (key < 0 || key >= TUNE_COUNT) ? DCCN_ERR_INVALID_ARG : g_tune[key]; }

@@ -77,7 +77,7 @@ struct Tile {
     static constexpr bool IC = (KIND == OP_ICONTIG);
     static constexpr bool CC = (KIND == OP_CCONV_W || KIND == OP_CCONV_WT);
     static constexpr int NOFF = CC ? 2 * NV : NV;
-    static_assert(NV >= 1 && (!IC || NV % 4 == 0), "tile too small for the thread block");
+    static_assert(NV >= 1 && (!IC || NV % 4 == 0) && (KIND != OP_CCONV_W || NV % 2 == 0), "tile too small for the thread block");
     float4 r[NV];
     unsigned okmask;        // masked path: bit v = piece v lies inside the k range (applied at LDS-write time)
     unsigned voff[NOFF];    // fast path: byte offsets from the uniform tile base
@@ -108,10 +108,17 @@ struct Tile {
                 const int k = (idx % (BK / 4)) * 4;                 // k offset inside the tile (multiple of 4)
                 if constexpr (KIND == OP_KCONTIG) {
                     voff[v] = (unsigned)((ic * ld + k) * 4);
-                } else if constexpr (KIND == OP_CCONV_W) {        // element (k,i) = Weff[k][i], i = ic fixed
-                    const int f = ic >> 1, c = ic & 1, n0 = k >> 1;
-                    voff[2 * v] = (unsigned)((n0 * 2 * cF + f + (c ? cF : 0)) * 4);       // q = 0, 2 (rows n0, n0+1), +
-                    voff[2 * v + 1] = (unsigned)((n0 * 2 * cF + f + (c ? 0 : cF)) * 4);   // q = 1, 3, negated
+                } else if constexpr (KIND == OP_CCONV_W) {
+                    // pieces 2u, 2u+1 = the Weff columns 2f', 2f'+1 of one (row pair n0, n0+1 ; filter f') unit: lanes
+                    // run over f' first, so the four dword loads of a unit read w rows contiguously (a wave touches
+                    // 2-4 cache lines per load instead of 64)
+                    if ((v & 1) == 0) {
+                        const int uidx = tid + (v >> 1) * kGemmThreads;
+                        const int fl = uidx % (BI / 2), np = uidx / (BI / 2);
+                        const int f = min(i0 / 2 + fl, I / 2 - 1);
+                        voff[2 * v] = (unsigned)(((2 * np) * 2 * cF + f) * 4);            // Wa[n0][f]; Wb at + cF*4
+                        voff[2 * v + 1] = (unsigned)((fl * 2) * LD + 4 * np);             // LDS float offset of column 2f'
+                    }
                 } else {                                          // element (k,i) = Weff[i][k], row i = ic fixed
                     const int n = ic >> 1, qb = ic & 1, f0 = k >> 1;
                     voff[2 * v] = (unsigned)((n * 2 * cF + (qb ? cF : 0) + f0) * 4);      // columns c = 0
@@ -132,12 +139,15 @@ struct Tile {
         if constexpr (KIND == OP_ICONTIG || KIND == OP_KCONTIG) {
             r[v] = *reinterpret_cast<const float4*>(base + voff[v]);
         } else if constexpr (KIND == OP_CCONV_W) {
-            const unsigned row = (unsigned)(2 * cF * 4);
-            const float a0 = *reinterpret_cast<const float*>(base + voff[2 * v]);
-            const float b0 = *reinterpret_cast<const float*>(base + voff[2 * v + 1]);
-            const float a1 = *reinterpret_cast<const float*>(base + voff[2 * v] + row);
-            const float b1 = *reinterpret_cast<const float*>(base + voff[2 * v + 1] + row);
-            r[v] = make_float4(a0, -b0, a1, -b1);
+            if ((v & 1) == 0) {
+                const unsigned row = (unsigned)(2 * cF * 4), half = (unsigned)(cF * 4);
+                const float a0 = *reinterpret_cast<const float*>(base + voff[2 * v]);
+                const float b0 = *reinterpret_cast<const float*>(base + voff[2 * v] + half);
+                const float a1 = *reinterpret_cast<const float*>(base + voff[2 * v] + row);
+                const float b1 = *reinterpret_cast<const float*>(base + voff[2 * v] + row + half);
+                r[v] = make_float4(a0, -b0, a1, -b1);             // column 2f'  : Weff[2n][2f'] = Wa, [2n+1][2f'] = -Wb
+                r[v + 1] = make_float4(b0, -a0, b1, -a1);         // column 2f'+1: Weff[2n][.] = Wb,   [2n+1][.]   = -Wa
+            }
         } else {
             const float2 a = *reinterpret_cast<const float2*>(base + voff[2 * v]);
             const float2 b = *reinterpret_cast<const float2*>(base + voff[2 * v + 1]);
@@ -219,28 +229,35 @@ struct Tile {
                 const bool ok = (okmask >> v) & 1u;
                 val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
             }
-            *reinterpret_cast<float4*>(lds + (idx / (BK / 4)) * LD + (idx % (BK / 4)) * 4) = val;
+            if constexpr (KIND == OP_CCONV_W && !MASKED) {
+                *reinterpret_cast<float4*>(lds + voff[2 * (v & ~1) + 1] + (v & 1) * LD) = val;     // fast-path unit mapping
+            } else {
+                *reinterpret_cast<float4*>(lds + (idx / (BK / 4)) * LD + (idx % (BK / 4)) * 4) = val;
+            }
         }
     }
 };
 
-template <int KA, int KB, int BM, int BN, int BK>
+// NBUF = 2: double-buffered k-tiles; NBUF = 1: the whole k range of a block is ONE tile (short-k GEMMs: every global
+// load of the block is in flight at once and no per-k-tile barrier remains)
+template <int KA, int KB, int BM, int BN, int BK, int NBUF = 2>
 constexpr size_t gemm_smem_bytes() {
-    return (size_t)(2 * BM * Tile<KA, BM, BK>::LD + 2 * BN * Tile<KB, BN, BK>::LD) * sizeof(float);
+    return (size_t)(NBUF * BM * Tile<KA, BM, BK>::LD + NBUF * BN * Tile<KB, BN, BK>::LD) * sizeof(float);
 }
 
 enum PrefetchMode : int { PF_NONE = 0, PF_FAST = 1, PF_MASKED = 2 };
+static int g_whole_k = 1;      // tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges
 
 // One 64x64 / 128x128 output tile (block `L` of `T` tiles, split `z`) of C = A.B
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC>
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC, int NBUF = 2>
 __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, const int T, const int z) {
     using TA = Tile<KA, BM, BK>;
     using TB = Tile<KB, BN, BK>;
     constexpr int LDA = TA::LD, LDB = TB::LD;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                       // [2][BM][LDA]
-    float* sB = smem + 2 * BM * LDA;        // [2][BN][LDB]
+    float* sA = smem;                       // [NBUF][BM][LDA]
+    float* sB = smem + NBUF * BM * LDA;     // [NBUF][BN][LDB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -376,8 +393,10 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
         }
         __syncthreads();
     };
-    for (; t + 1 < nfull; ++t) ktile(std::integral_constant<int, PF_FAST>{});
-    for (; t + 1 < ntiles; ++t) ktile(std::integral_constant<int, PF_MASKED>{});
+    if constexpr (NBUF > 1) {
+        for (; t + 1 < nfull; ++t) ktile(std::integral_constant<int, PF_FAST>{});
+        for (; t + 1 < ntiles; ++t) ktile(std::integral_constant<int, PF_MASKED>{});
+    }
     if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -410,9 +429,9 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
 }
 
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int NBUF = 2>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
-    gemm_block<KA, KB, BM, BN, BK, COLSUM, VEC>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+    gemm_block<KA, KB, BM, BN, BK, COLSUM, VEC, NBUF>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
 }
 
 // Two independent GEMMs in ONE grid (the dense layer's dX = dY.W^T and dW = X^T.dY share dY but not
@@ -431,10 +450,10 @@ __global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_kernel(const G
     }
 }
 
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC>
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int NBUF = 2>
 static int launch_gemm_cfg2(const GemmParams& p, int splits, hipStream_t s) {
-    auto kern = gemm_f32_mfma_kernel<KA, KB, BM, BN, BK, COLSUM, TAG, VEC>;
-    constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK>();
+    auto kern = gemm_f32_mfma_kernel<KA, KB, BM, BN, BK, COLSUM, TAG, VEC, NBUF>;
+    constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK, NBUF>();
     static bool attr_done = false;
     if (!attr_done) {
         if (smem > 48 * 1024)
@@ -486,6 +505,14 @@ template <int KA, int KB, int COLSUM, int TAG>
 static int launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * splits;
     if (big >= 2 * kCUs) return launch_gemm_cfg<KA, KB, 128, 128, 32, COLSUM, TAG>(p, splits, s);
+    // the N=64 C-Conv forward (K = 2*(N+CP) = 160, or 128 without the cyclic prefix): the whole k range as ONE tile --
+    // all of a block's loads are issued together (one exposed memory latency instead of five) and no k-tile barrier
+    if constexpr (KA == OP_KCONTIG && KB == OP_CCONV_W) {
+        if (splits == 1 && p.vecA && p.vecB && g_whole_k) {
+            if (p.K == 160) return launch_gemm_cfg2<KA, KB, 64, 64, 160, COLSUM, TAG, true, 1>(p, splits, s);
+            if (p.K == 128) return launch_gemm_cfg2<KA, KB, 64, 64, 128, COLSUM, TAG, true, 1>(p, splits, s);
+        }
+    }
     // short k ranges that are a multiple of 32 but not of 64 (the C-Conv: K = 2*(N+CP) = 160): 32-deep k-tiles keep
     // every tile on the fast unmasked loaders and do not multiply zeros in a half-empty last tile
     if constexpr (KA != OP_ICONTIG && KB != OP_ICONTIG) {

@@ -174,7 +174,8 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
 /* Kernel-configuration knobs for experiments and profiling (process-wide, not thread-safe against concurrent
  * launches): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
  * (0 = 32x32x2 tile family, >0 = a 16x16x4 configuration), 4/5 split-K counts of the two weight gradients
- * (0 = automatic), 6 minimum LDS per block in KiB.  Set them before workspaces are sized. */
+ * (0 = automatic), 6 minimum LDS per block in KiB, 7 single-tile launches for short k ranges (default 1).
+ * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
 
