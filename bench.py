@@ -104,6 +104,34 @@ def cpu_baseline(c, budget_s=20.0):
                 gemm_form_sample="%d steps, same graph with the C-Conv as a centre-tap GEMM" % out["gemm"]["steps"])
 
 
+def measure_config(name, dev, steps=20, warmup=5):
+    """ms per training step of another BASELINE configuration (same engine, graph replay, HIP-event timing)."""
+    import torch
+    from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine
+    c = CONFIGS[name]
+    dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
+    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
+    eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
+    for _ in range(warmup):
+        eng.train_step(graph=True)
+    torch.cuda.synchronize(dev)
+    t = HipTimer()
+    t.start(eng._stream())
+    for _ in range(steps):
+        eng.train_step(graph=True)
+    t.stop(eng._stream())
+    ms = t.elapsed_ms() / steps
+    fl = step_flops(c)
+    m = eng.metrics()
+    eng.close_graph()
+    return {"workload": c["workload"], "steps": steps, "ms_per_step": ms, "symbols_per_s": c["frames"] * 7 / (ms * 1e-3),
+            "algorithmic_gflop": fl / 1e9, "achieved_tflops": fl / (ms * 1e-3) / 1e12,
+            "mfma_frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "bits_counted": int(m["count"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +142,7 @@ def main():
     ap.add_argument("--fork", action="store_true", help="two-stream graph (dense dW on a forked stream) instead of the grouped dX+dW launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short C3 / C4 measurements of the `configs` object")
     args = ap.parse_args()
 
     import numpy as np
@@ -239,6 +268,12 @@ def main():
                                   "achieved": kt[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": kt[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                                   "avg_launch_us": kt[dom]["ms"] * 1e3, "flops_per_launch": kt[dom]["flops"]}
+        if world == 1 and args.config == "c2" and not args.no_other_configs:
+            # the other BASELINE.json training configurations, measured in the same run (short: <= 20 steps each, hipGraph
+            # replay, HIP events on the launch stream): C3 = config[2] shape (16-QAM), C4 = config[3] (N=1024, MFMA-bound)
+            del eng
+            torch.cuda.empty_cache()
+            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5) for k in ("c3", "c4")}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()

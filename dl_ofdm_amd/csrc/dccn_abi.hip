@@ -288,7 +288,11 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
         defer->splits = sp.splits;
         return DCCN_OK;
     }
-    const SplitPlan sp = plan_splitk(K, N, M);
+    SplitPlan sp = plan_splitk(K, N, M);
+    if (g_tune[TUNE_DENSE_BWD_SPLITS] > 0 && sp.splits > 1) {
+        const int cap = max_splits16(K, N);
+        sp = plan_splitk_n(M, g_tune[TUNE_DENSE_BWD_SPLITS] < cap ? g_tune[TUNE_DENSE_BWD_SPLITS] : cap, 64);
+    }
     Carver c(ws, ws_bytes);
     float* slabs = c.take<float>((size_t)sp.splits * K * N);
     float* cs = c.take<float>((size_t)sp.splits * N);
@@ -406,6 +410,10 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
     const bool v16 = variant > 0 && defer && fin && (kin % 2 == 0) && (F % 2 == 0) && aligned16(x) && aligned16(dout) &&
                      small_enough(rows, 2LL * kin) && small_enough(rows, 2LL * F) && 4LL * kin * F <= 512 * 512;
     SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    if (!v16 && g_tune[TUNE_CCONV_BWD_SPLITS] > 0 && defer && fin && 4LL * kin * F <= 512 * 512) {
+        const int want = g_tune[TUNE_CCONV_BWD_SPLITS];
+        sp = plan_splitk_n(rows, want < kCconvBwMaxSplits ? want : kCconvBwMaxSplits, 64);
+    }
     if (v16) {
         int want = g_tune[TUNE_CCONV_BWD_SPLITS];
         int tm, tn;
@@ -750,6 +758,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     if (!train) return DCCN_OK;
 
     DeferredSlabs ds;
+
     if (side) {
         // two-stream variant: dense dW/db on `side`, dX -> C-Conv dW on the main stream
         DCCN_HIP(hipEventRecord(ev_fork, s));
@@ -767,6 +776,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
     FoldDefer fd;
     fd.slabs = nullptr;
+
     const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
     DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                               L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));

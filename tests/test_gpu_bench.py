@@ -32,3 +32,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "OFDM symbols/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 20 * c["value"]
+    # the other BASELINE training configurations are measured in the same run (C4 = the MFMA-bound regime)
+    o = d["configs"]
+    assert set(o) == {"c3", "c4"}
+    assert o["c3"]["bits_counted"] == 1170 * 320 * 4 and o["c4"]["bits_counted"] == 585 * 4000 * 2
+    for k in o:
+        assert o[k]["ms_per_step"] > 0 and abs(o[k]["mfma_frac"] - o[k]["achieved_tflops"] / 157.3) < 1e-9
+    assert o["c4"]["mfma_frac"] > 0.3 and o["c4"]["algorithmic_gflop"] > 470
