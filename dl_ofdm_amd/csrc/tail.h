@@ -25,6 +25,16 @@ __host__ __device__ constexpr int tail_param_count(int nb) {
 
 __device__ __forceinline__ float leaky_relu(float x) { return fmaxf(kLeaky * x, x); }
 
+// The two softmaxes of a bit pair need exp of a non-positive argument, log of a value in (1, 2] and reciprocals of
+// values in (1, 2]: the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each) do that in 1-2
+// instructions where the IEEE-exact library forms (range reduction, denormal scaling, division fix-up) take 8-12.
+// Error budget: exp2(x*log2e) carries the rounding of the product, |x| * 6e-8 relative (<= 2e-6 for |x| <= 30, on a
+// result that is then <= 1e-13); log and reciprocal stay at 1-2 ulp -- all far inside the 1e-5 parity bound, and the hard
+// decision p1 > p0 is unaffected (both probabilities are the same positive reciprocal times e0 / e1).
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float log_1_2(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct TailBlockMetrics {      // one per block in the workspace
     double ce_sum;
     long long conf[4];
@@ -120,11 +130,11 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
             // softmax over the pair: exp(u - max) is exactly 1 for the larger logit, so one expf suffices
             // (bit-identical to evaluating both); likewise for the second softmax on the probabilities
             const bool u1_big = u1 > u0;
-            const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
+            const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
             const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
-            const float es = e0 + e1;
-            p0[u] = e0 / es;
-            p1[u] = e1 / es;
+            const float res = rcp_fast(e0 + e1);
+            p0[u] = e0 * res;
+            p1[u] = e1 * res;
         }
 #pragma unroll
         for (int u = 0; u < W; ++u) {
@@ -136,11 +146,11 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
             // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
             const bool p1_big = p1[u] > p0[u];
             const float mx2 = p1_big ? p1[u] : p0[u];
-            const float fo = expf(p1_big ? (p0[u] - p1[u]) : (p1[u] - p0[u]));
+            const float fo = exp_nonpos(p1_big ? (p0[u] - p1[u]) : (p1[u] - p0[u]));
             f0[u] = p1_big ? fo : 1.0f;
             f1[u] = p1_big ? 1.0f : fo;
             fs[u] = f0[u] + f1[u];
-            const float lse = logf(fs[u]) + mx2;
+            const float lse = log_1_2(fs[u]) + mx2;
             const float ce = lse - (label ? p1[u] : p0[u]);
             A.ce += (double)(valid[u] ? ce : 0.f);
             const int pred = (p1[u] > p0[u]) ? 1 : 0;    // argmax, first index on ties
@@ -155,7 +165,7 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
 #pragma unroll
             for (int u = 0; u < W; ++u) {
                 const int label = lab[u][j];
-                const float rfs = 1.0f / fs[u];
+                const float rfs = rcp_fast(fs[u]);
                 const float q0 = f0[u] * rfs, q1 = f1[u] * rfs;
                 const float g0 = (q0 - (label ? 0.f : 1.f)) * inv_eff[u];
                 const float g1 = (q1 - (label ? 1.f : 0.f)) * inv_eff[u];
@@ -432,17 +442,17 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
         const float p20 = s0 + swl[oB2 + 2 * q], p21 = s1 + swl[oB2 + 2 * q + 1];
         const float u0 = leaky_relu(p20), u1 = leaky_relu(p21);
         const bool u1_big = u1 > u0;
-        const float eo = expf(u1_big ? (u0 - u1) : (u1 - u0));
+        const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
         const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
-        const float es = e0 + e1;
-        const float p0 = e0 / es, p1 = e1 / es;
+        const float res = rcp_fast(e0 + e1);
+        const float p0 = e0 * res, p1 = e1 * res;
         if (WRITE_PROB) *reinterpret_cast<float2*>(prob + (cell * NB + q) * 2) = make_float2(p0, p1);
         const bool p1_big = p1 > p0;
         const float mx2 = p1_big ? p1 : p0;
-        const float fo = expf(p1_big ? (p0 - p1) : (p1 - p0));
+        const float fo = exp_nonpos(p1_big ? (p0 - p1) : (p1 - p0));
         const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
         const float fs = f0 + f1;
-        const float lse = logf(fs) + mx2;
+        const float lse = log_1_2(fs) + mx2;
         ce_acc += (double)(lse - (label ? p1 : p0));
         const int pred = (p1 > p0) ? 1 : 0;
         const int l1 = label != 0 ? 1 : 0;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
         c10 += l1 & (1 - pred);
         c11 += l1 & pred;
         // backward of this lane's bit
-        const float rfs = 1.0f / fs;
+        const float rfs = rcp_fast(fs);
         const float q0 = f0 * rfs, q1 = f1 * rfs;
         const float ga = (q0 - (label ? 0.f : 1.f)) * inv_count;
         const float gb = (q1 - (label ? 1.f : 0.f)) * inv_count;

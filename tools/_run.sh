@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -4
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_now.json; cut -c1-250 gpurun_out/bench_now.json
+echo -n "default: "; python tools/opbench.py dense_tail_fwd_bwd tail_fwd_bwd step --iters 200 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
+echo -n "c3 default: "; python tools/opbench.py tail_fwd_bwd step --iters 100 --config c3 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
+echo -n "noslp: "; DCCN_LIB_PATH=$GRAFT_REPO_ROOT/dl_ofdm_amd/lib/libdccn_noslp.so python tools/opbench.py dense_tail_fwd_bwd tail_fwd_bwd step --iters 200 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
+echo -n "c3 noslp: "; DCCN_LIB_PATH=$GRAFT_REPO_ROOT/dl_ofdm_amd/lib/libdccn_noslp.so python tools/opbench.py tail_fwd_bwd step --iters 100 --config c3 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
