@@ -161,3 +161,31 @@ def test_c5_scaled_sharded_equals_serial_and_ber_falls_with_snr(tmp_path):
             cur = ber[(b * 3 + c) * 4:(b * 3 + c) * 4 + 4]
             assert cur[0] > cur[-1] and np.all(np.diff(cur) <= 0.02), (b + 1, config5.CHANNELS[c], cur)
     assert ber[0] < 0.45 and ber[3] < ber[0]
+
+
+def test_classical_receivers_on_device_generated_frames():
+    """SURVEY.md 8(f-4) row on the GPU box: the LS / LMMSE / CP-enhanced baseline receivers of dl_ofdm_amd.benchmark fed
+    with frames from the device-side generator (the data the DCCN sweeps use) reproduce, within sampling error, their BER
+    on the host substrate's frames -- and perfect CSI (H from the generator's own channel kernel) beats the estimators."""
+    from dl_ofdm_amd import benchmark as B, ofdm, radio, receiver as R
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    for nbits, ch, snr in ((2, "EPA", 15.0), (1, "ETU", 20.0)):
+        F = R.Flags(nbits=nbits, channel=ch, nfilter=64)
+        o = ofdm.ofdm_tx(F)
+        rxr = B.ClassicalReceiver(F, o)
+        fading = radio.rayleigh_chan_lte(F, o.Fs)
+        adv = rxr.advance_of(fading)
+        gen = DeviceDataGen(F, o, device="cuda", seed=11)
+        n = 1200
+        x, bits, _, H = gen.make_batch(n, snr, want_H=True)
+        x, bits = x.cpu().numpy(), bits.cpu().numpy()
+        H = H.cpu().numpy()                                             # complex [n, K] (static channel)
+        Hs = np.repeat(H[:, None, :], o.nSymbol, axis=1) if H.ndim == 2 else H
+        dev_ber = {m: float(np.mean(rxr.receive(x, m, snr, H_true=Hs, R_long=rxr.long_term_correlation(fading),
+                                                 advance=adv) != bits))
+                   for m in ("Perfect", "LS-Spline", "ALMMSE", "LS-CP", "LMMSE-Fast")}
+        host_ber = {m: float(B.ber_curve(F, m, [snr], n_frames=n, seed=3)[0]) for m in dev_ber}
+        for m in dev_ber:
+            tol = 5.0 * np.sqrt(max(host_ber[m], 1e-4) / (n * 320 * nbits) * 40.0) + 0.15 * host_ber[m]   # frames are correlated cells
+            assert abs(dev_ber[m] - host_ber[m]) <= tol, (ch, m, dev_ber[m], host_ber[m])
+        assert dev_ber["Perfect"] <= min(dev_ber["LS-Spline"], dev_ber["ALMMSE"], dev_ber["LS-CP"]) + 1e-4, dev_ber
