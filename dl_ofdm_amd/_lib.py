@@ -105,6 +105,8 @@ SIGNATURES = {
     "dccn_dense_tail_workspace_size": (_sz, [_i, _i, _i]),
     "dccn_dense_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_dense_tail_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "dccn_cconv_im2col": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
+    "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
     "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),
     "dccn_ingraph_awgn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),

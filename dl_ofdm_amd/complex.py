@@ -127,19 +127,6 @@ def _live_taps(in_size: int, k: int, stride: int, out: int, pad_before: int) -> 
     return [a for a in range(k) if any(0 <= o * stride + a - pad_before < in_size for o in range(out))]
 
 
-def _gather_axis(x: torch.Tensor, axis: int, in_size: int, taps: List[int], stride: int, out: int, pad_before: int):
-    """im2col along one axis: returns x with `axis` replaced by (out, len(taps)) -- zero where padded."""
-    idx = torch.tensor([[o * stride + a - pad_before for a in taps] for o in range(out)], device=x.device)
-    valid = (idx >= 0) & (idx < in_size)
-    g = x.index_select(axis, idx.clamp(0, in_size - 1).reshape(-1))
-    shp = list(x.shape)
-    g = g.reshape(shp[:axis] + [out, len(taps)] + shp[axis + 1:])
-    if not bool(valid.all()):
-        mask = valid.to(x.dtype).reshape([1] * axis + [out, len(taps)] + [1] * (len(shp) - axis - 1))
-        g = g * mask
-    return g
-
-
 def _split_complex(inputs: torch.Tensor):
     return torch.stack([inputs.real, inputs.imag], dim=-1).to(torch.float32)
 
@@ -164,7 +151,7 @@ def nn_conv1d_complex(inputs: torch.Tensor, filter: torch.Tensor) -> torch.Tenso
     k = filter.shape[0]
     out, p0, _ = tf_padding(L, k, 1, "same")
     taps = list(range(k))
-    g = _gather_axis(inputs, 1, L, taps, 1, out, p0)                   # [B, L, k, C, 2]
+    g = ops.cconv_im2col(inputs.reshape(B, L, 1, C, 2), out, 1, taps, [0], (1, 1), (p0, 0))      # [B*L, k*C, 2]
     rows = g.reshape(B * L, k * C * 2)                                    # interleaved (tap, c, iq)
     fr, fi = filter[..., 0, 0].reshape(k * C), filter[..., 0, 1].reshape(k * C)
     w = torch.stack([torch.stack([fr, fi], dim=-1), torch.stack([-fi, fr], dim=-1)], dim=1)   # [kC, iq_in, 2]
@@ -190,10 +177,10 @@ def _cconv_lower(x5: torch.Tensor, filters: int, ksize, strides, padding: str, s
         # big one-channel 'same' kernel (equaliser smoothing conv, model.py:428): im2col would blow the
         # image up kL*kW-fold, so run it as a block-Toeplitz dense layer instead
         return ops.cconv2d_same(x5[:, :, :, 0, :], kern.view(kL, kW, 2), bias).view(B, L, Wd, 1, 2)
-    g = _gather_axis(x5, 1, L, tl, sL, Lo, pl0)                        # [B, Lo, tl, Wd, C, 2]
-    g = _gather_axis(g, 3, Wd, tw, sW, Wo, pw0)                          # [B, Lo, tl, Wo, tw, C, 2]
-    g = g.permute(0, 1, 3, 2, 4, 5, 6)                                   # [B, Lo, Wo, tl, tw, C, 2]
-    rows = g.reshape(B * Lo * Wo, len(tl) * len(tw) * C, 2)
+    if len(tl) == 1 and len(tw) == 1 and (sL, sW) == (1, 1) and Lo == L and Wo == Wd and tl[0] == pl0 and tw[0] == pw0:
+        rows = x5.reshape(B * L * Wd, C, 2)                               # one live tap over the input itself: no gather
+    else:
+        rows = ops.cconv_im2col(x5, Lo, Wo, tl, tw, (sL, sW), (pl0, pw0))  # HIP patch gather [B*Lo*Wo, tl*tw*C, 2]
     out = ops.cconv_gemm(rows, kern.reshape(-1, 2 * filters), bias)
     return out.view(B, Lo, Wo, filters, 2)
 

@@ -11,6 +11,7 @@
 #include "gemm16.h"
 #include "equalizer.h"
 #include "datagen.h"
+#include "im2col.h"
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
@@ -1429,6 +1430,32 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
                            noise_power);
         DCCN_LAUNCH_CHECK();
     }
+    return DCCN_OK;
+}
+
+// ---- patch gather of the general-k complex convolutions -----------------------------------------------------
+static bool im2col_geom_ok(const Im2colGeom& g) {
+    return g.B > 0 && g.L > 0 && g.Wd > 0 && g.C > 0 && g.Lo > 0 && g.Wo > 0 && g.ntl > 0 && g.ntw > 0 && g.sL > 0 && g.sW > 0 &&
+           g.tl0 >= 0 && g.tw0 >= 0 && g.pl0 >= 0 && g.pw0 >= 0;
+}
+int dccn_cconv_im2col(const float* x, float* rows, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
+                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
+    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
+    if (!x || !rows || !im2col_geom_ok(g)) return DCCN_ERR_INVALID_ARG;
+    const long long n = (long long)B * Lo * Wo * ntl * ntw * C;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)x, (float2*)rows, g, n);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
+                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
+    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
+    if (!drows || !dx || !im2col_geom_ok(g)) return DCCN_ERR_INVALID_ARG;
+    const long long n = (long long)B * L * Wd * C;
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)drows, (float2*)dx, g, n);
+    DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 

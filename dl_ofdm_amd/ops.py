@@ -150,6 +150,42 @@ class _CConvGemm(torch.autograd.Function):
         return dx, dw, db
 
 
+class _Im2col(torch.autograd.Function):
+    """dccn_cconv_im2col / _col2im: the patch gather in front of the C-Conv GEMM and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        _need_cuda(x); _f32(x)
+        B, L, Wd, C, _ = x.shape
+        Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0 = geom
+        rows = torch.empty(B * Lo * Wo, ntl * ntw * C, 2, dtype=torch.float32, device=x.device)
+        check(_lib.load().dccn_cconv_im2col(_p(x), _p(rows), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0,
+                                            _stream()), "dccn_cconv_im2col")
+        ctx.geom, ctx.shape = geom, (B, L, Wd, C)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        B, L, Wd, C = ctx.shape
+        Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0 = ctx.geom
+        drows = drows.contiguous()
+        dx = torch.empty(B, L, Wd, C, 2, dtype=torch.float32, device=drows.device)
+        check(_lib.load().dccn_cconv_col2im(_p(drows), _p(dx), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0,
+                                            _stream()), "dccn_cconv_col2im")
+        return dx, None
+
+
+def cconv_im2col(x: torch.Tensor, Lo: int, Wo: int, taps_l, taps_w, strides, pads) -> torch.Tensor:
+    """x [B, L, Wd, C, 2] -> patch rows [B*Lo*Wo, len(taps_l)*len(taps_w)*C, 2] (zeros in the SAME padding); taps_* are
+    the contiguous live-tap ranges, strides (sL, sW), pads (pad_before_L, pad_before_W).  Differentiable."""
+    tl, tw = list(taps_l), list(taps_w)
+    if tl != list(range(tl[0], tl[0] + len(tl))) or tw != list(range(tw[0], tw[0] + len(tw))):
+        raise ValueError("live taps must form a contiguous range")
+    geom = (int(Lo), int(Wo), len(tl), len(tw), int(tl[0]), int(tw[0]), int(strides[0]), int(strides[1]), int(pads[0]),
+            int(pads[1]))
+    return _Im2col.apply(x.contiguous(), geom)
+
+
 def cconv_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """Complex convolution in GEMM form (complex.py:140-196 after im2col).
 

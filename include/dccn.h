@@ -155,6 +155,15 @@ int dccn_dense_tail_fwd_bwd(const float* x, const float* w, const float* bias, f
                             int M, int K, int N, int nbits, void* workspace, size_t workspace_bytes,
                             dccn_stream_t stream);
 
+/* Patch gather in front of dccn_cconv_gemm_* for the general-k cases of dev/py/complex.py:51-92 / :140-196 (k taps over
+ * one or two axes, strides, TF SAME / VALID geometry): x [B, L, Wd, C, 2] -> rows [B*Lo*Wo, ntl*ntw*C, 2], zeros where
+ * SAME padding lies; only the live taps tl0..tl0+ntl-1 / tw0..tw0+ntw-1 (those that ever meet data) are gathered.
+ * _col2im is its adjoint: dx [B, L, Wd, C, 2] = sum of the patch entries that read each input element (deterministic). */
+int dccn_cconv_im2col(const float* x, float* rows, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
+                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream);
+int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
+                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream);
+
 /* The in-graph AWGN monitor branch of the receiver graph (dev/py/radio.py:62-88 AWGN_channel, called at
  * dev/py/ofdmreceiver_np.py:136; tensors `tx_signal:0`, `iq_tx:0`, `iq_rx:0`, `noise_power:0`, :151-152,172-183):
  * tx_signal = complex_clip(x_norm, peak); xn = batch_norm(tx_signal, eps 1e-8)/sqrt(2);

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_configs.py -m gpu -q -x -k classical 2>&1 | tail -12
+timeout 1200 python tools/eq_trajectory.py --steps 200 --out gpurun_out/eq_traj.csv 2>&1 | grep -v amdgpu | tail -14
