@@ -104,8 +104,8 @@ def cpu_baseline(c, budget_s=20.0):
                 gemm_form_sample="%d steps, same graph with the C-Conv as a centre-tap GEMM" % out["gemm"]["steps"])
 
 
-def measure_config(name, dev, steps=20, warmup=5):
-    """ms per training step of another BASELINE configuration (same engine, graph replay, HIP-event timing)."""
+def measure_config(name, dev, steps=20, warmup=5, graph=False):
+    """ms per training step of another BASELINE configuration (same engine and launch mode, HIP-event timing)."""
     import torch
     from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine
     c = CONFIGS[name]
@@ -116,12 +116,12 @@ def measure_config(name, dev, steps=20, warmup=5):
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
     eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
     for _ in range(warmup):
-        eng.train_step(graph=True)
+        eng.train_step(graph=graph)
     torch.cuda.synchronize(dev)
     t = HipTimer()
     t.start(eng._stream())
     for _ in range(steps):
-        eng.train_step(graph=True)
+        eng.train_step(graph=graph)
     t.stop(eng._stream())
     ms = t.elapsed_ms() / steps
     fl = step_flops(c)
@@ -138,7 +138,10 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--no-graph", action="store_true", help="eager launch sequence instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="hipGraph replay of the captured step instead of stream launches (measured slower on ROCm 7.2: "
+                         "every graph kernel node pays ~0.9 us more than a same-stream launch, DESIGN.md section 5)")
+    ap.add_argument("--no-graph", action="store_true", help="(default since round 2) eager launch sequence")
     ap.add_argument("--fork", action="store_true", help="two-stream graph (dense dW on a forked stream) instead of the grouped dX+dW launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
@@ -183,7 +186,7 @@ def main():
     g.manual_seed(1234 + rank)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
     eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
-    use_graph, fork = not args.no_graph, args.fork
+    use_graph, fork = (args.graph or args.fork) and not args.no_graph, args.fork
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -273,7 +276,7 @@ def main():
             # replay, HIP events on the launch stream): C3 = config[2] shape (16-QAM), C4 = config[3] (N=1024, MFMA-bound)
             del eng
             torch.cuda.empty_cache()
-            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5) for k in ("c3", "c4")}
+            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph) for k in ("c3", "c4")}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()

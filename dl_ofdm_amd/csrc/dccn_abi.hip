@@ -45,7 +45,7 @@ enum TuneKey : int {
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_COUNT = 8
 };
-static int g_tune[TUNE_COUNT] = {2, 0, 0, 0, 0, 0, 0, 1};
+static int g_tune[TUNE_COUNT] = {9, 0, 0, 0, 0, 0, 0, 1};
 static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
 // ---------------------------------------------------------------------------------------
@@ -605,6 +605,7 @@ static int dense_tail_launch(int variant, const GemmParams& p, const TailEpiPara
         case 6: return launch_dense_tail16<2, 2, 2, 2, 64, 2, NB, BWD>(p, tp, s, sm);
         case 7: return launch_dense_tail16<2, 2, 1, 2, 32, 1, NB, BWD>(p, tp, s, sm);     // 32x64
         case 8: return launch_dense_tail16<1, 4, 2, 1, 64, 2, NB, BWD>(p, tp, s, sm);
+        case 9: return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);  // 48x64, loads two k-tiles ahead
         default: return DCCN_ERR_INVALID_ARG;
     }
 }

@@ -65,7 +65,7 @@ struct Tile16 {
     static constexpr int NU = (UNITS + NT - 1) / NT;
     static constexpr int NV = IC ? 4 * NU : NU;          // float4 registers = global loads = LDS stores per thread
     static constexpr int NOFF = CC ? 2 * NV : NV;
-    float4 r[NV];
+    float4 r[2][NV];            // staging registers; set 1 only exists in the prefetch-distance-2 loop
     unsigned voff[NOFF];        // fast path: byte offsets from the uniform tile base
     unsigned soff[NU];          // LDS float offset of the unit
     unsigned okmask;
@@ -113,16 +113,16 @@ struct Tile16 {
         else return reinterpret_cast<const char*>(p + (size_t)(k0 >> 1) * 2 * cF);
     }
     // ---- fast path: k-tiles completely inside the k range; address = uniform tile base + per-thread constant ----
-    __device__ __forceinline__ void load_fast(int v, const char* __restrict__ base, int cF) {
+    __device__ __forceinline__ void load_fast(int v, const char* __restrict__ base, int cF, int s = 0) {
         if constexpr (!CC) {
-            r[v] = *reinterpret_cast<const float4*>(base + voff[v]);
+            r[s][v] = *reinterpret_cast<const float4*>(base + voff[v]);
         } else {
             const unsigned row = (unsigned)(2 * cF * 4);
             const float a0 = *reinterpret_cast<const float*>(base + voff[2 * v]);
             const float b0 = *reinterpret_cast<const float*>(base + voff[2 * v + 1]);
             const float a1 = *reinterpret_cast<const float*>(base + voff[2 * v] + row);
             const float b1 = *reinterpret_cast<const float*>(base + voff[2 * v + 1] + row);
-            r[v] = make_float4(a0, -b0, a1, -b1);
+            r[s][v] = make_float4(a0, -b0, a1, -b1);
         }
     }
 
@@ -136,16 +136,16 @@ struct Tile16 {
             int i4, k4;
             ic_coords(idx, i4, k4);
             const int k = k0 + 4 * k4 + (v & 3);
-            r[v] = *reinterpret_cast<const float4*>(p + (size_t)min(k, K - 1) * ld + min(i0 + 4 * i4, I - 4));
+            r[0][v] = *reinterpret_cast<const float4*>(p + (size_t)min(k, K - 1) * ld + min(i0 + 4 * i4, I - 4));
             okmask = (okmask & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
         } else {
             const int ic = min(i0 + idx / K4, I - 1);
             const int k = k0 + (idx % K4) * 4;
             const int kc = min(k, K - 4);
             if constexpr (KIND == OP_KCONTIG) {
-                r[v] = *reinterpret_cast<const float4*>(p + (size_t)ic * ld + kc);
+                r[0][v] = *reinterpret_cast<const float4*>(p + (size_t)ic * ld + kc);
             } else {
-                r[v] = make_float4(cconv_weff(p, cF, kc, ic), cconv_weff(p, cF, kc + 1, ic), cconv_weff(p, cF, kc + 2, ic),
+                r[0][v] = make_float4(cconv_weff(p, cF, kc, ic), cconv_weff(p, cF, kc + 1, ic), cconv_weff(p, cF, kc + 2, ic),
                                    cconv_weff(p, cF, kc + 3, ic));
             }
             okmask = (okmask & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
@@ -154,10 +154,10 @@ struct Tile16 {
 
     // v must be a compile-time constant after unrolling
     template <bool MASKED>
-    __device__ __forceinline__ void store_piece(int v, float* __restrict__ lds) const {
+    __device__ __forceinline__ void store_piece(int v, float* __restrict__ lds, int s = 0) const {
         if constexpr (IC) {
             const int b = v & ~3, q = v & 3;               // row i = 4*i4 + q of the transposed block
-            float4 val = make_float4(f4c(r[b + 0], q), f4c(r[b + 1], q), f4c(r[b + 2], q), f4c(r[b + 3], q));
+            float4 val = make_float4(f4c(r[s][b + 0], q), f4c(r[s][b + 1], q), f4c(r[s][b + 2], q), f4c(r[s][b + 3], q));
             if constexpr (MASKED) {
                 val.x = ((okmask >> (b + 0)) & 1u) ? val.x : 0.f;
                 val.y = ((okmask >> (b + 1)) & 1u) ? val.y : 0.f;
@@ -166,7 +166,7 @@ struct Tile16 {
             }
             *reinterpret_cast<float4*>(lds + soff[v / 4] + q * LD) = val;
         } else {
-            float4 val = r[v];
+            float4 val = r[s][v];
             if constexpr (MASKED) {
                 const bool ok = (okmask >> v) & 1u;
                 val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
@@ -192,7 +192,11 @@ struct Cfg16 {
 };
 
 // One BM x BN output tile (block `L` of `T` tiles, grid split `z`) of C = A.B
-template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int EPI, int NB, bool BWD>
+// PD = 2: global loads run TWO k-tiles ahead of the MFMAs (second staging register set, loop unrolled by two): with a
+// single block per CU nothing else covers the ~0.6 us load latency, which is longer than half a 48x64x64 tile's MFMA
+// time; needs the whole k range on the fast loaders (else the block falls back to the PD = 1 schedule).
+template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int EPI, int NB, bool BWD,
+          int PD = 1>
 __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiParams& tp, const int L, const int T,
                                              const int z, const int slab) {
     static_assert(WGM * WGN == 4, "four waves per wave set");
@@ -253,6 +257,13 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
                 }
     }
 
+    // EPI_TAIL: this lane's bias values are requested before the k-loop as well
+    float bjv[(EPI == EPI_TAIL) ? TN : 1];
+    if constexpr (EPI == EPI_TAIL) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bjv[b] = p.bias != nullptr ? p.bias[min(n0 + wn0 + b * 16 + l15, p.N - 1)] : 0.f;
+    }
+
     TA ta;
     TB tb;
     ta.init(p.lda, m0, p.M, p.cF, tid);
@@ -293,13 +304,14 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
     __syncthreads();
 
     // k-tile body: NSTEP steps of TM*TN MFMAs; the operand fragments of the next 16-deep group are read while the
-    // current group's MFMAs run, the next k-tile's global loads go out in the first half of the steps and are written
-    // to the other LDS buffer in the second half.
+    // current group's MFMAs run; the global loads of k-tile t+DIST go out in the first half of the steps (register set
+    // LSET) and the registers holding k-tile t+1 (set SSET) are written to the other LDS buffer in the second half.
     int t = 0;
-    auto ktile = [&](auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
+    auto ktile2 = [&](auto load_tag, auto store_tag, auto lset_tag, auto sset_tag, auto dist_tag) {
+        constexpr int LMODE = decltype(load_tag)::value, SMODE = decltype(store_tag)::value;
+        constexpr int LSET = decltype(lset_tag)::value, SSET = decltype(sset_tag)::value, DIST = decltype(dist_tag)::value;
         const int cur = t & 1;
-        const int k0n = kbeg + (t + 1) * BK;
+        const int k0n = kbeg + (t + DIST) * BK;
         const float* As = sA + cur * BM * LDA + (wm0 + l15) * LDA + 4 * kg + 16 * NGS * set;
         const float* Bs = sB + cur * BN * LDB + (wn0 + l15) * LDB + 4 * kg + 16 * NGS * set;
         float* An = sA + (cur ^ 1) * BM * LDA;
@@ -322,10 +334,17 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int step = g * 4 + j;
-                if constexpr (MODE != PF_NONE && !(GEMM16_ABL & 1)) {
+                if constexpr (LMODE != PF_NONE && !(GEMM16_ABL & 1)) {
                     if (step < HALF) {
 #pragma unroll
-                        for (int q = step * LPS; q < (step + 1) * LPS && q < PA + PB; ++q) load_ab(mode_tag, q, k0n);
+                        for (int q = step * LPS; q < (step + 1) * LPS && q < PA + PB; ++q) {
+                            if constexpr (LMODE == PF_FAST) {
+                                if (q < PA) ta.load_fast(q, TA::tile_base(p.A, p.lda, k0n, p.cF), p.cF, LSET);
+                                else tb.load_fast(q - PA, TB::tile_base(p.B, p.ldb, k0n, p.cF), p.cF, LSET);
+                            } else {
+                                load_ab(load_tag, q, k0n);
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -336,11 +355,13 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(fa[g & 1][a], j), f4c(fb[g & 1][b], j),
                                                                          acc[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (MODE != PF_NONE && !(GEMM16_ABL & 2)) {
+                if constexpr (SMODE != PF_NONE && !(GEMM16_ABL & 2)) {
                     if (step >= HALF) {
 #pragma unroll
-                        for (int q = (step - HALF) * LPS; q < (step - HALF + 1) * LPS && q < PA + PB; ++q)
-                            store_ab(mode_tag, q, An, Bn);
+                        for (int q = (step - HALF) * LPS; q < (step - HALF + 1) * LPS && q < PA + PB; ++q) {
+                            if (q < PA) ta.template store_piece<SMODE == PF_MASKED>(q, An, SSET);
+                            else tb.template store_piece<SMODE == PF_MASKED>(q - PA, Bn, SSET);
+                        }
                     }
                 }
             }
@@ -354,10 +375,43 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
             }
         }
         if constexpr (!(GEMM16_ABL & 4)) __syncthreads();
+        ++t;
     };
-    for (; t + 1 < nfull; ++t) ktile(std::integral_constant<int, PF_FAST>{});
-    for (; t + 1 < ntiles; ++t) ktile(std::integral_constant<int, PF_MASKED>{});
-    if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using TF = std::integral_constant<int, PF_FAST>;
+    using TM_ = std::integral_constant<int, PF_MASKED>;
+    using TN_ = std::integral_constant<int, PF_NONE>;
+    bool deep = false;
+    if constexpr (PD == 2) deep = nfull == ntiles && ntiles >= 2;
+    if (deep) {
+        // k-tile n travels through register set n & 1; tile 1 is already in flight when the first MFMA issues
+#pragma unroll
+        for (int q = 0; q < PA + PB; ++q) {
+            if (q < PA) ta.load_fast(q, TA::tile_base(p.A, p.lda, kbeg + BK, p.cF), p.cF, 1);
+            else tb.load_fast(q - PA, TB::tile_base(p.B, p.ldb, kbeg + BK, p.cF), p.cF, 1);
+        }
+        while (t + 3 < ntiles) {                              // t even here
+            ktile2(TF{}, TF{}, I0{}, I1{}, I2{});
+            ktile2(TF{}, TF{}, I1{}, I0{}, I2{});
+        }
+        const int rem = ntiles - t;                           // 1..3 tiles left, t even
+        if (rem == 3) {
+            ktile2(TF{}, TF{}, I0{}, I1{}, I2{});
+            ktile2(TN_{}, TF{}, I1{}, I0{}, I2{});
+            ktile2(TN_{}, TN_{}, I0{}, I0{}, I2{});
+        } else if (rem == 2) {
+            ktile2(TN_{}, TF{}, I0{}, I1{}, I2{});
+            ktile2(TN_{}, TN_{}, I0{}, I0{}, I2{});
+        } else {
+            ktile2(TN_{}, TN_{}, I0{}, I0{}, I2{});
+        }
+    } else {
+        while (t + 1 < nfull) ktile2(TF{}, TF{}, I0{}, I0{}, I1{});
+        while (t + 1 < ntiles) ktile2(TM_{}, TM_{}, I0{}, I0{}, I1{});
+        if (ntiles > 0) ktile2(TN_{}, TN_{}, I0{}, I0{}, I1{});
+    }
 
     if (COLSUM && do_cs) {
         const int col = n0 + tid;
@@ -440,7 +494,7 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
             for (int b = 0; b < TN; ++b) {
                 const int col = n0 + wn0 + b * 16 + l15;   // this lane's own column
                 const int colc = min(col, p.N - 1);
-                const float bj = p.bias != nullptr ? p.bias[colc] : 0.f;
+                const float bj = bjv[b];
                 float own[4], oth[4];
                 if constexpr (KS == 1) {
 #pragma unroll
@@ -516,9 +570,10 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
 }
 
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator
-template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int EPI, int NB, bool BWD, int TAG>
+template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int EPI, int NB, bool BWD, int TAG,
+          int PD = 1>
 __global__ __launch_bounds__(256 * KS) void gemm16_kernel(const GemmParams p, const TailEpiParams tp) {
-    gemm16_block<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI, NB, BWD>(p, tp, (int)blockIdx.x, (int)gridDim.x,
+    gemm16_block<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI, NB, BWD, PD>(p, tp, (int)blockIdx.x, (int)gridDim.x,
                                                                         (int)blockIdx.z, (int)blockIdx.x);
 }
 
@@ -581,10 +636,10 @@ static int launch_gemm16(const GemmParams& p, int splits, hipStream_t s, size_t 
 }
 
 // dense forward + fused tail
-template <int WGM, int WGN, int TM, int TN, int BK, int KS, int NB, bool BWD>
+template <int WGM, int WGN, int TM, int TN, int BK, int KS, int NB, bool BWD, int PD = 1>
 static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hipStream_t s, size_t smem_min = 0) {
     using CF = Cfg16<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS>;
-    auto kern = gemm16_kernel<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS, 0, EPI_TAIL, NB, BWD, TAG_DENSE_FWD>;
+    auto kern = gemm16_kernel<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS, 0, EPI_TAIL, NB, BWD, TAG_DENSE_FWD, PD>;
     size_t smem = CF::smem_bytes(tail_reduce_lds_floats<NB, BWD>(CF::NT));
     if (smem < smem_min) smem = smem_min;
     static size_t attr_for = 0;
