@@ -9,6 +9,7 @@
 #include "norm_adam.h"
 #include "tail.h"
 #include "gemm16.h"
+#include "gemm_kmajor.h"
 #include "equalizer.h"
 #include "datagen.h"
 #include "im2col.h"
@@ -45,7 +46,8 @@ enum TuneKey : int {
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_COUNT = 8
 };
-static int g_tune[TUNE_COUNT] = {9, 0, 0, 0, 0, 0, 0, 1};
+static int g_tune[TUNE_COUNT] = {9, 7, 0, 0, 0, 0, 0, 1};
+constexpr int kDenseBwdKmajor = 7;   // TUNE_DENSE_BWD value: dW in the k-major form of gemm_kmajor.h (dX as variant 0)
 static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
 // ---------------------------------------------------------------------------------------
@@ -210,7 +212,11 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     }
     p.C = slabs;
     p.colsum = dbias ? cs : nullptr;
-    DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
+    const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * sp.splits;
+    if (g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor && kmajor_ok(p) && big < 2 * kCUs)
+        DCCN_TRY((launch_kmajor<1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
+    else
+        DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
     if (defer) {
         defer->dw_slabs = slabs;
         defer->db_slabs = dbias ? cs : nullptr;
@@ -263,7 +269,7 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     pw.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
     pw.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     const bool vec = px.vecA && px.vecB && pw.vecA && pw.vecB;
-    const int variant = g_tune[TUNE_DENSE_BWD];
+    const int variant = g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor ? 0 : g_tune[TUNE_DENSE_BWD];
     const long long big = (long long)ceil_div(M, 128) * ceil_div(K, 128);
     if (variant > 0 && vec && big < 2 * kCUs) {
         int xm, xn, wm, wn;
@@ -303,7 +309,9 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
         DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, defer));
         return dense_bwd_x_impl(dy, w, dx, M, K, N, s);
     }
-    DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
+    pw.ldc = N;
+    if (g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor && kmajor_ok(pw)) DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
+    else DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
     defer->dw_slabs = slabs;
     defer->db_slabs = dbias ? cs : nullptr;
     defer->splits = sp.splits;

@@ -442,6 +442,9 @@ template <int BM, int BN, int BK, bool VEC>
 __global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_kernel(const GemmParams px, const GemmParams pw,
                                                                          const int nx, const int tw) {
     const int b = (int)blockIdx.x;
+#ifdef GROUPED_ABL          // timing experiments only: 1 = the dX blocks return at once, 2 = the dW blocks do
+    if ((GROUPED_ABL == 1) == (b < nx)) return;
+#endif
     if (b < nx) {
         gemm_block<OP_KCONTIG, OP_KCONTIG, BM, BN, BK, 0, VEC>(px, b, nx, 0);
     } else {

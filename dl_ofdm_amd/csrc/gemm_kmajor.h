@@ -1,0 +1,246 @@
+// Weight-gradient GEMM with both operands "k-major": C[M,N] = A^T . B with A = [K][M] and B = [K][N] row-major -- the
+// natural layout of dW = X^T . dY (k = batch row): no operand is transposed anywhere.
+//
+// A k-tile (64 rows of A and of B, 64 columns each) goes to LDS as it lies in memory (float4 copies, unpadded 256-byte
+// rows).  v_mfma_f32_16x16x4_f32 wants lane (c = l%16, kq = l/16) to supply A[i=c][k=kq] and B[k=kq][j=c]; one
+// ds_read_b128 of row k0+kq at column 4c hands the lane FOUR columns of that row, used as the operand of four
+// different 16-wide sub-tiles: sub-tile s of A holds the rows m = 4c+s, sub-tile t of B the columns n = 4c+t.  Wave w
+// of a block owns the row class s = w of the 64x64 tile (16 rows x 64 columns, 4 accumulators): per k-step it reads its
+// one A column (ds_read_b32) and the B float4 and issues 4 MFMAs; nothing is exchanged between the waves.
+// With unpadded rows the B reads are conflict free: the 16-lane service groups of ds_read_b128 ({0-3,12-15,20-27}, ...)
+// take 8 lanes of one row and 8 of the next, which cover complementary halves of the 64 banks.
+// Accumulator t, register r of lane l in wave w is C[m0 + 16*(l/16) + 4r + w][n0 + 4*(l%16) + t]: the four t of a lane
+// are one float4 of the output row, the 16 lanes of a row one 256-byte segment.
+//
+// Vector-legal operands only (M, N multiples of 4, 16-byte aligned, < 2 GiB); callers fall back to the
+// gemm_f32_mfma.h path otherwise.
+#pragma once
+#include "gemm_f32_mfma.h"
+
+namespace dccn {
+
+typedef float kf32x4 __attribute__((ext_vector_type(4)));
+
+template <int BK = 64>
+constexpr size_t kmajor_smem_bytes() { return (size_t)(2 * 2 * BK * 64) * sizeof(float); }
+
+// COLSUM: also the column sums of the B rows of this k range (bias gradient), written by the m0 == 0 tiles
+template <int COLSUM, int BK = 64>
+__device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, const int T, const int z) {
+    constexpr int BT = 64, NV = BK / 16;                // 64x64 output tile, BK-deep k-tiles, NV float4 per thread/operand
+    constexpr int NKS = BK / 4;                         // k-steps per k-tile
+    static_assert(BK == 32 || BK == 64, "k-tile depth");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                       // [2][BK][64]
+    float* sB = smem + 2 * BK * BT;         // [2][BK][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int ntn = (p.N + BT - 1) / BT;
+    int tile;
+    {
+        const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int m0 = (tile / ntn) * BT, n0 = (tile % ntn) * BT;
+    const int kbeg = z * p.klen;
+    const int kend = min(p.K, kbeg + p.klen);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int nfull = (kend - kbeg) / BK;
+
+    kf32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_cs = COLSUM && p.colsum != nullptr && m0 == 0 && w == 0;       // wave-uniform
+
+    // staging: piece v of a thread = row (tid + 256 v) / 16, float4 column (tid + 256 v) % 16 of the k-tile
+    unsigned offA[NV], offB[NV];
+    float4 ra[NV], rb[NV];
+    unsigned okm = 0u;                                  // masked path: bit v = row of piece v lies inside the k range
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
+        offA[v] = (unsigned)((row * p.lda + min(m0 + 4 * c4, p.M - 4)) * 4);
+        offB[v] = (unsigned)((row * p.ldb + min(n0 + 4 * c4, p.N - 4)) * 4);
+    }
+    auto load = [&](auto masked_tag, int q, int k0) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int v = q % NV;
+        if constexpr (!MASKED) {
+            const char* base = reinterpret_cast<const char*>(q < NV ? p.A + (size_t)k0 * p.lda : p.B + (size_t)k0 * p.ldb);
+            if (q < NV) ra[v] = *reinterpret_cast<const float4*>(base + offA[v]);
+            else rb[v] = *reinterpret_cast<const float4*>(base + offB[v]);
+        } else {
+            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
+            const int k = k0 + row, kc = min(k, p.K - 1);
+            if (q < NV) {
+                ra[v] = *reinterpret_cast<const float4*>(p.A + (size_t)kc * p.lda + min(m0 + 4 * c4, p.M - 4));
+                okm = (okm & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
+            } else {
+                rb[v] = *reinterpret_cast<const float4*>(p.B + (size_t)kc * p.ldb + min(n0 + 4 * c4, p.N - 4));
+            }
+        }
+    };
+    auto store = [&](auto masked_tag, int q, float* An, float* Bn) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int v = q % NV;
+        float4 val = q < NV ? ra[v] : rb[v];
+        if constexpr (MASKED) {
+            const bool ok = (okm >> v) & 1u;
+            val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
+        }
+        *reinterpret_cast<float4*>((q < NV ? An : Bn) + 4 * (tid + 256 * v)) = val;
+    };
+    using TFalse = std::false_type;
+    using TTrue = std::true_type;
+    if (ntiles > 0) {
+        if (nfull > 0) {
+#pragma unroll
+            for (int q = 0; q < 2 * NV; ++q) load(TFalse{}, q, kbeg);
+#pragma unroll
+            for (int q = 0; q < 2 * NV; ++q) store(TFalse{}, q, sA, sB);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2 * NV; ++q) load(TTrue{}, q, kbeg);
+#pragma unroll
+            for (int q = 0; q < 2 * NV; ++q) store(TTrue{}, q, sA, sB);
+        }
+    }
+    __syncthreads();
+
+    // one k-tile = BK/4 k-steps (rows 4ks + kq) x 4 MFMAs per wave; the next k-tile's 8 global loads go out during the
+    // first 8 steps, their LDS writes (other buffer) during the last 8
+    int t = 0;
+    auto ktile = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const int cur = t & 1;
+        const int k0n = kbeg + (t + 1) * BK;
+        const float* As = sA + cur * BK * BT + kq * BT + 4 * c + w;
+        const float* Bs = sB + cur * BK * BT + kq * BT + 4 * c;
+        float* An = sA + (cur ^ 1) * BK * BT;
+        float* Bn = sB + (cur ^ 1) * BK * BT;
+        float fa[2];
+        float4 fb[2];
+        fa[0] = As[0];
+        fb[0] = *reinterpret_cast<const float4*>(Bs);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) {
+                fa[(ks + 1) & 1] = As[4 * (ks + 1) * BT];
+                fb[(ks + 1) & 1] = *reinterpret_cast<const float4*>(Bs + 4 * (ks + 1) * BT);
+            }
+            if constexpr (MODE != PF_NONE) {
+                if (ks < 2 * NV) {
+                    if constexpr (MODE == PF_FAST) load(TFalse{}, ks, k0n);
+                    else load(TTrue{}, ks, k0n);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1], f4c(fb[ks & 1], tt), acc[tt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (COLSUM && do_cs) {
+                const float4 b = fb[ks & 1];
+                bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w;
+            }
+            if constexpr (MODE != PF_NONE) {
+                if (ks >= NKS - 2 * NV) {
+                    if constexpr (MODE == PF_FAST) store(TFalse{}, ks - (NKS - 2 * NV), An, Bn);
+                    else store(TTrue{}, ks - (NKS - 2 * NV), An, Bn);
+                }
+            }
+        }
+        __syncthreads();
+        ++t;
+    };
+    while (t + 1 < nfull) ktile(std::integral_constant<int, PF_FAST>{});
+    while (t + 1 < ntiles) ktile(std::integral_constant<int, PF_MASKED>{});
+    if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
+
+    float* Cz = p.C + (size_t)z * p.slab;
+    const int col = n0 + 4 * c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * kq + 4 * r + w;
+        if (row < p.M && col < p.N)
+            *reinterpret_cast<float4*>(Cz + (size_t)row * p.ldc + col) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+    if (COLSUM && do_cs) {
+        // wave 0 has seen every element of the B rows once: lanes c, c+16, c+32, c+48 hold the same four columns
+#pragma unroll
+        for (int m = 16; m < 64; m <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, m, 64);
+            bsum.y += __shfl_xor(bsum.y, m, 64);
+            bsum.z += __shfl_xor(bsum.z, m, 64);
+            bsum.w += __shfl_xor(bsum.w, m, 64);
+        }
+        if (lane < 16 && col < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)z * p.N + col) = bsum;
+    }
+}
+
+static inline bool kmajor_ok(const GemmParams& p) {
+    return p.vecA && p.vecB && (p.M % 4 == 0) && (p.N % 4 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && (p.ldc % 4 == 0) &&
+           p.M >= 4 && p.N >= 4 && ((reinterpret_cast<uintptr_t>(p.C) | (uintptr_t)(p.slab * 4)) & 15) == 0;
+}
+
+// stand-alone launch: grid (tiles, 1, splits)
+template <int COLSUM, int TAG>
+__global__ __launch_bounds__(kGemmThreads) void gemm_kmajor_kernel(const GemmParams p) {
+    kmajor_block<COLSUM>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+}
+
+template <int COLSUM, int TAG>
+static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
+    auto kern = gemm_kmajor_kernel<COLSUM, TAG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kmajor_smem_bytes<64>()));
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(p.N, 64) * ceil_div(p.M, 64), 1, splits);
+    hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), kmajor_smem_bytes<64>(), s, p);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// dense backward in one grid: blocks [0, nx) = the dX tiles (gemm_f32_mfma.h, k-contiguous operands), the rest = the
+// dW (tile, split) items in the k-major form
+template <int BK>
+__global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_km_kernel(const GemmParams px, const GemmParams pw,
+                                                                            const int nx, const int tw) {
+    const int b = (int)blockIdx.x;
+#ifdef GROUPED_ABL          // timing experiments only: 1 = the dX blocks return at once, 2 = the dW blocks do
+    if ((GROUPED_ABL == 1) == (b < nx)) return;
+#endif
+    if (b < nx) {
+        gemm_block<OP_KCONTIG, OP_KCONTIG, 64, 64, BK, 0, true>(px, b, nx, 0);
+    } else {
+        const int c = b - nx;
+        kmajor_block<1, BK>(pw, c % tw, tw, c / tw);
+    }
+}
+
+template <int BK>
+static int launch_dense_bwd_grouped_km(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
+    constexpr size_t sx = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, 64, 64, BK>();
+    constexpr size_t smem = sx > kmajor_smem_bytes<BK>() ? sx : kmajor_smem_bytes<BK>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_grouped_km_kernel<BK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
+    const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
+    hipLaunchKernelGGL(dense_bwd_grouped_km_kernel<BK>, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+}  // namespace dccn
