@@ -46,8 +46,8 @@ enum TuneKey : int {
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_COUNT = 8
 };
-static int g_tune[TUNE_COUNT] = {9, 7, 0, 0, 0, 0, 0, 1};
-constexpr int kDenseBwdKmajor = 7;   // TUNE_DENSE_BWD value: dW in the k-major form of gemm_kmajor.h (dX as variant 0)
+static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1};
+constexpr int kVariantKmajor = 7;   // TUNE_DENSE_BWD / TUNE_CCONV_BWD_W value: weight gradient in the k-major form of gemm_kmajor.h
 static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
 // ---------------------------------------------------------------------------------------
@@ -213,7 +213,7 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
     p.C = slabs;
     p.colsum = dbias ? cs : nullptr;
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * sp.splits;
-    if (g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor && kmajor_ok(p) && big < 2 * kCUs)
+    if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && kmajor_ok(p) && big < 2 * kCUs)
         DCCN_TRY((launch_kmajor<1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
     else
         DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_DENSE_BWD_W>(p, sp.splits, s)));
@@ -269,7 +269,7 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     pw.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
     pw.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     const bool vec = px.vecA && px.vecB && pw.vecA && pw.vecB;
-    const int variant = g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor ? 0 : g_tune[TUNE_DENSE_BWD];
+    const int variant = g_tune[TUNE_DENSE_BWD] == kVariantKmajor ? 0 : g_tune[TUNE_DENSE_BWD];
     const long long big = (long long)ceil_div(M, 128) * ceil_div(K, 128);
     if (variant > 0 && vec && big < 2 * kCUs) {
         int xm, xn, wm, wn;
@@ -310,7 +310,7 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
         return dense_bwd_x_impl(dy, w, dx, M, K, N, s);
     }
     pw.ldc = N;
-    if (g_tune[TUNE_DENSE_BWD] == kDenseBwdKmajor && kmajor_ok(pw)) DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
+    if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && kmajor_ok(pw)) DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
     else DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
     defer->dw_slabs = slabs;
     defer->db_slabs = dbias ? cs : nullptr;
@@ -387,6 +387,19 @@ __global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_finalize_kernel(cons
     }
 }
 
+// the same with the GEMM blocks in the k-major form (gemm_kmajor.h)
+template <int BK>
+__global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_km_finalize_kernel(const GemmParams p, int tiles, int gemm_blocks,
+                                                                               TailFinalizeArgs a) {
+    const int b = (int)blockIdx.x;
+    if (b < gemm_blocks) {
+        kmajor_block<1, BK>(p, b % tiles, tiles, b / tiles);
+    } else {
+        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
+                                 a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
+    }
+}
+
 constexpr int kCconvBwMaxSplits = 128;
 static void cconv_bw16_tiles(int variant, int& tm, int& tn) {
     tm = 64; tn = 64;
@@ -415,7 +428,7 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
                             FoldDefer* defer = nullptr) {
     if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < cconv_bw_ws_bytes(rows, kin, F)) return DCCN_ERR_WORKSPACE;
-    const int variant = g_tune[TUNE_CCONV_BWD_W];
+    const int variant = g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor ? 0 : g_tune[TUNE_CCONV_BWD_W];
     const bool v16 = variant > 0 && defer && fin && (kin % 2 == 0) && (F % 2 == 0) && aligned16(x) && aligned16(dout) &&
                      small_enough(rows, 2LL * kin) && small_enough(rows, 2LL * F) && 4LL * kin * F <= 512 * 512;
     SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
@@ -458,7 +471,17 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         // fused step: GEMM + tail finalize in one launch; the fold happens inside the optimizer kernel
         const int tiles = ceil_div(p.N, 64) * ceil_div(p.M, 64), gemm_blocks = tiles * sp.splits;
         const dim3 grid(gemm_blocks + tail_finalize_blocks(fin->P));
-        if (sp.klen == 128 && g_whole_k) {
+        if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p)) {
+            auto kern = cconv_bwd_w_km_finalize_kernel<64>;
+            constexpr size_t smem = kmajor_smem_bytes<64>();
+            static bool attr_done = false;
+            if (!attr_done) {
+                DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
+        } else if (sp.klen == 128 && g_whole_k) {
             // 128 rows per split: the whole k range of a block as one tile (all loads in flight at once, no k-tile barrier)
             auto kern = cconv_bwd_w_finalize_kernel<true, 128, 1>;
             constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 128, 1>();
@@ -486,7 +509,11 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         return DCCN_OK;
     }
     if (defer) defer->slabs = nullptr;
-    DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
+    const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * sp.splits;
+    if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p) && big < 2 * kCUs)
+        DCCN_TRY((launch_kmajor<1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
+    else
+        DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     const int nthreads = kin * F + F;
     const int fold_blocks = ceil_div(nthreads, kRedLanes);
     if (fin)

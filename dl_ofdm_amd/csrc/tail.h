@@ -124,14 +124,16 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         float p0[W], p1[W], f0[W], f1[W], fs[W];
+        bool big[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) {
             const float u0 = leaky_relu(pre2[2 * j][u]), u1 = leaky_relu(pre2[2 * j + 1][u]);
             // softmax over the pair: exp(u - max) is exactly 1 for the larger logit, so one expf suffices
             // (bit-identical to evaluating both); likewise for the second softmax on the probabilities
-            const bool u1_big = u1 > u0;
-            const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
-            const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
+            // (the smaller logit minus the larger one is -|u0 - u1| either way: abs/neg are free source modifiers)
+            big[u] = u1 > u0;
+            const float eo = exp_nonpos(-fabsf(u0 - u1));
+            const float e0 = big[u] ? eo : 1.0f, e1 = big[u] ? 1.0f : eo;
             const float res = rcp_fast(e0 + e1);
             p0[u] = e0 * res;
             p1[u] = e1 * res;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
             // second softmax on the probabilities (softmax_cross_entropy_with_logits_v2)
             const bool p1_big = p1[u] > p0[u];
             const float mx2 = p1_big ? p1[u] : p0[u];
-            const float fo = exp_nonpos(p1_big ? (p0[u] - p1[u]) : (p1[u] - p0[u]));
+            const float fo = exp_nonpos(-fabsf(p0[u] - p1[u]));
             f0[u] = p1_big ? fo : 1.0f;
             f1[u] = p1_big ? 1.0f : fo;
             fs[u] = f0[u] + f1[u];
