@@ -175,6 +175,11 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # kernel experiments: DCCN_TUNE="key=value,key=value" applies dccn_set_tuning pairs at load time
+    for kv in filter(None, os.environ.get("DCCN_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        if lib.dccn_set_tuning(int(k), int(v)) != 0:
+            raise DccnError("DCCN_TUNE: bad tuning pair %r" % kv)
     return lib
 
 

@@ -44,9 +44,27 @@ enum TuneKey : int {
     TUNE_CCONV_BWD_SPLITS = 5,  // 0 = automatic
     TUNE_SMEM_MIN_KB = 6,       // minimum dynamic LDS per block of the gemm16 launches (caps resident blocks per CU)
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
-    TUNE_COUNT = 8
+    TUNE_SKINNY = 8,            // > 0: GEMMs with <= 96 output rows (the equaliser's 73-frame batch) use small gemm16 tiles
+    TUNE_COUNT = 9
 };
-static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1};
+static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1};
+
+// few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
+// the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
+template <int KA, int KB, int TAG>
+static int skinny_launch(int variant, const GemmParams& p, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 16x64
+        case 2: return launch_gemm16<KA, KB, 1, 4, 2, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 32x64
+        case 3: return launch_gemm16<KA, KB, 2, 2, 1, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 32x32
+        case 4: return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 2, 0, TAG, 2>(p, 1, s);       // 16x64, 8 waves
+        default: return DCCN_ERR_INVALID_ARG;
+    }
+}
+static bool skinny_ok(const GemmParams& p) {
+    return g_tune[TUNE_SKINNY] > 0 && p.M <= 96 && p.N >= 256 && p.K >= 256 && p.vecA && p.vecB && (p.K % 4 == 0) &&
+           (p.N % 4 == 0);
+}
 constexpr int kVariantKmajor = 7;   // TUNE_DENSE_BWD / TUNE_CCONV_BWD_W value: weight gradient in the k-major form of gemm_kmajor.h
 static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
 
@@ -140,6 +158,7 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.klen = round_k(K);
     p.vecA = (K % 4 == 0) && (lda % 4 == 0) && aligned16(x) && small_enough(M, lda);     // KCONTIG: k extent K
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
+    if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD>(g_tune[TUNE_SKINNY], p, s);
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 
@@ -163,6 +182,7 @@ static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, i
     p.klen = round_k(N);
     p.vecA = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);
+    if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_KCONTIG, TAG_DENSE_BWD_X>(g_tune[TUNE_SKINNY], p, s);
     return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
 }
 

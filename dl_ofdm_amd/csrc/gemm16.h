@@ -617,10 +617,10 @@ static int set_smem_attr(K kern, size_t smem) {
 }
 
 // plain launch of one configuration; smem_pad lets a caller force fewer resident blocks per CU (experiments)
-template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int TAG>
+template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int TAG, int PD = 1>
 static int launch_gemm16(const GemmParams& p, int splits, hipStream_t s, size_t smem_min = 0) {
     using CF = Cfg16<KA, KB, WGM, WGN, TM, TN, BK, KS>;
-    auto kern = gemm16_kernel<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI_STORE, 1, false, TAG>;
+    auto kern = gemm16_kernel<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI_STORE, 1, false, TAG, PD>;
     size_t smem = CF::smem_bytes(0);
     if (smem < smem_min) smem = smem_min;
     static size_t attr_for = 0;
