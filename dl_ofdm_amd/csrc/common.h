@@ -37,7 +37,22 @@ static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kWave = 64;          // CDNA wavefront
-constexpr int kCUs = 256;          // MI355X
+// compute units of the current device (MI355X: 256; fewer in the partitioned CPX/DPX modes): asked once, 256 when no
+// device is visible (workspace-size queries on a host without a GPU).  Host-side planning only.
+static inline int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
+}
+#define kCUs (dccn::device_cus())
 
 // ---- wave reductions (wave64) on the DPP crossbar: no LDS round trips ------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror sums each 16-lane row

@@ -299,11 +299,11 @@ def op_launchers(eng: RxEngine):
         "dense_bwd_slabs": (lambda: lib.dccn_dense_bwd_slabs(
             eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
             seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, None,
-            s()), 4.0 * B * dK * dN, "dense_bwd_grouped_kernel"),
+            s()), 4.0 * B * dK * dN, "dense_bwd_grouped_km_kernel (dX 32x32x2 tiles + dW k-major 16x16x4 tiles)"),
         "cconv_bwd_w": (lambda: lib.dccn_cconv_gemm_bwd_w(
             eng.x_norm.data_ptr(), eng.dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
             seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),
-            8.0 * rows * d.kin * d.F, "gemm<cconv_bwd_w>+fold"),
+            8.0 * rows * d.kin * d.F, "gemm_kmajor<cconv_bwd_w>+fold"),
     }
     if d.nbits <= 2 and lib.dccn_get_tuning(0) > 0:
         ops["dense_tail_fwd_bwd"] = (lambda: lib.dccn_dense_tail_fwd_bwd(

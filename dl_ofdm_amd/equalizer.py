@@ -197,12 +197,17 @@ class EqualizerTrainer:
         return m
 
     def chan_rms(self, chest: torch.Tensor, chan_gt) -> torch.Tensor:
-        """ofdmreceiver_np_mp.py:309-317 monitor: MSE between the layer-normalised true channel and the
-        layer-normalised estimate (no gradient: it is fetched, never part of total_loss)."""
+        """ofdmreceiver_np_mp.py:245, 325-333 monitor: MSE between the true channel and the estimate, each passed through
+        tf.keras.layers.LayerNormalization(axis=1, center=False, scale=False) -- moments over the OFDM-symbol axis only,
+        Keras' default epsilon 1e-3 (no gradient: it is fetched, never part of total_loss)."""
+        def ln_axis1(t):
+            mean = t.mean(dim=1, keepdim=True)
+            var = ((t - mean) ** 2).mean(dim=1, keepdim=True)
+            return (t - mean) * torch.rsqrt(var + 1e-3)
         with torch.no_grad():
             g = torch.view_as_real(torch.as_tensor(chan_gt).to(self.device).to(torch.complex64)).contiguous()
-            a = ops.layer_norm(g)
-            b = ops.layer_norm(torch.view_as_real(chest).contiguous())
+            a = ln_axis1(g)
+            b = ln_axis1(torch.view_as_real(chest).contiguous())
             return ((a - b) ** 2).mean()
 
     def _adam_step(self):

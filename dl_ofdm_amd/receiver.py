@@ -227,13 +227,17 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
     engines: Dict[int, RxEngine] = {}
 
     def engine_for(bs: int, src: Optional[RxEngine]) -> RxEngine:
-        """One engine (arenas + plan) per batch size; optimizer state follows the training run."""
+        """The engine (arenas + plan) of the current batch size; optimizer state follows the training run.  The batch
+        size only ever grows with the falling BER (:232-236), so the previous engine is released as soon as its state
+        has been copied: one training engine is alive at a time."""
         if bs not in engines:
             engines[bs] = RxEngine(dims, bs, device=device, train=True, seed=FLAGS.seed, want_prob=False)
         e = engines[bs]
         if src is not None and src is not e:
             e.params.copy_(src.params); e.adam_m.copy_(src.adam_m); e.adam_v.copy_(src.adam_v)
             e.adam_state.copy_(src.adam_state)
+            for old_bs in [k for k, v in engines.items() if v is src]:
+                engines.pop(old_bs).close_graph()
         return e
 
     eng = engine_for(batch_size, None)
@@ -255,7 +259,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             steps = n_use // batch_size
             for i in range(steps):
                 noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR)
-                eng.train_step(graph=True)
+                eng.train_step()          # stream launches: faster than hipGraph replay on ROCm 7.2
                 acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power); acc[2:3].add_(noise_t)
             a = acc.cpu().numpy() / max(steps, 1)
             losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])

@@ -380,6 +380,23 @@ def test_fused_step_equals_composed_step(cp):
     close(pl.chest, torch.view_as_real(out_b[4]).cpu().numpy(), 1e-5, "chest")
 
 
+def test_chan_rms_monitor_is_keras_layer_normalization_over_the_symbol_axis():
+    """ofdmreceiver_np_mp.py:245, 325-333: LayerNormalization(axis=1, center=False, scale=False), epsilon 1e-3"""
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer(seed=3, cp=True)
+    rng = np.random.RandomState(4)
+    gt = (rng.standard_normal((6, 7, 64)) + 1j * rng.standard_normal((6, 7, 64))).astype(np.complex64)
+    est = (rng.standard_normal((6, 7, 64)) + 1j * rng.standard_normal((6, 7, 64))).astype(np.complex64)
+
+    def keras_ln(c):
+        t = np.stack([c.real, c.imag], -1).astype(np.float64)                  # [B, S, K, 2]
+        mean = t.mean(axis=1, keepdims=True)
+        var = t.var(axis=1, keepdims=True)
+        return (t - mean) / np.sqrt(var + 1e-3)
+    want = float(((keras_ln(gt) - keras_ln(est)) ** 2).mean())
+    got = float(tr.chan_rms(torch.as_tensor(est).cuda(), gt))
+    assert abs(got - want) <= 1e-5 * want
+
+
 def test_equalizer_harness_on_device_generated_data():
     """receiver_mp.train(device_data=True): bits, frames, fading, noise and the true channel response all come
     from the GPU generator; same learning criterion as the host-data test above."""

@@ -73,7 +73,8 @@ def test_clip_power(ops):
 
 
 # ---- R1 -------------------------------------------------------------------------------------
-CCONV_SHAPES = [(252, 80, 64), (8190, 80, 64), (37, 5, 3), (100, 64, 64), (129, 33, 17), (70, 1096, 256)]
+CCONV_SHAPES = [(252, 80, 64), (8190, 80, 64), (37, 5, 3), (100, 64, 64), (129, 33, 17), (70, 1096, 256),
+                (1000, 34, 18), (511, 64, 64)]     # ragged k-major tiles; the equaliser's (1,K) C-Convs
 
 
 @pytest.mark.parametrize("rows,kin,F", CCONV_SHAPES)
@@ -120,7 +121,9 @@ def test_cconv_known_answer_dft(ops):
 
 
 # ---- R2 -------------------------------------------------------------------------------------
-DENSE_SHAPES = [(36, 896, 640), (1170, 896, 640), (7, 13, 5), (300, 2048, 1024), (65, 130, 67), (1, 896, 640)]
+DENSE_SHAPES = [(36, 896, 640), (1170, 896, 640), (7, 13, 5), (300, 2048, 1024), (65, 130, 67), (1, 896, 640),
+                (600, 260, 132), (2000, 64, 64),       # k-major weight gradient: ragged tiles / ragged last k range
+                (73, 896, 896), (90, 512, 300)]        # <= 96 rows: the skinny 16x64 tiles (forward and dX)
 
 
 @pytest.mark.parametrize("M,K,N", DENSE_SHAPES)

@@ -33,12 +33,12 @@ def main():
     gen = DeviceDataGen(F, o, seed=1)
     for _ in range(20):
         gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
-        eng.train_step(graph=True)
+        eng.train_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
-        eng.train_step(graph=True)
+        eng.train_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps(dict(mode="device-generated", channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
@@ -50,7 +50,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.host_steps):
         xs, ys, _ = R.make_batch(F, o, fading, a.frames, F.SNR)
-        eng.train_step(xs, ys, graph=True)
+        eng.train_step(xs, ys)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.host_steps
     print(json.dumps(dict(mode="host-generated (NumPy substrate)", channel=a.channel, frames=a.frames,

@@ -13,7 +13,10 @@ import sys
 from collections import defaultdict
 
 OP_OF_KERNEL = [  # kernel-name substring -> bench.py operator key (C2 shapes)
+    ("dense_bwd_grouped_km_kernel", "dense_bwd_slabs"),
     ("dense_bwd_grouped_kernel", "dense_bwd_slabs"),
+    ("gemm16_kernel<1, 0, 1, 4, 3, 1, 64", "dense_tail_fwd_bwd"),
+    ("cconv_bwd_w_km_finalize_kernel", "cconv_bwd_w"),
     ("gemm_f32_mfma_kernel<1, 0,", "dense_fwd"),
     ("gemm_f32_mfma_kernel<1, 2,", "cconv_fwd"),        # any tile configuration of the C-Conv forward
     ("gemm_f32_mfma_kernel<0, 0,", "cconv_bwd_w"),

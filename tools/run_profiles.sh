@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (gpurun): bench line, kernel-trace stats, four separate --pmc passes
 # (never combined with sys/hip/hsa traces), stage timings.  Results land under gpurun_out/$1.
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$R
 mkdir -p $O
@@ -15,7 +15,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -o p -- python tools/opbench.py step --iters 10 > $O/pmc_$i.log 2>&1
 done
+rocprofv3 --kernel-trace --stats -d $O/c4_kt -o kt -- python tools/opbench.py step --iters 20 --config c4 > $O/c4_kt.log 2>&1
 python tools/eqbench.py --steps 100 > $O/eqbench.json 2>&1
+rocprofv3 --kernel-trace --stats -d $O/eq73_kt -o kt -- python tools/eqbench.py --frames 73 --steps 100 --paths fused-eager > $O/eq73_kt.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/eq_kt -o kt -- python tools/eqbench.py --frames 1170 --steps 100 --paths fused-graph > $O/eq_kt.log 2>&1
 python tools/e2ebench.py > $O/e2e.json 2>&1
 python tools/e2ebench.py --channel AWGN >> $O/e2e.json 2>&1
