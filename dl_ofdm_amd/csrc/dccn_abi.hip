@@ -74,7 +74,13 @@ static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; 
 static int norm_grid_x(int cols) { return ceil_div(ceil_div(cols, 4), 64); }
 static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
 
-constexpr int kNormFusedCG = 2, kNormFusedRPT = 12;
+#ifndef DCCN_NORM_CG
+#define DCCN_NORM_CG 2
+#endif
+#ifndef DCCN_NORM_RPT
+#define DCCN_NORM_RPT 12
+#endif
+constexpr int kNormFusedCG = DCCN_NORM_CG, kNormFusedRPT = DCCN_NORM_RPT;
 static int norm_fused_blocks(int cols) { return ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8; }
 static size_t norm_power_slots(int batch, int cols) {
     const size_t a = (size_t)norm_grid_x(cols) * norm_grid_y(batch), b = (size_t)norm_fused_blocks(cols);
