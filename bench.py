@@ -104,7 +104,7 @@ def cpu_baseline(c, budget_s=20.0):
                 gemm_form_sample="%d steps, same graph with the C-Conv as a centre-tap GEMM" % out["gemm"]["steps"])
 
 
-def measure_config(name, dev, steps=20, warmup=5, graph=False):
+def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True):
     """ms per training step of another BASELINE configuration (same engine and launch mode, HIP-event timing)."""
     import torch
     from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine
@@ -115,13 +115,14 @@ def measure_config(name, dev, steps=20, warmup=5, graph=False):
     g.manual_seed(4321)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
     eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
+    step = (lambda: eng.train_step_pipelined(graph=graph)) if pipeline else (lambda: eng.train_step(graph=graph))
     for _ in range(warmup):
-        eng.train_step(graph=graph)
+        step()
     torch.cuda.synchronize(dev)
     t = HipTimer()
     t.start(eng._stream())
     for _ in range(steps):
-        eng.train_step(graph=graph)
+        step()
     t.stop(eng._stream())
     ms = t.elapsed_ms() / steps
     fl = step_flops(c)
@@ -142,6 +143,9 @@ def main():
                     help="hipGraph replay of the captured step instead of stream launches (measured slower on ROCm 7.2: "
                          "every graph kernel node pays ~0.9 us more than a same-stream launch, DESIGN.md section 5)")
     ap.add_argument("--no-graph", action="store_true", help="(default since round 2) eager launch sequence")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="every step normalises its own batch first (6 launches) instead of normalising the next batch "
+                         "behind its Adam update (5 launches; same results, DESIGN.md section 3.5)")
     ap.add_argument("--fork", action="store_true", help="two-stream graph (dense dW on a forked stream) instead of the grouped dX+dW launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
@@ -187,6 +191,13 @@ def main():
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
     eng.bits.copy_(torch.randint(0, 2, eng.bits.shape, generator=g, device=dev, dtype=torch.int32))
     use_graph, fork = (args.graph or args.fork) and not args.no_graph, args.fork
+    pipeline = not args.no_pipeline and not fork
+
+    def step():
+        if pipeline:
+            eng.train_step_pipelined(graph=use_graph)
+        else:
+            eng.train_step(graph=use_graph, fork=fork)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -199,7 +210,7 @@ def main():
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.5:
         for _ in range(50):
-            eng.train_step(graph=use_graph, fork=fork)
+            step()
         torch.cuda.synchronize(dev)
     lib = _lib.load()
 
@@ -212,14 +223,14 @@ def main():
             dist.all_reduce(table)
 
     for _ in range(args.warmup):
-        eng.train_step(graph=use_graph, fork=fork)
+        step()
     reduce_table()          # warm-up pass: first use loads torch's element-wise code objects (tens of ms, once)
     barrier()
     timer = HipTimer()
     timer.start(eng._stream())
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.train_step(graph=use_graph, fork=fork)
+        step()
     t_enqueue = time.perf_counter() - t0                        # host cost of issuing the K steps (no sync yet)
     reduce_table()
     timer.stop(eng._stream())
@@ -241,7 +252,9 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
                    "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
-                   "launch": ("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph else "eager",
+                   "launch": (("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph
+                              else "stream launches") + (", R0 of the next batch behind the Adam update (5 launches per step)"
+                                                          if pipeline else ", 6 launches per step"),
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }
     if rank == 0:
@@ -276,7 +289,7 @@ def main():
             # replay, HIP events on the launch stream): C3 = config[2] shape (16-QAM), C4 = config[3] (N=1024, MFMA-bound)
             del eng
             torch.cuda.empty_cache()
-            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph) for k in ("c3", "c4")}
+            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph, pipeline=pipeline) for k in ("c3", "c4")}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()

@@ -49,7 +49,8 @@ class RxBuffers(C.Structure):
                 ("adam_m", c_void_p), ("adam_v", c_void_p), ("reg_coef", c_void_p), ("adam", c_void_p),
                 ("x_norm", c_void_p), ("fft_out", c_void_p), ("z", c_void_p), ("prob", c_void_p),
                 ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+                ("x_next", c_void_p), ("x_prenormalised", c_int)]
 
 
 class EqShape(C.Structure):
@@ -117,6 +118,7 @@ SIGNATURES = {
     "dccn_rx_workspace_size": (_sz, [POINTER(RxShape), _i]),
     "dccn_rx_eval_step": (_i, [POINTER(RxShape), POINTER(RxBuffers), _vp]),
     "dccn_rx_train_step": (_i, [POINTER(RxShape), POINTER(RxBuffers), AdamHParams, _vp]),
+    "dccn_rx_normalise": (_i, [POINTER(RxShape), POINTER(RxBuffers), _vp]),
     "dccn_rx_graph_create": (_i, [POINTER(RxShape), POINTER(RxBuffers), _i, AdamHParams, _vp, POINTER(c_void_p)]),
     "dccn_rx_graph_launch": (_i, [_vp, _vp]),
     "dccn_rx_graph_destroy": (_i, [_vp]),

@@ -74,13 +74,6 @@ static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; 
 static int norm_grid_x(int cols) { return ceil_div(ceil_div(cols, 4), 64); }
 static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
 
-#ifndef DCCN_NORM_CG
-#define DCCN_NORM_CG 2
-#endif
-#ifndef DCCN_NORM_RPT
-#define DCCN_NORM_RPT 12
-#endif
-constexpr int kNormFusedCG = DCCN_NORM_CG, kNormFusedRPT = DCCN_NORM_RPT;
 static int norm_fused_blocks(int cols) { return ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8; }
 static size_t norm_power_slots(int batch, int cols) {
     const size_t a = (size_t)norm_grid_x(cols) * norm_grid_y(batch), b = (size_t)norm_fused_blocks(cols);
@@ -105,6 +98,16 @@ struct PowerPartials {      // where normalise left the R8 partial sums (finishe
 
 // want_power: also emit the per-block partial sums of the clipped power (R8); adam != nullptr: the
 // optimizer bookkeeping of the fused training step rides on the first kernel
+// where norm_impl leaves the R8 partial sums for a [batch, cols] input in workspace `ws` (no launch)
+static void norm_power_partials(int batch, int cols, void* ws, size_t ws_bytes, const float* x, const float* y,
+                                PowerPartials* pp) {
+    Carver c(ws, ws_bytes);
+    c.take<double>((size_t)kNormRowChunks * cols * 2);
+    pp->partial = c.take<double>(norm_power_slots(batch, cols));
+    pp->n = norm_fused_ok(x, y, batch, cols) ? norm_fused_blocks(cols) : norm_grid_x(cols) * norm_grid_y(batch);
+    pp->denom = (double)batch * (double)(cols / 2);
+}
+
 static int norm_impl(const float* x, float* y, float* mean, float* var, bool want_power, PowerPartials* pp, int batch,
                      int cols, float eps, float peak, dccn_adam_state* adam, dccn_adam_hparams hp, void* ws,
                      size_t ws_bytes, hipStream_t s) {
@@ -395,8 +398,7 @@ __global__ __launch_bounds__(256) void cconv_fold_finalize_kernel(const float* _
     if ((int)blockIdx.x < fold_blocks) {
         cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x);
     } else {
-        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
-                                 a.power_partial, a.n_power, a.power_denom, a.power_out, (int)blockIdx.x - fold_blocks);
+        demod_tail_finalize_body(a, (int)blockIdx.x - fold_blocks);
     }
 }
 
@@ -408,8 +410,7 @@ __global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_finalize_kernel(cons
     if (b < gemm_blocks) {
         gemm_block<OP_ICONTIG, OP_ICONTIG, 64, 64, BK, 1, VEC, NBUF>(p, b % tiles, tiles, b / tiles);
     } else {
-        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
-                                 a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
+        demod_tail_finalize_body(a, b - gemm_blocks);
     }
 }
 
@@ -421,8 +422,7 @@ __global__ __launch_bounds__(kGemmThreads) void cconv_bwd_w_km_finalize_kernel(c
     if (b < gemm_blocks) {
         kmajor_block<1, BK>(p, b % tiles, tiles, b / tiles);
     } else {
-        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
-                                 a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
+        demod_tail_finalize_body(a, b - gemm_blocks);
     }
 }
 
@@ -497,7 +497,9 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         // fused step: GEMM + tail finalize in one launch; the fold happens inside the optimizer kernel
         const int tiles = ceil_div(p.N, 64) * ceil_div(p.M, 64), gemm_blocks = tiles * sp.splits;
         const dim3 grid(gemm_blocks + tail_finalize_blocks(fin->P));
-        if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p)) {
+        // (large outputs, e.g. N = 1024: the 32x32x2 form measured 0.7 % faster per step -- the k-major form pays off where
+        // the k-loops are short)
+        if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p) && tiles <= 2 * kCUs) {
             auto kern = cconv_bwd_w_km_finalize_kernel<64>;
             constexpr size_t smem = kmajor_smem_bytes<64>();
             static bool attr_done = false;
@@ -535,8 +537,7 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         return DCCN_OK;
     }
     if (defer) defer->slabs = nullptr;
-    const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * sp.splits;
-    if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p) && big < 2 * kCUs)
+    if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p) && ceil_div(p.N, 64) * ceil_div(p.M, 64) <= 2 * kCUs)
         DCCN_TRY((launch_kmajor<1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     else
         DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
@@ -625,6 +626,7 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     fa.blk_metrics = bm; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp));
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -708,6 +710,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp));
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -798,10 +801,16 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     float* P = b->params;
     float* G = b->grads;
 
-    // R0 (+R8 partial sums; + the optimizer's per-step bookkeeping when training)
+    // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
-    DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, sh->batch, L.cols, 1e-9f, 8.0f,
-                       train ? b->adam : nullptr, hp, ws_norm, L.ws_norm, s));
+    const bool pre = train && b->x_prenormalised != 0;
+    if (pre) {
+        if (L.cols & 1) return DCCN_ERR_INVALID_ARG;
+        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next ? b->x_next : b->x, b->x_norm, &pp);
+    } else {
+        DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, sh->batch, L.cols, 1e-9f, 8.0f,
+                           nullptr, hp, ws_norm, L.ws_norm, s));
+    }
     // R1
     DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     TailFinalizeArgs fin;
@@ -819,6 +828,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                            L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
     }
     if (!train) return DCCN_OK;
+    fin.adam = b->adam;                 // the optimizer's per-step bookkeeping rides on the tail finalize stage
+    fin.hp = hp;
 
     DeferredSlabs ds;
 
@@ -859,6 +870,17 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
     if (blocks > 8 * kCUs) blocks = 8 * kCUs;
     blocks += aa.fold_blocks;
+    // R0 of the next batch on the leading blocks of this launch (dccn_rx_buffers.x_next)
+    aa.nx = nullptr; aa.ny = nullptr; aa.npower = nullptr; aa.nbatch = 0; aa.ncols = 0; aa.norm_blocks = 0;
+    aa.neps = 1e-9f; aa.npeak = 8.0f;
+    const bool ride = b->x_next != nullptr && kNormFusedCG == 2 && norm_fused_ok(b->x_next, b->x_norm, sh->batch, L.cols);
+    if (ride) {
+        PowerPartials np;
+        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm, &np);
+        aa.nx = b->x_next; aa.ny = b->x_norm; aa.npower = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
+        aa.nbatch = sh->batch; aa.ncols = L.cols; aa.norm_blocks = norm_fused_blocks(L.cols);
+        blocks += aa.norm_blocks;
+    }
     switch (ds.splits) {
         case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         case 3: hipLaunchKernelGGL(adam_rx_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
@@ -866,6 +888,12 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         default: hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
     }
     DCCN_LAUNCH_CHECK();
+    if (b->x_next != nullptr && !ride) {
+        // shapes the single-pass kernel does not take: the same normalisation as launches of their own
+        PowerPartials np;
+        DCCN_TRY(norm_impl(b->x_next, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &np, sh->batch, L.cols, 1e-9f,
+                           8.0f, nullptr, hp, ws_norm, L.ws_norm, s));
+    }
     return DCCN_OK;
 }
 
@@ -1094,6 +1122,20 @@ int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dc
 int dccn_rx_train_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_adam_hparams hp,
                        dccn_stream_t stream) {
     return rx_step_impl(shape, buf, true, hp, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+// R0 (+R8 partial sums) of buf->x into buf->x_norm exactly as a step would run it: primes the pipelined mode
+// (dccn_rx_buffers.x_prenormalised) before the first call
+int dccn_rx_normalise(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream) {
+    if (!shape_ok(shape) || !buf || !buf->x || !buf->x_norm) return DCCN_ERR_INVALID_ARG;
+    if (!buf->workspace || buf->workspace_bytes < rx_ws_bytes(shape, 1)) return DCCN_ERR_WORKSPACE;
+    const RxLayout L = rx_layout(shape);
+    Carver c(buf->workspace, buf->workspace_bytes);
+    void* ws_norm = c.take<char>(L.ws_norm);
+    PowerPartials pp;
+    dccn_adam_hparams hp;
+    memset(&hp, 0, sizeof(hp));
+    return norm_impl(buf->x, buf->x_norm, nullptr, nullptr, buf->tx_power != nullptr, &pp, shape->batch, L.cols, 1e-9f,
+                     8.0f, nullptr, hp, ws_norm, L.ws_norm, (hipStream_t)stream);
 }
 
 // mode: bit0 = train, bit1 = fork the dense weight-gradient branch onto a second stream

@@ -603,8 +603,7 @@ __global__ __launch_bounds__(256) void gemm16_bwd_w_finalize_kernel(const GemmPa
         gemm16_block<OP_ICONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, 1, 1, EPI_STORE, 1, false>(p, none, b % tiles, tiles,
                                                                                              b / tiles, 0);
     } else {
-        demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp,
-                                 a.power_partial, a.n_power, a.power_denom, a.power_out, b - gemm_blocks);
+        demod_tail_finalize_body(a, b - gemm_blocks);
     }
 }
 

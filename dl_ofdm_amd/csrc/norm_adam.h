@@ -8,6 +8,15 @@ namespace dccn {
 
 constexpr int kNormRowChunks = 32;      // partial-moment slabs per column
 constexpr int kNormRowsPerBlock = 32;   // rows handled by one normalise block
+// single-pass kernel: column groups per block / rows per thread (overridable for experiments; 128*CG threads per block,
+// the optimizer kernel's ride needs CG = 2)
+#ifndef DCCN_NORM_CG
+#define DCCN_NORM_CG 2
+#endif
+#ifndef DCCN_NORM_RPT
+#define DCCN_NORM_RPT 12
+#endif
+constexpr int kNormFusedCG = DCCN_NORM_CG, kNormFusedRPT = DCCN_NORM_RPT;
 
 __device__ __forceinline__ float adam_alpha(const dccn_adam_state* st, const dccn_adam_hparams& hp) {
     const float lr = hp.lr0 * powf(hp.decay_rate, floorf(st->global_step / hp.decay_steps));
@@ -196,21 +205,21 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
 // grid = ceil(cols / (4*CG)) rounded up to a multiple of 8, block = 128*CG threads; needs cols % 4 == 0 and
 // batch <= 128*RPT.
 // power_partial[blockIdx.x] = sum over the block of |clip(y)|^2; adam: see moments_kernel.
+// (a __device__ body: the kernel below runs it, and so do the leading blocks of the optimizer kernel when the step
+// normalises the NEXT batch behind its Adam update -- bidx / nblk are the block's index and count inside that group)
 template <int CG, int RPT>
-__global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int batch, int cols, float eps, float peak,
-                                                              double* __restrict__ power_partial,
-                                                              float* __restrict__ mean_out,
-                                                              float* __restrict__ var_out,
-                                                              dccn_adam_state* __restrict__ adam,
-                                                              dccn_adam_hparams hp) {
+__device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, float* __restrict__ y, int batch, int cols,
+                                                float eps, float peak, double* __restrict__ power_partial,
+                                                float* __restrict__ mean_out, float* __restrict__ var_out,
+                                                dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp,
+                                                const int bidx, const int nblk) {
     constexpr int NW = 2 * CG;                        // waves per block
     constexpr int RS = 64 / CG;                       // row slots per wave
     __shared__ double red[NW][CG][8];
     __shared__ double stat[CG][8];
     __shared__ double pred[NW];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (adam != nullptr && blockIdx.x == 0 && t == 0) {
+    if (adam != nullptr && bidx == 0 && t == 0) {
         adam->alpha = adam_alpha(adam, hp);
         adam->beta1_power = adam->beta1_power * hp.beta1;
         adam->beta2_power = adam->beta2_power * hp.beta2;
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __res
     }
     // XCD-aware strip order: workgroups go round-robin over the 8 XCDs (each with its own L2), and strips that
     // share 128-byte lines of x are neighbours -- so XCD k takes the k-th run of consecutive strips
-    const int per_xcd = gridDim.x / 8;
-    const int strip = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int per_xcd = nblk / 8;
+    const int strip = (bidx % 8) * per_xcd + bidx / 8;
     const int cg = t % CG, slot = t / CG;
     const int c4 = (strip * CG + cg) * 4;
     const bool live = c4 < cols;
@@ -311,9 +320,21 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __res
             double a = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) a += pred[w];
-            power_partial[blockIdx.x] = a;              // (idle strips past the last column contribute 0)
+            power_partial[bidx] = a;              // (idle strips past the last column contribute 0)
         }
     }
+}
+
+template <int CG, int RPT>
+__global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int batch, int cols, float eps, float peak,
+                                                              double* __restrict__ power_partial,
+                                                              float* __restrict__ mean_out,
+                                                              float* __restrict__ var_out,
+                                                              dccn_adam_state* __restrict__ adam,
+                                                              dccn_adam_hparams hp) {
+    norm_fused_body<CG, RPT>(x, y, batch, cols, eps, peak, power_partial, mean_out, var_out, adam, hp, (int)blockIdx.x,
+                             (int)gridDim.x);
 }
 
 // out[0] = (float)(sum(partial[0..n)) / denom)
@@ -432,6 +453,11 @@ struct AdamRxArgs {
     const float* cw_slabs; const float* cw_colsum;
     int cw_splits, kin, F, fold_blocks;
     long long cw_slab, o_cw, n_conv;       // o_cw: arena offset of the C-Conv kernel (its bias follows)
+    // R0 of the NEXT batch riding on this launch (norm_blocks > 0): the leading blocks normalise nx -> ny, which no
+    // kernel of the current step reads any more (software pipelining across steps: one boundary less per step)
+    const float* nx; float* ny; double* npower;
+    int nbatch, ncols, norm_blocks;
+    float neps, npeak;
 };
 
 template <int SPLITS>     // 0: runtime count
@@ -441,12 +467,18 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
     const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
     const bool seg4 = ((a.o_dw | a.n_dw | a.o_db | a.n_db) & 3) == 0;
     const int splits = SPLITS > 0 ? SPLITS : a.splits;
-    if ((int)blockIdx.x < a.fold_blocks) {
+    if ((int)blockIdx.x < a.norm_blocks) {
+        norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, a.neps, a.npeak, a.npower, nullptr, nullptr,
+                                           nullptr, hp, (int)blockIdx.x, a.norm_blocks);
+        return;
+    }
+    const int bx = (int)blockIdx.x - a.norm_blocks, nbx = (int)gridDim.x - a.norm_blocks;
+    if (bx < a.fold_blocks) {
         // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here
         long long idx[2];
         float gv[2];
         cconv_fold_body(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
-                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, (int)blockIdx.x, idx, gv);
+                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (idx[e] < 0) continue;
@@ -461,8 +493,8 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
         return;
     }
     const long long first = a.fold_blocks > 0 ? a.n_conv : 0;
-    const long long stride = (long long)(gridDim.x - a.fold_blocks) * blockDim.x * 4;
-    for (long long i = first + ((long long)((int)blockIdx.x - a.fold_blocks) * blockDim.x + threadIdx.x) * 4; i < a.n;
+    const long long stride = (long long)(nbx - a.fold_blocks) * blockDim.x * 4;
+    for (long long i = first + ((long long)(bx - a.fold_blocks) * blockDim.x + threadIdx.x) * 4; i < a.n;
          i += stride) {
         const int cnt = (int)((a.n - i) < 4 ? (a.n - i) : 4);
         float g[4] = {0.f, 0.f, 0.f, 0.f}, p[4], mm[4], vv[4], cc[4] = {0.f, 0.f, 0.f, 0.f};

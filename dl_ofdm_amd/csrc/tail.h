@@ -549,16 +549,24 @@ struct TailFinalizeArgs {
     int n_power;
     double power_denom;
     float* power_out;
+    // fused training step: the optimizer's per-step bookkeeping (alpha of THIS step from the current global_step /
+    // beta powers, then advance them) rides on one wave of this stage: it runs after the previous step's Adam kernel
+    // and before this step's.  nullptr elsewhere.
+    dccn_adam_state* adam;
+    dccn_adam_hparams hp;
 };
-static inline int tail_finalize_blocks(int P) { return (P + 2 + 3) / 4; }
+static inline int tail_finalize_blocks(int P) { return (P + 3 + 3) / 4; }
 
-__device__ __forceinline__ void demod_tail_finalize_body(const TailBlockMetrics* __restrict__ blk_metrics,
-                                                         const float* __restrict__ blk_grads, int nblocks, int P,
-                                                         long long count, dccn_metrics* __restrict__ metrics,
-                                                         float* __restrict__ dtailp,
-                                                         const double* __restrict__ power_partial, int n_power,
-                                                         double power_denom, float* __restrict__ power_out,
-                                                         int block) {
+__device__ __forceinline__ void demod_tail_finalize_body(const TailFinalizeArgs& a, const int block) {
+    const TailBlockMetrics* __restrict__ blk_metrics = a.blk_metrics;
+    const float* __restrict__ blk_grads = a.blk_grads;
+    const int nblocks = a.nblocks, P = a.P, n_power = a.n_power;
+    const long long count = a.count;
+    dccn_metrics* __restrict__ metrics = a.metrics;
+    float* __restrict__ dtailp = a.dtailp;
+    const double* __restrict__ power_partial = a.power_partial;
+    const double power_denom = a.power_denom;
+    float* __restrict__ power_out = a.power_out;
     const int lane = threadIdx.x & 63;
     const int g = block * 4 + (threadIdx.x >> 6);
     if (g < P) {
@@ -602,12 +610,18 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailBlockMetrics*
         for (int i = lane; i < n_power; i += 64) s += power_partial[i];
         s = wave_sum(s);
         if (lane == 0) power_out[0] = (float)(s / power_denom);
+    } else if (g == P + 2 && a.adam != nullptr && lane == 0) {
+        dccn_adam_state* st = a.adam;
+        const float lr = a.hp.lr0 * powf(a.hp.decay_rate, floorf(st->global_step / a.hp.decay_steps));
+        st->alpha = lr * sqrtf(1.0f - st->beta2_power) / (1.0f - st->beta1_power);
+        st->beta1_power = st->beta1_power * a.hp.beta1;
+        st->beta2_power = st->beta2_power * a.hp.beta2;
+        st->global_step = st->global_step + 1.0f;
     }
 }
 
 __global__ __launch_bounds__(256) void demod_tail_finalize_kernel(TailFinalizeArgs a) {
-    demod_tail_finalize_body(a.blk_metrics, a.blk_grads, a.nblocks, a.P, a.count, a.metrics, a.dtailp, a.power_partial,
-                             a.n_power, a.power_denom, a.power_out, blockIdx.x);
+    demod_tail_finalize_body(a, blockIdx.x);
 }
 
 }  // namespace dccn

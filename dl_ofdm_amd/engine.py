@@ -133,7 +133,11 @@ class RxEngine:
         self.buffers = RxBuffers(p(self.x), p(self.bits), p(self.params), p(self.grads), p(self.adam_m),
                                  p(self.adam_v), p(self.reg_coef), p(self.adam_state), p(self.x_norm),
                                  p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
-                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws)
+                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0)
+        # the same buffers in the pipelined mode (dccn.h: x_next / x_prenormalised), built on demand per (label slot, last)
+        self._pipe_bufs = {}
+        self.bits_alt = None                 # second label buffer: the generator fills it while a step reads the first
+        self._norm_ready = False
         self.load_params(params if params is not None else glorot_init(dims, seed))
 
     # ---- parameters ----------------------------------------------------------------------
@@ -166,15 +170,69 @@ class RxEngine:
             raise _lib.DccnError("engine built with train=False")
         if x is not None:
             self.set_batch(x, bits)
+        self._norm_ready = False            # x_norm is about to hold this batch, not a prefetched one
         if graph:
             self._launch_graph(1 | (2 if fork else 0))
         else:
             check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(self.buffers), self.hp, self._stream()),
                   "dccn_rx_train_step")
 
+    def prime(self, x=None):
+        """R0 of the batch in ``eng.x`` (or ``x``) into ``x_norm``: what ``train_step_pipelined`` expects to find."""
+        if x is not None:
+            self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        check(self.lib.dccn_rx_normalise(C.byref(self.shape), C.byref(self.buffers), self._stream()), "dccn_rx_normalise")
+        self._norm_ready = True
+
+    def label_slot(self, slot: int) -> torch.Tensor:
+        """Label buffer ``slot`` (0 = ``eng.bits``, 1 = a second buffer of the same shape, allocated on first use)."""
+        if slot == 0:
+            return self.bits
+        if self.bits_alt is None:
+            self.bits_alt = torch.zeros_like(self.bits)
+        return self.bits_alt
+
+    def _pipe_buffers(self, slot: int, last: bool) -> RxBuffers:
+        key = (slot, last)
+        if key not in self._pipe_bufs:
+            vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
+            vals["bits"] = self.label_slot(slot).data_ptr()
+            vals["x_next"] = 0 if last else self.x.data_ptr()
+            vals["x_prenormalised"] = 1
+            self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
+        return self._pipe_bufs[key]
+
+    def train_step_pipelined(self, next_x=None, bits=None, graph: bool = False, slot: int = 0, last: bool = False):
+        """One training step with R0 software-pipelined across steps: the step runs on the batch whose normalisation is
+        already in ``x_norm`` (written by the previous pipelined call, or by ``prime()``; the first call primes itself from
+        ``eng.x``), with the labels of THAT batch (``bits``, or what ``label_slot(slot)`` already holds), and normalises
+        ``next_x`` (default: whatever ``eng.x`` holds now) behind its Adam update for the following call -- one launch and
+        one kernel boundary less per step.  ``eng.x`` is only read by R0, so the caller refills the same buffer between
+        calls; the labels lag one batch behind the input, hence the two label slots for producers that write both at once.
+        ``last=True``: nothing follows (end of an epoch), no normalisation is issued and the next call primes again.
+        Results are bit-identical to ``train_step`` fed the same batches in the same order."""
+        if not self.train:
+            raise _lib.DccnError("engine built with train=False")
+        if not self._norm_ready:
+            self.prime()
+        if bits is not None:
+            self.label_slot(slot).copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
+        if next_x is not None:
+            self.x.copy_(torch.as_tensor(next_x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        if graph:
+            if slot != 0 or last:
+                raise _lib.DccnError("captured pipelined steps use label slot 0 and always prefetch")
+            self._launch_graph(1 | 4)
+        else:
+            check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(self._pipe_buffers(slot, last)), self.hp,
+                                              self._stream()), "dccn_rx_train_step")
+        if last:
+            self._norm_ready = False
+
     def eval_step(self, x=None, bits=None, graph: bool = False):
         if x is not None:
             self.set_batch(x, bits)
+        self._norm_ready = False
         if graph:
             self._launch_graph(0)
         else:
@@ -186,7 +244,8 @@ class RxEngine:
             self.close_graph()
             g = C.c_void_p(0)
             torch.cuda.synchronize(self.device)
-            check(self.lib.dccn_rx_graph_create(C.byref(self.shape), C.byref(self.buffers), mode, self.hp,
+            bufs = self._pipe_buffers(0, False) if mode & 4 else self.buffers
+            check(self.lib.dccn_rx_graph_create(C.byref(self.shape), C.byref(bufs), mode & 3, self.hp,
                                                 self._stream(), C.byref(g)), "dccn_rx_graph_create")
             self._graph, self._graph_mode = g, mode
         check(self.lib.dccn_rx_graph_launch(self._graph, self._stream()), "dccn_rx_graph_launch")

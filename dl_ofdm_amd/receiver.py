@@ -151,11 +151,13 @@ def _device_gen(FLAGS: Flags, ofdmobj, device):
     return DeviceDataGen(FLAGS, ofdmobj, device=device, seed=FLAGS.seed)
 
 
-def _gen_into(gen, eng, FLAGS: Flags, ofdmobj, n_frames: int, snr_db):
-    """make_batch on the GPU, written into the engine's resident input buffers (cropped when cp=False)."""
+def _gen_into(gen, eng, FLAGS: Flags, ofdmobj, n_frames: int, snr_db, slot: int = 0):
+    """make_batch on the GPU, written into the engine's resident input buffers (cropped when cp=False); ``slot`` picks
+    the label buffer (RxEngine.label_slot: the pipelined training loop fills one while a step reads the other)."""
+    bits = eng.label_slot(slot) if slot else eng.bits
     if FLAGS.cp:
-        return gen.make_batch(n_frames, snr_db, out_x=eng.x, out_bits=eng.bits)[2]
-    x, _, npow = gen.make_batch(n_frames, snr_db, out_bits=eng.bits)
+        return gen.make_batch(n_frames, snr_db, out_x=eng.x, out_bits=bits)[2]
+    x, _, npow = gen.make_batch(n_frames, snr_db, out_bits=bits)
     eng.x.copy_(x[:, :, ofdmobj.CP:ofdmobj.CP + ofdmobj.K, :])
     return npow
 
@@ -257,18 +259,29 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             mview = eng.metrics_buf.view(torch.float32)              # dccn_metrics: [12] ce_mean, [13] berlin
             acc = torch.zeros(3, dtype=torch.float32, device=eng.device)
             steps = n_use // batch_size
+            # R0 is software-pipelined across the steps (RxEngine.train_step_pipelined): batch i+1 is generated into
+            # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
+            noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=0) if steps else None
+            eng.prime()
             for i in range(steps):
-                noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR)
-                eng.train_step()          # stream launches: faster than hipGraph replay on ROCm 7.2
+                last = i + 1 == steps
+                noise_next = None if last else _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=(i + 1) & 1)
+                eng.train_step_pipelined(slot=i & 1, last=last)      # stream launches
                 acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power); acc[2:3].add_(noise_t)
+                noise_t = noise_next
             a = acc.cpu().numpy() / max(steps, 1)
             losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
             berl = eng.metrics()["berlin"]
         else:
             xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
-            for i in range(n_use // batch_size):
+            nb = n_use // batch_size
+            for i in range(nb):
                 sl = slice(i * batch_size, (i + 1) * batch_size)
-                eng.train_step(xs[sl], ys[sl])
+                if i == 0:
+                    eng.prime(xs[sl])
+                last = i + 1 == nb
+                eng.train_step_pipelined(next_x=None if last else xs[(i + 1) * batch_size:(i + 2) * batch_size],
+                                         bits=ys[sl], last=last)
                 m = eng.metrics()
                 losses.append(m["ce_mean"]); pwrs.append(m["tx_power"]); berl = m["berlin"]
         train_loss_epoch = float(np.mean(losses))

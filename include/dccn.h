@@ -251,6 +251,15 @@ typedef struct dccn_rx_buffers {
     float* tx_power;           /* device float[1] `tx_power:0` (nullable: skip R8) */
     void* workspace;
     size_t workspace_bytes;
+    /* Software pipelining of R0 across training steps (both default 0 = every step normalises its own batch first):
+       x_next != NULL  the step also normalises x_next into x_norm behind its Adam update (the leading blocks of the
+                       optimizer launch; x_norm is dead by then), for the following call;
+       x_prenormalised x_norm (and the R8 partial sums in the workspace) already hold this step's batch -- written
+                       by the previous call through x_next -- so the step starts at R1.
+       x itself is only read by R0: with both set, x and x_next may be the same buffer, refilled between calls.
+       The workspace must be the same memory in both calls. */
+    const float* x_next;
+    int x_prenormalised;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
@@ -259,6 +268,9 @@ size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train);
 int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream);
 int dccn_rx_train_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
                        dccn_adam_hparams hp, dccn_stream_t stream);
+/* R0 (+R8 partial sums) of buf->x into buf->x_norm, as the first launch of a step does it: primes the pipelined
+   mode (x_prenormalised) before its first call.  Workspace = the training step's. */
+int dccn_rx_normalise(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream);
 /* hipGraph-captured replay of the same sequences */
 typedef struct dccn_rx_graph dccn_rx_graph;
 /* mode: bit0 = train (else eval), bit1 = run the dense weight-gradient branch on a forked stream */

@@ -198,3 +198,36 @@ def test_large_fft_config_c4_slice():
     eng.train_step(x, bits)
     torch.cuda.synchronize()
     staged_checks(eng, p, x, bits, cfg, rtol=2e-5, grad_rtol=2e-5, cos_tol=1e-4)    # K up to 14336: a little more fp32 rounding
+
+
+@pytest.mark.parametrize("frames,nbits", [(1170, 2), (300, 2), (64, 4), (2000, 1)])
+def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits):
+    """dccn_rx_buffers.x_next / x_prenormalised: R0 of batch t+1 rides on the Adam launch of step t.  Same kernels, same
+    order of arithmetic -> parameters, gradients, probabilities, metrics and the optimizer state are bit-identical to
+    plain steps fed the same batches (2000 frames: the two-kernel normalisation; step 3-4: hipGraph replay; the label
+    slots alternate like in receiver.train's device-data loop; last=True ends the pipeline)."""
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    dims = RxDims(S=7, kin=80, F=64, D=320, nbits=nbits)
+    rng = np.random.RandomState(5)
+    xs = [rng.standard_normal((frames, 7, 80, 2)).astype(np.float32) * (1 + 0.1 * t) for t in range(6)]
+    bs = [rng.randint(0, 2, (frames, 320, nbits)).astype(np.int32) for t in range(6)]
+    a = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True)
+    b = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True)
+    b.prime(xs[0])
+    for t in range(6):
+        a.train_step(xs[t], bs[t])
+        if t < 3:        # labels through the alternating slots, next input copied by the call
+            b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], slot=t & 1)
+        elif t < 5:      # captured replay (slot 0)
+            b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], graph=True)
+        else:            # end of the epoch: nothing is prefetched, the next call would prime again
+            b.train_step_pipelined(bits=bs[t], last=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads), t
+        assert torch.equal(a.prob, b.prob) and torch.equal(a.adam_state, b.adam_state), t
+        assert a.metrics() == b.metrics(), t
+    assert not b._norm_ready
+    a.train_step(xs[1], bs[1])
+    b.train_step_pipelined(next_x=xs[2], bits=bs[1])          # primes itself from eng.x ...
+    torch.cuda.synchronize()
+    assert not torch.equal(a.params, b.params)                # ... which still holds xs[5]: a different batch, by design

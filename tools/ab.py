@@ -57,6 +57,8 @@ def main():
             for w in args.what.split(","):
                 if w == "step":
                     fn = lambda: eng.train_step(graph=args.graph)
+                elif w == "step_pipe":
+                    fn = lambda: eng.train_step_pipelined(graph=args.graph)
                 else:
                     fn = ops[w][0]
                 for _ in range(20):

@@ -31,14 +31,19 @@ def main():
     o = ofdm.ofdm_tx(F)
     eng = RxEngine(R.rx_dims(F, o), a.frames, train=True, want_prob=False)
     gen = DeviceDataGen(F, o, seed=1)
-    for _ in range(20):
-        gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
-        eng.train_step()
+    # the training loop of dl_ofdm_amd.receiver.train (device_data): batch i+1 is generated into eng.x / the other label
+    # slot before step i is issued, and normalised behind step i's Adam update
+    def run(n, first):
+        if first:
+            gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.label_slot(0))
+            eng.prime()
+        for i in range(n):
+            gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.label_slot((i + 1) & 1))
+            eng.train_step_pipelined(slot=i & 1)
+    run(20, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.bits)
-        eng.train_step()
+    run(a.steps, False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps(dict(mode="device-generated", channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
