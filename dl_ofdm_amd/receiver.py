@@ -261,8 +261,10 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             steps = n_use // batch_size
             # R0 is software-pipelined across the steps (RxEngine.train_step_pipelined): batch i+1 is generated into
             # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
-            noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=0) if steps else None
-            eng.prime()
+            noise_t = None
+            if steps:
+                noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=0)
+                eng.prime()
             for i in range(steps):
                 last = i + 1 == steps
                 noise_next = None if last else _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=(i + 1) & 1)
