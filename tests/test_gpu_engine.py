@@ -231,3 +231,33 @@ def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits):
     b.train_step_pipelined(next_x=xs[2], bits=bs[1])          # primes itself from eng.x ...
     torch.cuda.synchronize()
     assert not torch.equal(a.params, b.params)                # ... which still holds xs[5]: a different batch, by design
+
+
+@pytest.mark.parametrize("key,value", [(0, 2), (0, 1), (0, 0), (1, 0), (1, 3), (2, 1), (3, 0), (3, 1), (4, 3), (5, 32), (7, 0), (8, 0)])
+def test_every_tuning_setting_computes_the_same_step(key, value):
+    """dccn_set_tuning only selects tile configurations: two training steps under any setting agree with the default
+    ones to rounding (the settings that keep the summation order are bitwise equal; the others regroup fp32 sums)."""
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    lib = _lib.load()
+    dims = RxDims(S=7, kin=80, F=64, D=320, nbits=2)
+    rng = np.random.RandomState(11)
+    x = rng.standard_normal((300, 7, 80, 2)).astype(np.float32)
+    bits = rng.randint(0, 2, (300, 320, 2)).astype(np.int32)
+
+    def run():
+        e = RxEngine(dims, 300, train=True, seed=2, want_prob=True)
+        for _ in range(2):
+            e.train_step(x, bits)
+        torch.cuda.synchronize()
+        return e.params.clone(), e.prob.clone(), e.metrics()
+    default = lib.dccn_get_tuning(key)
+    p0, q0, m0 = run()
+    try:
+        assert lib.dccn_set_tuning(key, value) == 0
+        p1, q1, m1 = run()
+    finally:
+        lib.dccn_set_tuning(key, default)
+    assert float((p1 - p0).abs().max()) <= 2e-6 * float(p0.abs().max())
+    assert float((q1 - q0).abs().max()) <= 2e-6
+    assert abs(m1["ce_mean"] - m0["ce_mean"]) <= 1e-6 and abs(sum(sum(r) for r in m1["conf"]) - sum(sum(r) for r in m0["conf"])) == 0
