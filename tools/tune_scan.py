@@ -23,7 +23,8 @@ from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine, op_launchers
 
 lib = _lib.load()
 dev = torch.device("cuda", 0)
-KEYS = dict(dense_fwd=0, dense_bwd=1, cconv_fwd=2, cconv_bwd_w=3, dense_bwd_splits=4, cconv_bwd_splits=5, smem_kb=6, whole_k=7)
+KEYS = dict(dense_fwd=0, dense_bwd=1, cconv_fwd=2, cconv_bwd_w=3, dense_bwd_splits=4, cconv_bwd_splits=5, smem_kb=6, whole_k=7,
+            skinny=8)
 
 
 def tune(**kw):
