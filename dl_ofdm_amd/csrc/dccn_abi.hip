@@ -898,6 +898,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         case 3: hipLaunchKernelGGL(adam_rx_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         case 4: hipLaunchKernelGGL(adam_rx_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+        case 5: hipLaunchKernelGGL(adam_rx_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
+        case 6: hipLaunchKernelGGL(adam_rx_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         default: hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
     }
     DCCN_LAUNCH_CHECK();

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $ROOT
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_args.json 2> $O/bench_driver_args.err
 python bench.py --graph --no-cpu-baseline --no-other-configs --no-kernel-times > $O/bench_graph.json 2> $O/bench_graph.err
+python bench.py --no-pipeline --no-cpu-baseline --no-other-configs --no-kernel-times > $O/bench_no_pipeline.json 2> $O/bench_no_pipeline.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --no-cpu-baseline --no-kernel-times > $O/kt.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
