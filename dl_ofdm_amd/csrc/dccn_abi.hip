@@ -45,9 +45,10 @@ enum TuneKey : int {
     TUNE_SMEM_MIN_KB = 6,       // minimum dynamic LDS per block of the gemm16 launches (caps resident blocks per CU)
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_SKINNY = 8,            // > 0: GEMMs with <= 96 output rows (the equaliser's 73-frame batch) use small gemm16 tiles
-    TUNE_COUNT = 9
+    TUNE_DENSE_BWD_BIG = 9,     // 1: large dense layers run dX and dW (128x128x32 tiles) as one grouped launch
+    TUNE_COUNT = 10
 };
-static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1};
+static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1, 1};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -347,6 +348,15 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     float* cs = c.take<float>((size_t)sp.splits * N);
     pw.C = slabs; pw.colsum = dbias ? cs : nullptr;
     pw.klen = sp.klen;
+    if (vec && g_tune[TUNE_DENSE_BWD_BIG] && grouped_big_ok(px, pw, sp.splits)) {
+        pw.ldc = N;
+        if (sp.splits == 1) { pw.C = dw; pw.colsum = dbias; pw.slab = 0; }
+        DCCN_TRY((launch_dense_bwd_grouped<true, 128, 128, 32>(px, pw, sp.splits, s)));
+        defer->dw_slabs = sp.splits > 1 ? slabs : nullptr;
+        defer->db_slabs = (sp.splits > 1 && dbias) ? cs : nullptr;
+        defer->splits = sp.splits;
+        return DCCN_OK;
+    }
     if (sp.splits < 2 || !vec || !grouped_ok(px, pw, sp.splits)) {
         DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, defer));
         return dense_bwd_x_impl(dy, w, dx, M, K, N, s);

@@ -478,9 +478,8 @@ static int launch_gemm_cfg(const GemmParams& p, int splits, hipStream_t s) {
     return launch_gemm_cfg2<KA, KB, BM, BN, BK, COLSUM, TAG, false>(p, splits, s);
 }
 
-template <bool VEC>
+template <bool VEC, int BM = 64, int BN = 64, int BK = 64>
 static int launch_dense_bwd_grouped(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
-    constexpr int BM = 64, BN = 64, BK = 64;
     auto kern = dense_bwd_grouped_kernel<BM, BN, BK, VEC>;
     constexpr size_t smem = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, BM, BN, BK>();
     static bool attr_done = false;
@@ -500,6 +499,13 @@ static inline bool grouped_ok(const GemmParams& px, const GemmParams& pw, int sp
     const long long bigx = (long long)ceil_div(px.M, 128) * ceil_div(px.N, 128);
     const long long bigw = (long long)ceil_div(pw.M, 128) * ceil_div(pw.N, 128) * splits_w;
     return bigx < 2 * kCUs && bigw < 2 * kCUs;
+}
+// large layers (N = 1024: 128x128x32 tiles on both GEMMs): the few hundred long dX tiles do not fill a whole number of
+// rounds of the chip (560 tiles on 512 slots at C4), the thousands of short dW tiles behind them in the same grid do
+static inline bool grouped_big_ok(const GemmParams& px, const GemmParams& pw, int splits_w) {
+    const long long bigx = (long long)ceil_div(px.M, 128) * ceil_div(px.N, 128);
+    const long long bigw = (long long)ceil_div(pw.M, 128) * ceil_div(pw.N, 128) * splits_w;
+    return bigx >= 2 * kCUs && bigw >= 2 * kCUs && bigx + bigw < (1LL << 30);
 }
 
 // tile choice: 128x128x32 (four accumulators per wave) only when it still yields >= 2 blocks per CU,
