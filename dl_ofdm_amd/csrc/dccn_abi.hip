@@ -46,9 +46,10 @@ enum TuneKey : int {
     TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
     TUNE_SKINNY = 8,            // > 0: GEMMs with <= 96 output rows (the equaliser's 73-frame batch) use small gemm16 tiles
     TUNE_DENSE_BWD_BIG = 9,     // 1: large dense layers run dX and dW (128x128x32 tiles) as one grouped launch
-    TUNE_COUNT = 10
+    TUNE_DENSE_FWD_PLAIN = 10,  // 1: the un-fused dense forward (nbits >= 3, layer API) of small layers runs 48x64 gemm16 tiles
+    TUNE_COUNT = 11
 };
-static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1, 1};
+static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1, 1, 1};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -169,6 +170,11 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.vecA = (K % 4 == 0) && (lda % 4 == 0) && aligned16(x) && small_enough(M, lda);     // KCONTIG: k extent K
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
     if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD>(g_tune[TUNE_SKINNY], p, s);
+    // small layers (64x64 tiles would leave CUs without a block: 1170x640 = 190 tiles): the 48x64 tiles of the fused
+    // kernel, loads two k-tiles ahead
+    if (g_tune[TUNE_DENSE_FWD_PLAIN] && p.vecA && p.vecB && (K % 4 == 0) && (N % 4 == 0) && K >= 128 &&
+        (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs)
+        return launch_gemm16<OP_KCONTIG, OP_ICONTIG, 1, 4, 3, 1, 64, 1, 0, TAG_DENSE_FWD, 2>(p, 1, s);
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 

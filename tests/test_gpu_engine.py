@@ -234,7 +234,7 @@ def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits):
 
 
 @pytest.mark.parametrize("key,value", [(0, 2), (0, 1), (0, 0), (1, 0), (1, 3), (2, 1), (3, 0), (3, 1), (4, 3), (5, 32), (7, 0), (8, 0),
-                                       (9, 0)])
+                                       (9, 0), (10, 0)])
 def test_every_tuning_setting_computes_the_same_step(key, value):
     """dccn_set_tuning only selects tile configurations: two training steps under any setting agree with the default
     ones to rounding (the settings that keep the summation order are bitwise equal; the others regroup fp32 sums)."""
