@@ -90,10 +90,10 @@ __device__ __forceinline__ void tail_cells(const float (&z0)[W], const float (&z
     constexpr int M = 1 << NB;
     constexpr int O = 2 * NB;
     constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
-    // NB <= 2 (the kernels this function is the whole tail of): the two small matrix products use fused multiply-adds,
-    // bias as the chain's start value -- 36 VALU instructions fewer per cell.  NB >= 3 keeps the separate multiply / add
-    // of demod_tail_quad4_kernel's forward, which training uses for those sizes and which must produce the same bits.
-    constexpr bool FMA_FWD = NB <= 2;
+    // the two small matrix products of the forward are fused multiply-adds with the bias as the chain's start value
+    // (36 VALU instructions fewer per QPSK cell); demod_tail_quad4_kernel evaluates the same expressions, so training
+    // and evaluation produce identical probabilities for every modulation
+    constexpr bool FMA_FWD = true;
     float c[M + 2][W], pre1[M][W];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -436,22 +436,22 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
         float c[M + 2], pre1[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            pre1[j] = (z0 * swl[oW1 + j] + z1 * swl[oW1 + M + j]) + swl[oB1 + j];
+            pre1[j] = __builtin_fmaf(z1, swl[oW1 + M + j], __builtin_fmaf(z0, swl[oW1 + j], swl[oB1 + j]));   // as tail_cells
             c[j] = leaky_relu(pre1[j]);
         }
         c[M] = z0;
         c[M + 1] = z1;
         float w2[M + 2][2];                              // this lane's two columns of dense_1
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = swl[oB2 + 2 * q], s1 = swl[oB2 + 2 * q + 1];
 #pragma unroll
         for (int i = 0; i < M + 2; ++i) {
             const float2 w = *reinterpret_cast<const float2*>(swl + oW2 + i * O + 2 * q);
             w2[i][0] = w.x;
             w2[i][1] = w.y;
-            s0 += c[i] * w.x;
-            s1 += c[i] * w.y;
+            s0 = __builtin_fmaf(c[i], w.x, s0);
+            s1 = __builtin_fmaf(c[i], w.y, s1);
         }
-        const float p20 = s0 + swl[oB2 + 2 * q], p21 = s1 + swl[oB2 + 2 * q + 1];
+        const float p20 = s0, p21 = s1;
         const float u0 = leaky_relu(p20), u1 = leaky_relu(p21);
         const bool u1_big = u1 > u0;
         const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
