@@ -555,8 +555,33 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
 #pragma unroll
             for (int ci = 0; ci < NCELL; ++ci) cprob[ci] = nullptr;
         }
-        if constexpr (!(GEMM16_ABL & 64))
-            tail_cells<NB, BWD, NCELL>(cz0, cz1, labs, cvalid, tp.tailp, tp.inv_count, cprob, A, cdzv);
+        // (at most 8 cells share one interleaved instruction stream: larger tiles run the tail in batches -- same
+        // per-cell arithmetic and the same accumulation order as one batch)
+        if constexpr (!(GEMM16_ABL & 64)) {
+            constexpr int TW = NCELL <= 8 ? NCELL : (NCELL % 8 == 0 ? 8 : (NCELL % 6 == 0 ? 6 : (NCELL % 5 == 0 ? 5 : 4)));
+            static_assert(NCELL % TW == 0, "tail batches");
+            if constexpr (TW == NCELL) {
+                tail_cells<NB, BWD, NCELL>(cz0, cz1, labs, cvalid, tp.tailp, tp.inv_count, cprob, A, cdzv);
+            } else {
+#pragma unroll
+                for (int g0 = 0; g0 < NCELL; g0 += TW) {
+                    float a0[TW], a1[TW];
+                    int lb[TW][NB];
+                    bool vd[TW];
+                    float* pc[TW];
+                    float2 dv[TW];
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) {
+                        a0[u] = cz0[g0 + u]; a1[u] = cz1[g0 + u]; vd[u] = cvalid[g0 + u]; pc[u] = cprob[g0 + u];
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) lb[u][j] = labs[g0 + u][j];
+                    }
+                    tail_cells<NB, BWD, TW>(a0, a1, lb, vd, tp.tailp, tp.inv_count, pc, A, dv);
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) cdzv[g0 + u] = dv[u];
+                }
+            }
+        }
         if constexpr (BWD && !(GEMM16_ABL & 32)) {
 #pragma unroll
             for (int ci = 0; ci < NCELL; ++ci)
