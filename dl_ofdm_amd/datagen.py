@@ -131,10 +131,14 @@ class DeviceDataGen:
         off = self.offset if offset is None else int(offset)
         if isinstance(snr_db, torch.Tensor):
             w["snr"].copy_(snr_db.reshape(-1).to(torch.float32))
+            w["snr_scalar"] = None
         elif np.isscalar(snr_db):
-            w["snr"].fill_(float(snr_db))
+            if w.get("snr_scalar") != float(snr_db):           # a training run keeps one SNR: fill once, not per batch
+                w["snr"].fill_(float(snr_db))
+                w["snr_scalar"] = float(snr_db)
         else:
             w["snr"].copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)))
+            w["snr_scalar"] = None
         if out_x is None:
             out_x = torch.empty(n, self.S, self.n_sc, 2, dtype=torch.float32, device=self.device)
         hshape = (n, self.S, self.K, 2) if (self.doppler or self.mixed) else (n, self.K, 2)
