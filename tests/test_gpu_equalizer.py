@@ -203,7 +203,8 @@ def test_equalizer_forward_and_gradients(nbits, B):
         want = g_ref[n].ravel()
         cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
         assert cos >= 1 - 1e-6, (n, cos)
-        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), (n, np.abs(got - want).max(), np.abs(want).max())
+        # (+ 1e-8 absolute: conv3d_1/bias is a 2e-5 difference of O(1e-2) sums -- fp32 accumulation noise, not a scale error)
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-8, (n, np.abs(got - want).max(), np.abs(want).max())
     assert all(p_.grad is None for p_ in rx.store.parameters())           # receiver stays frozen
 
 
