@@ -191,13 +191,7 @@ static GemmParams dense_bwd_x_params(const float* dy, const float* w, float* dx,
 
 static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
     if (!dy || !w || !dx || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
-    GemmParams p = gp_zero();                 // dx[M,K] = dy[M,N] . w[K,N]^T
-    p.A = dy; p.B = w; p.C = dx;
-    p.M = M; p.N = K; p.K = N;
-    p.lda = N; p.ldb = N; p.ldc = K;
-    p.klen = round_k(N);
-    p.vecA = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
-    p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);
+    const GemmParams p = dense_bwd_x_params(dy, w, dx, M, K, N);
     if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_KCONTIG, TAG_DENSE_BWD_X>(g_tune[TUNE_SKINNY], p, s);
     return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
 }
@@ -277,8 +271,8 @@ static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* d
         return DCCN_OK;
     }
     const long long n = (long long)K * N;
-    DCCN_TRY(launch_splitk_reduce(slabs, sp.splits, n, dw, n, s));
-    if (dbias) DCCN_TRY(launch_splitk_reduce(cs, sp.splits, (long long)N, dbias, (long long)N, s));
+    if (dbias) DCCN_TRY(launch_splitk_reduce2(slabs, sp.splits, n, dw, n, cs, (long long)N, dbias, (long long)N, s));
+    else DCCN_TRY(launch_splitk_reduce(slabs, sp.splits, n, dw, n, s));
     return DCCN_OK;
 }
 
@@ -753,11 +747,15 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     return DCCN_OK;
 }
 
+// prep = false: the per-step bookkeeping (alpha, beta powers, global_step) already rode on an earlier kernel of the step
 static int adam_impl(float* param, const float* grad, float* m, float* v, const float* reg_coef,
-                     const float* reg_gate, dccn_adam_state* st, dccn_adam_hparams hp, long long n, hipStream_t s) {
+                     const float* reg_gate, dccn_adam_state* st, dccn_adam_hparams hp, long long n, hipStream_t s,
+                     bool prep = true) {
     if (!param || !grad || !m || !v || !st || n <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, st, hp);
-    DCCN_LAUNCH_CHECK();
+    if (prep) {
+        hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, st, hp);
+        DCCN_LAUNCH_CHECK();
+    }
     long long blocks = ceil_div_ll(ceil_div_ll(n, 4), 256);
     if (blocks > 4 * kCUs) blocks = 4 * kCUs;
     hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, param, grad, m, v, reg_coef,

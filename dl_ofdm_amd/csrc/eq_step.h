@@ -122,9 +122,10 @@ static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, 
     DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds));
     if (ds.dw_slabs) {
         const long long n = (long long)K * N;
-        DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw, n, s));
         if (dbias && ds.db_slabs)
-            DCCN_TRY(launch_splitk_reduce(ds.db_slabs, ds.splits, (long long)N, dbias, (long long)N, s));
+            DCCN_TRY(launch_splitk_reduce2(ds.dw_slabs, ds.splits, n, dw, n, ds.db_slabs, (long long)N, dbias, (long long)N, s));
+        else
+            DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw, n, s));
     }
     return DCCN_OK;
 }
@@ -153,8 +154,9 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
 
     // `input:0` (ofdmreceiver_np.py:128-137) + tx_power partials
     PowerPartials pp;
-    DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, d.S * N2, 1e-9f, 8.0f, nullptr,
-                       hp, w.ws_norm, w.n_norm, s));
+    // (training: the optimizer's per-step bookkeeping rides on this first launch)
+    DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, d.S * N2, 1e-9f, 8.0f,
+                       train ? b->adam : nullptr, hp, w.ws_norm, w.n_norm, s));
     // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"
     hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
                        (float*)nullptr, d.S * N2, 1e-12f);
@@ -246,5 +248,5 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_split, w.n_split, s, nullptr,
                               N2));
     // optimizer: Equalizer/* only (ofdmreceiver_np_mp.py:330), L2 terms enter through reg_coef
-    return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s);
+    return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s, false);
 }

@@ -559,11 +559,11 @@ constexpr int kRedLanes = 64, kRedGroups = 4;
 
 // out[i] = sum_z partial[z*slab + i],  i in float4 units when vec4
 template <bool VEC4>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits,
-                                                            long long slab, float* __restrict__ out, long long n) {
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ partial, int splits, long long slab,
+                                                   float* __restrict__ out, long long n, const int block) {
     __shared__ float4 red[kRedGroups][kRedLanes];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long i = ((long long)blockIdx.x * kRedLanes + lane) * (VEC4 ? 4 : 1);
+    const long long i = ((long long)block * kRedLanes + lane) * (VEC4 ? 4 : 1);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
         // batches of 8 slabs: loads first (clamped slab index, weight by validity), then a fixed-order sum
@@ -595,6 +595,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         else out[i] = t.x;
     }
 }
+template <bool VEC4>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                            long long slab, float* __restrict__ out, long long n) {
+    splitk_reduce_body<VEC4>(partial, splits, slab, out, n, (int)blockIdx.x);
+}
+// two reductions of the same split count in one launch (a weight gradient and its bias gradient): blocks [0, blocks_a)
+// take segment a, the rest segment b (scalar path)
+template <bool VEC4A>
+__global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __restrict__ pa, long long slab_a,
+                                                             float* __restrict__ out_a, long long na, int blocks_a,
+                                                             const float* __restrict__ pb, long long slab_b,
+                                                             float* __restrict__ out_b, long long nb, int splits) {
+    if ((int)blockIdx.x < blocks_a) splitk_reduce_body<VEC4A>(pa, splits, slab_a, out_a, na, (int)blockIdx.x);
+    else splitk_reduce_body<false>(pb, splits, slab_b, out_b, nb, (int)blockIdx.x - blocks_a);
+}
 
 static int launch_splitk_reduce(const float* partial, int splits, long long slab, float* out, long long n,
                                 hipStream_t s) {
@@ -603,6 +618,20 @@ static int launch_splitk_reduce(const float* partial, int splits, long long slab
     const unsigned blocks = (unsigned)ceil_div_ll(units, kRedLanes);
     if (vec4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, partial, splits, slab, out, n);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, partial, splits, slab, out, n);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+static int launch_splitk_reduce2(const float* pa, int splits, long long slab_a, float* out_a, long long na,
+                                 const float* pb, long long slab_b, float* out_b, long long nb, hipStream_t s) {
+    const bool vec4 = (na % 4 == 0) && (slab_a % 4 == 0) && aligned16(pa) && aligned16(out_a);
+    const int blocks_a = (int)ceil_div_ll(vec4 ? na / 4 : na, kRedLanes), blocks_b = (int)ceil_div_ll(nb, kRedLanes);
+    if (vec4)
+        hipLaunchKernelGGL(splitk_reduce2_kernel<true>, dim3(blocks_a + blocks_b), dim3(256), 0, s, pa, slab_a, out_a, na,
+                           blocks_a, pb, slab_b, out_b, nb, splits);
+    else
+        hipLaunchKernelGGL(splitk_reduce2_kernel<false>, dim3(blocks_a + blocks_b), dim3(256), 0, s, pa, slab_a, out_a, na,
+                           blocks_a, pb, slab_b, out_b, nb, splits);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
