@@ -415,10 +415,16 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
                     bj = p.bias[col];
                 }
             }
+            if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
+                float* Cc = Cz + (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[a][b][r] + bj;
+                for (int r = 0; r < 16; ++r) Cc[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[a][b][r] + bj;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[a][b][r] + bj;
+                }
             }
         }
     }

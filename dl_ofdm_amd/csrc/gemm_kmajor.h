@@ -164,11 +164,18 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
 
     float* Cz = p.C + (size_t)z * p.slab;
     const int col = n0 + 4 * c;
+    if (m0 + BT <= p.M && n0 + BT <= p.N) {                // interior tile (block-uniform): stores without exec masks
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 16 * kq + 4 * r + w;
-        if (row < p.M && col < p.N)
-            *reinterpret_cast<float4*>(Cz + (size_t)row * p.ldc + col) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(Cz + (size_t)(m0 + 16 * kq + 4 * r + w) * p.ldc + col) =
+                make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * kq + 4 * r + w;
+            if (row < p.M && col < p.N)
+                *reinterpret_cast<float4*>(Cz + (size_t)row * p.ldc + col) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
     }
     if (COLSUM && do_cs) {
         // wave 0 has seen every element of the B rows once: lanes c, c+16, c+32, c+48 hold the same four columns
