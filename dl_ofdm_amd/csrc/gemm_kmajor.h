@@ -144,15 +144,20 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             for (int tt = 0; tt < 4; ++tt)
                 acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1], f4c(fb[ks & 1], tt), acc[tt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (COLSUM && do_cs) {
-                const float4 b = fb[ks & 1];
-                bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w;
-            }
             if constexpr (MODE != PF_NONE) {
                 if (ks >= NKS - 2 * NV) {
                     if constexpr (MODE == PF_FAST) store(TFalse{}, ks - (NKS - 2 * NV), An, Bn);
                     else store(TTrue{}, ks - (NKS - 2 * NV), An, Bn);
                 }
+            }
+        }
+        // bias gradient: wave 0 of the m0 == 0 tiles re-reads the B rows it just multiplied (a real branch around LDS
+        // loads: as selects inside the loop above the compiler executed these adds in every wave of every block)
+        if (COLSUM && do_cs) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const float4 b = *reinterpret_cast<const float4*>(Bs + 4 * ks * BT);
+                bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w;
             }
         }
         __syncthreads();
