@@ -110,7 +110,8 @@ def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True):
     from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine
     c = CONFIGS[name]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
-    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False)
+    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False,
+                   want_dfft=False)
     g = torch.Generator(device=dev)
     g.manual_seed(4321)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
@@ -133,6 +134,66 @@ def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True):
             "mfma_frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "bits_counted": int(m["count"])}
 
 
+SWEEP = dict(nbits=4, channel="EVA", frames=20000, snr_lo=-10, snr_hi=29,
+             workload="16-QAM, Rayleigh EVA, N=64/CP=16, SNR sweep -10:29 dB (40 points x 20 000 frames, "
+                      "dev/py/ofdmreceiver_np.py:59-91), frames generated on the device, evaluation only")
+
+
+def measure_sweep(dev, rank, world, reps=2, frames=None):
+    """BASELINE.json configs[2]: the SNR sweep of a 16-QAM receiver on EVA, sharded over the ranks exactly like
+    dl_ofdm_amd.sweep shards every sweep of the harness (point i -> rank i % world; a point's 20 000 frames are one batch:
+    R0's batch statistics couple them) and reduced by ONE all-reduce of the [points, 6] table.  Per point: five generator
+    launches (bits -> grid -> IFFT+CP -> EVA taps -> FIR -> AWGN) + the evaluation step + one table row update, all
+    stream-ordered, no host round trip.  Strong scaling: the 40 points are fixed, time = slowest rank."""
+    import torch
+    import torch.distributed as dist
+    from dl_ofdm_amd import _lib, ofdm, receiver as R, sweep
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    from dl_ofdm_amd.engine import RxEngine
+    lib = _lib.load()
+    frames = int(frames or SWEEP["frames"])
+    F = R.Flags(nbits=SWEEP["nbits"], nfilter=64, channel=SWEEP["channel"], device_data=True, seed=1, test_frames=frames)
+    o = ofdm.ofdm_tx(F)
+    eng = RxEngine(R.rx_dims(F, o), frames, device=dev, train=False, seed=1, want_prob=False, want_tx_power=True, want_z=True)
+    gen = DeviceDataGen(F, o, device=dev, seed=1)
+    pts = sweep.make_points([F.nbits], [F.channel], range(SWEEP["snr_lo"], SWEEP["snr_hi"] + 1), base_seed=1)
+    table = torch.zeros(len(pts), 6, dtype=torch.float64, device=dev)
+
+    def evaluate_into(p, row):
+        gen.seed, gen.offset = p.seed, 0
+        gen.make_batch(frames, p.snr_db, out_x=eng.x, out_bits=eng.bits)
+        eng.eval_step()
+        _lib.check(lib.dccn_metrics_table_add(eng.metrics_buf.data_ptr(), row.data_ptr(), eng._stream()), "table_add")
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    best = None
+    for rep in range(reps + 1):               # rep 0 = warm-up (code objects, clocks, RCCL channels)
+        barrier()
+        t0 = time.perf_counter()
+        sweep.run_sweep_device(pts, evaluate_into, rank, world, device=dev, table=table)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+        if rep > 0 and (best is None or el < best):
+            best = el
+    t = table.cpu().numpy()
+    ber, _ = sweep.ber_loss(t)
+    nsym = len(pts) * frames * F.nsymbol
+    return {"workload": SWEEP["workload"], "points": len(pts), "frames_per_point": frames, "n_gpus": world,
+            "points_per_rank": [len(sweep.shard(pts, r, world)) for r in range(world)], "scaling": "strong",
+            "seconds": best, "points_per_s": len(pts) / best, "symbols_per_s": nsym / best,
+            "bits_counted": int(t[:, 5].sum()), "ber_first_last": [float(ber[0]), float(ber[-1])],
+            "collective": "one all-reduce of the [40, 6] float64 table" if world > 1 else "none (1 rank)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +211,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short C3 / C4 measurements of the `configs` object")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the `sweep` object (configs[2]: 40-point SNR sweep sharded over the ranks)")
+    ap.add_argument("--sweep-frames", type=int, default=0, help="frames per sweep point (default 20 000, the reference's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,7 +248,8 @@ def main():
     S, kin = 7, c["nfft"] + c["cp"]
     dims = RxDims(S=S, kin=kin, F=c["F"], D=c["D"], nbits=c["nbits"])
     eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1 + rank, want_prob=True, want_tx_power=True,
-                   want_z=False)      # z (dense output) is consumed inside the fused dense+tail launch, never stored
+                   want_z=False, want_dfft=False)   # z / dfft are consumed inside the launches that produce them (fused
+    #                                                  dense+tail forward, fused backward) whenever the library's plan allows
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
@@ -234,8 +298,12 @@ def main():
     t_enqueue = time.perf_counter() - t0                        # host cost of issuing the K steps (no sync yet)
     reduce_table()
     timer.stop(eng._stream())
-    barrier()
+    # a rank's time = common start (barrier above) -> its own K steps and the table reduction have completed; the job's
+    # time = MAX over ranks.  (The closing barrier is taken after the clock is read: with the driver's K = 20 a step
+    # sequence lasts 1.5 ms, and a second RCCL barrier inside it would be timed instead of the path.)
+    torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    barrier()
     ev_ms = timer.elapsed_ms()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -253,7 +321,7 @@ def main():
         "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
                    "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
                    "launch": (("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph
-                              else "stream launches") + (", R0 of the next batch behind the Adam update (5 launches per step)"
+                              else "stream launches") + (", R0 of the next batch behind the Adam update (4 launches per step: C-Conv fwd, dense fwd + tail, fused backward, optimizer)"
                                                           if pipeline else ", 6 launches per step"),
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }
@@ -269,8 +337,12 @@ def main():
             result["kernels"] = {k: {"us": round(v["ms"] * 1e3, 3), "tflops": round(v["tflops"], 2), "kernel": v["kernel"]}
                                  for k, v in kt.items()}
             dfw = "dense_tail_fwd_bwd" if "dense_tail_fwd_bwd" in kt else "dense_fwd"
-            in_step = ("cconv_fwd", dfw, "dense_bwd_slabs", "cconv_bwd_w") if not fork else \
-                ("cconv_fwd", dfw, "dense_bwd_x", "dense_bwd_w", "cconv_bwd_w")
+            if fork:
+                in_step = ("cconv_fwd", dfw, "dense_bwd_x", "dense_bwd_w", "cconv_bwd_w")
+            elif "rx_backward" in kt:          # the backward half of the step is one launch (rx_bwd.h)
+                in_step = ("cconv_fwd", dfw, "rx_backward")
+            else:
+                in_step = ("cconv_fwd", dfw, "dense_bwd_slabs", "cconv_bwd_w")
             gemm = {k: v for k, v in kt.items() if k in in_step}
             dom = max(gemm, key=lambda k: gemm[k]["ms"])
             traffic = None
@@ -287,9 +359,19 @@ def main():
         if world == 1 and args.config == "c2" and not args.no_other_configs:
             # the other BASELINE.json training configurations, measured in the same run (short: <= 20 steps each, hipGraph
             # replay, HIP events on the launch stream): C3 = config[2] shape (16-QAM), C4 = config[3] (N=1024, MFMA-bound)
-            del eng
+            eng = None
             torch.cuda.empty_cache()
             result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph, pipeline=pipeline) for k in ("c3", "c4")}
+    sweep_res = None
+    if args.config == "c2" and not args.no_sweep:
+        # configs[2] on every rank count the driver launches: this is the curve north_star calls "1/2/4/8-GPU SNR-sweep
+        # scaling" (the training value above is weak scaling of replicas by construction)
+        eng = None
+        torch.cuda.empty_cache()
+        sweep_res = measure_sweep(dev, rank, world, frames=args.sweep_frames or None)
+    if rank == 0:
+        if sweep_res is not None:
+            result["sweep"] = sweep_res
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()

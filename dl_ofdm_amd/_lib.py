@@ -113,6 +113,10 @@ SIGNATURES = {
     "dccn_ingraph_awgn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
     "dccn_set_tuning": (_i, [_i, _i]),
     "dccn_get_tuning": (_i, [_i]),
+    "dccn_dense_tail_supported": (_i, [_i, _i, _i, _i]),
+    "dccn_rx_bwd_fused_supported": (_i, [POINTER(RxShape)]),
+    "dccn_rx_backward_workspace_size": (_sz, [_i, _i, _i, _i, _i]),
+    "dccn_rx_backward": (_i, [_vp] * 9 + [_i] * 6 + [_vp, _sz, _vp]),
     "dccn_adam_tf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, AdamHParams, _ll, _vp]),
     "dccn_rx_param_offsets": (_i, [POINTER(RxShape), POINTER(c_longlong)]),
     "dccn_rx_workspace_size": (_sz, [POINTER(RxShape), _i]),

@@ -349,30 +349,45 @@ class ClassicalReceiver:
         return self.demap(Y[:, self.dat] / G[:, self.dat])
 
 
+class CurvePoints:
+    """One estimator on one (modulation, channel): SNR point ``i`` of a curve as an independent unit -- its draws depend
+    only on (seed, i), so the points of a curve may be evaluated in any order, on any rank (config5 deals them round-robin
+    over the GPUs' host processes).  ``point`` returns (bit errors, bits)."""
+
+    def __init__(self, FLAGS, method: str, n_frames: int = 2000, seed: int = 1, mobile: bool = False, mapping: str = "table",
+                 aligned: bool = True):
+        self.FLAGS, self.method, self.n_frames, self.seed, self.aligned = FLAGS, method, int(n_frames), int(seed), aligned
+        self.o = ofdm.ofdm_tx(FLAGS)
+        self.rxr = ClassicalReceiver(FLAGS, self.o, mapping=mapping)
+        self.fading = radio.rayleigh_chan_lte(FLAGS, self.o.Fs, mobile=mobile)
+        self.awgn = FLAGS.channel.lower() == "awgn"
+        if method == "LMMSE-Fast" and not self.awgn:
+            self.R_long = self.rxr.long_term_correlation(self.fading, aligned)
+        elif method in ("LMMSE-UniPDP", "LMMSE-ExpPDP") and not self.awgn:
+            self.R_long = self.rxr.pdp_correlation(self.fading, uniform=(method == "LMMSE-UniPDP"), aligned=aligned)
+        else:
+            self.R_long = np.ones((self.o.K, self.o.K), dtype=np.complex128)
+
+    def point(self, i: int, snr: float):
+        np.random.seed(self.seed + 7919 * i)
+        bits = util.bit_source(self.FLAGS.nbits, self.o.frame_size, self.n_frames)
+        iq = self.rxr.transmit(bits)
+        y, H = self.fading.run(iq)
+        rx, _ = radio.AWGN_channel_np(y, snr * np.ones((self.n_frames, 1)))
+        det = self.rxr.receive(rx, self.method, snr, H_true=H, R_long=self.R_long,
+                               advance=0 if self.awgn else self.rxr.advance_of(self.fading), aligned=self.aligned)
+        return int(np.count_nonzero(det != bits)), int(bits.size)
+
+
 def ber_curve(FLAGS, method: str, snrs: Sequence[float], n_frames: int = 2000, seed: int = 1, mobile: bool = False,
               mapping: str = "table", aligned: bool = True):
     """BER of one estimator over an SNR list on FLAGS.channel / FLAGS.nbits (bits -> transmitter of the chosen mapping
     -> radio.py channel + AWGN)."""
-    o = ofdm.ofdm_tx(FLAGS)
-    rxr = ClassicalReceiver(FLAGS, o, mapping=mapping)
-    fading = radio.rayleigh_chan_lte(FLAGS, o.Fs, mobile=mobile)
-    awgn = FLAGS.channel.lower() == "awgn"
-    if method == "LMMSE-Fast" and not awgn:
-        R_long = rxr.long_term_correlation(fading, aligned)
-    elif method in ("LMMSE-UniPDP", "LMMSE-ExpPDP") and not awgn:
-        R_long = rxr.pdp_correlation(fading, uniform=(method == "LMMSE-UniPDP"), aligned=aligned)
-    else:
-        R_long = np.ones((o.K, o.K), dtype=np.complex128)
+    cp = CurvePoints(FLAGS, method, n_frames, seed, mobile, mapping, aligned)
     out = []
     for i, snr in enumerate(snrs):
-        np.random.seed(seed + 7919 * i)
-        bits = util.bit_source(FLAGS.nbits, o.frame_size, n_frames)
-        iq = rxr.transmit(bits)
-        y, H = fading.run(iq)
-        rx, _ = radio.AWGN_channel_np(y, snr * np.ones((n_frames, 1)))
-        det = rxr.receive(rx, method, snr, H_true=H, R_long=R_long,
-                          advance=0 if FLAGS.channel.lower() == "awgn" else rxr.advance_of(fading), aligned=aligned)
-        out.append(float(np.mean(det != bits)))
+        e, n = cp.point(i, snr)
+        out.append(e / n)
     return np.asarray(out)
 
 

@@ -4,8 +4,9 @@ next to the classical LMMSE / LS receivers of :mod:`dl_ofdm_amd.benchmark` (dev/
 
 The (modulation, channel, SNR) points are independent units (own data, own batch statistics, own confusion matrix): they
 are dealt round-robin to the ranks of a ``torch.distributed`` job, one process per GPU, and meet in ONE all-reduce of
-the ``[points, 6]`` table (sweep.py).  Every rank trains the (small) models itself -- seconds each, bitwise
-reproducible from the seeds -- so no parameter broadcast is needed.
+the ``[points, 6]`` table (sweep.py).  The expensive stages shard the same way: the four (receiver -> equaliser) training
+chains are dealt to ranks and the trained arenas broadcast (9 MB per modulation), the classical receivers' (modulation,
+channel, estimator, SNR) units are dealt round-robin and meet in one more all-reduce.  Nothing is replicated.
 
     python tools/config5_sweep.py --out profiles/r02_config5 [--frames 20000] [--eq_epochs 600]
 """
@@ -42,25 +43,97 @@ def init_distributed(backend: Optional[str] = None):
     return rank, world, local
 
 
+def job_owners(nbits_list: Sequence[int], world: int) -> Dict[int, int]:
+    """Training jobs = one (receiver -> equaliser) chain per modulation (the reference driver runs each as an OS process
+    of its own, dev/py/run_local_ofdm.py:61-118; the equaliser needs ITS receiver, so a chain is the independent unit).
+    Longest chain first (epochs scale with nbits), each to the least-loaded rank so far (LPT): 2 ranks get {4, 1} and
+    {3, 2}, 4 or more ranks one chain each."""
+    load = [0] * max(world, 1)
+    owners = {}
+    for b in sorted((int(b) for b in nbits_list), reverse=True):
+        r = min(range(len(load)), key=lambda i: (load[i], i))
+        owners[b] = r
+        load[r] += b
+    return owners
+
+
+def _broadcast(t, src: int, group=None):
+    """One tensor from its owner to every rank (RCCL on device tensors; gloo stages through the host)."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs: int, rx_epoch_scale: float = 1.0,
-                 rank: int = 0, device="cuda", verbose: bool = False):
-    """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded)."""
-    from . import receiver as R, receiver_mp as H
-    t0, trainers = time.time(), {}
-    for nbits in nbits_list:
+                 rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
+                 timing: Optional[dict] = None):
+    """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
+
+    world > 1: each chain is trained by its owner only (job_owners); the owner then broadcasts the two flat arenas
+    (receiver 2.3 MB, equaliser 7 MB) and the other ranks build the same trainer around them.  Training is bitwise
+    reproducible from the seeds, so the trainers equal those of a serial run whatever the rank count."""
+    import torch
+    from . import ofdm, receiver as R, receiver_mp as H
+    from .engine import PARAM_NAMES, param_layout
+    from .equalizer import EqualizerTrainer
+    owners = job_owners(nbits_list, world)
+    t0, trainers, flags = time.time(), {}, {}
+    for nbits in sorted(owners, reverse=True):
         save = os.path.join(out_dir, "ckpt_r%d/" % rank)
         rf = R.Flags(nbits=nbits, nfilter=64, channel="AWGN", SNR=5.0 * nbits,
                      max_epoch_num=max(1, int(1200 * nbits * rx_epoch_scale)), early_stop=200, token="C5_%dmod" % nbits,
                      save_dir=save, device_data=True, seed=nbits)
-        res = R.train(rf, device=device, verbose=False, run_test=False)
         hf = H.Flags(nbits=nbits, nfilter=64, channel="mixRayleigh", max_epoch_num=eq_epochs, early_stop=200,
                      token=rf.token, save_dir=save, device_data=True, seed=10 + nbits, test_frames=frames)
+        flags[nbits] = (rf, hf)
+        if owners[nbits] != rank:
+            continue
+        t1 = time.time()
+        res = R.train(rf, device=device, verbose=False, run_test=False)
+        t2 = time.time()
         out = H.train(hf, device=device, verbose=False, run_test=False, rx_params=res["params"])
         H.load_checkpoint(out["best_path"], out["trainer"], with_optimizer=False)
         trainers[nbits] = (hf, out["trainer"])
+        if timing is not None:
+            timing["train_rx_%d" % nbits] = t2 - t1
+            timing["train_eq_%d" % nbits] = time.time() - t2
         if verbose:
-            print("nbits %d: receiver %d epochs, equaliser %d epochs, %.0f s"
-                  % (nbits, len(res["history"]), len(out["history"]), time.time() - t0))
+            print("rank %d nbits %d: receiver %d epochs %.0f s, equaliser %d epochs %.0f s"
+                  % (rank, nbits, len(res["history"]), t2 - t1, len(out["history"]), time.time() - t2), flush=True)
+    if timing is not None:
+        timing["train_total"] = time.time() - t0
+    if world > 1:
+        t3 = time.time()
+        for nbits in sorted(owners, reverse=True):
+            rf, hf = flags[nbits]
+            o = ofdm.ofdm_tx(hf)
+            lay, total = param_layout(R.rx_dims(rf, o))
+            if owners[nbits] == rank:
+                tr = trainers[nbits][1]
+                rx_arena, eq_arena = tr.rx_arena, tr.params
+                n_eq = torch.tensor([eq_arena.numel()], dtype=torch.int64, device=rx_arena.device)
+            else:
+                rx_arena = torch.zeros(total, dtype=torch.float32, device=device)
+                n_eq = torch.zeros(1, dtype=torch.int64, device=device)
+            _broadcast(rx_arena, owners[nbits], group)
+            _broadcast(n_eq, owners[nbits], group)
+            if owners[nbits] != rank:
+                rxp = {n: rx_arena[lay[n][0]:lay[n][0] + int(np.prod(lay[n][1]))].view(*lay[n][1]).cpu().numpy()
+                       for n in PARAM_NAMES}
+                tr = EqualizerTrainer(hf, o, rxp, device=device, seed=hf.seed)
+                assert tr.params.numel() == int(n_eq.item())
+                eq_arena = tr.params
+                trainers[nbits] = (hf, tr)
+            with torch.no_grad():
+                _broadcast(eq_arena, owners[nbits], group)
+        if timing is not None:
+            timing["broadcast"] = time.time() - t3
     return trainers
 
 
@@ -93,37 +166,87 @@ def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str
     return pts, table
 
 
+CLASSICAL_METHODS = ("LMMSE", "LS-Spline", "Perfect")
+
+
+def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: Sequence[int], n_frames: int,
+                     rank: int = 0, world: int = 1, group=None, seed: int = 5, methods: Sequence[str] = CLASSICAL_METHODS):
+    """The LMMSE / LS baseline curves (dev/m/OFDM_Benchmark_dev.m:339-456 via dl_ofdm_amd.benchmark), one unit per
+    (modulation, channel, estimator, SNR) -- each with its own seeded draws -- dealt round-robin to the ranks; ONE
+    all-reduce of the [units, 2] table {bit errors, bits}.  Returns {(nbits, channel, method): BER per csnr}."""
+    import torch
+    from . import benchmark, receiver as R, sweep
+    units = [(b, ch, m, i) for b in nbits_list for ch in channels for m in methods for i in range(len(csnr))]
+    table = torch.zeros(len(units), 2, dtype=torch.float64)
+    cache = {}
+    for u, (b, ch, m, i) in enumerate(units):
+        if u % max(world, 1) != rank:
+            continue
+        key = (b, ch, m)
+        if key not in cache:
+            cache[key] = benchmark.CurvePoints(R.Flags(nbits=b, channel=ch), m, n_frames=n_frames, seed=seed)
+        e, n = cache[key].point(i, float(csnr[i]))
+        table[u, 0], table[u, 1] = e, n
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend(group) != "gloo":
+            table = table.cuda()
+        sweep.reduce_table(table, world, group)
+        table = table.cpu()
+    t = table.numpy()
+    out = {}
+    for u, (b, ch, m, i) in enumerate(units):
+        out.setdefault((b, ch, m), np.zeros(len(csnr)))[i] = t[u, 0] / max(t[u, 1], 1.0)
+    return out
+
+
 def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frames: int = 1500, rx_epoch_scale: float = 1.0,
         nbits_list: Sequence[int] = (1, 2, 3, 4), channels: Sequence[str] = CHANNELS, snrs: Sequence[int] = SNRS,
         classical_every: int = 3, rank: int = 0, world: int = 1, device="cuda", verbose: bool = True):
-    """Train, sweep, and (rank 0) write ``<out_dir>/config5_ber.csv``; returns (points, BER per point)."""
-    from . import benchmark, receiver as R, sweep
+    """Train (chains dealt to ranks), sweep (points dealt to ranks), classical curves (units dealt to ranks); rank 0
+    writes ``<out_dir>/config5_ber.csv`` and ``config5_timing.json`` (wall time per stage and rank).  Returns
+    (points, BER per point)."""
+    import json
+    from . import benchmark, sweep
     os.makedirs(out_dir, exist_ok=True)
     t0 = time.time()
-    trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose and rank == 0)
+    timing = {}
+    trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
+                            timing=timing)
+    t1 = time.time()
     pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world)
     ber, _ = sweep.ber_loss(table)
+    timing["sweep"] = time.time() - t1
+    if verbose and rank == 0:
+        print("DCCN sweep done: %d points, %.0f s since start" % (len(pts), time.time() - t0), flush=True)
+    t2 = time.time()
+    csnr = list(snrs)[::classical_every]
+    classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world)
+    timing["classical"] = time.time() - t2
+    timing["total"] = time.time() - t0
+    all_t = [timing]
+    if world > 1:
+        import torch.distributed as dist
+        all_t = [None] * world
+        dist.all_gather_object(all_t, timing)
     if rank == 0:
-        if verbose:
-            print("DCCN sweep done: %d points, %.0f s" % (len(pts), time.time() - t0))
-        csnr = list(snrs)[::classical_every]
-        classical = {}
-        for nbits in nbits_list:
-            for ch in channels:
-                fl = R.Flags(nbits=nbits, channel=ch)
-                for m in ("LMMSE", "LS-Spline", "Perfect"):
-                    classical[(nbits, ch, m)] = benchmark.ber_curve(fl, m, csnr, n_frames=classical_frames, seed=5)
         with open(os.path.join(out_dir, "config5_ber.csv"), "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["modulation", "channel", "SNR", "DCCN+Equalizer", "LMMSE", "LS-Spline", "Perfect"])
+            w.writerow(["modulation", "channel", "SNR", "DCCN+Equalizer"] + list(CLASSICAL_METHODS))
             for p in pts:
                 row = [benchmark.MOD_NAMES[p.nbits - 1], p.channel, int(p.snr_db), "%.6g" % ber[p.index]]
                 if int(p.snr_db) in csnr:
                     j = csnr.index(int(p.snr_db))
-                    row += ["%.6g" % classical[(p.nbits, p.channel, m)][j] for m in ("LMMSE", "LS-Spline", "Perfect")]
+                    row += ["%.6g" % classical[(p.nbits, p.channel, m)][j] for m in CLASSICAL_METHODS]
                 else:
                     row += ["", "", ""]
                 w.writerow(row)
+        # what every rank spent where: nothing is replicated (training chains, sweep points and classical units are all
+        # dealt to ranks); `broadcast` + the table reductions are the only joint steps
+        with open(os.path.join(out_dir, "config5_timing.json"), "w") as f:
+            json.dump({"world": world, "frames": frames, "eq_epochs": eq_epochs, "rx_epoch_scale": rx_epoch_scale,
+                       "classical_frames": classical_frames, "points": len(pts), "job_owners": job_owners(nbits_list, world),
+                       "per_rank_seconds": all_t}, f, indent=1)
         if verbose:
-            print("wrote %s, total %.0f s" % (os.path.join(out_dir, "config5_ber.csv"), time.time() - t0))
+            print("wrote %s, total %.0f s" % (os.path.join(out_dir, "config5_ber.csv"), time.time() - t0), flush=True)
     return pts, ber

@@ -2,6 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
+#include <map>
+#include <utility>
 #include "../../include/dccn.h"
 
 namespace dccn {
@@ -37,20 +41,36 @@ static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kWave = 64;          // CDNA wavefront
-// compute units of the current device (MI355X: 256; fewer in the partitioned CPX/DPX modes): asked once, 256 when no
-// device is visible (workspace-size queries on a host without a GPU).  Host-side planning only.
+// compute units of the current device (MI355X: 256; fewer in the partitioned CPX/DPX modes): asked once PER DEVICE
+// (a process may drive several), 256 when no device is visible (workspace-size queries on a host without a GPU).
+// Host-side planning only.
 static inline int device_cus() {
-    static int n = 0;
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cache[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
-            n = prop.multiProcessorCount;
-        else
-            n = 256;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cache[dev].store(n, std::memory_order_relaxed);
     }
     return n;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): kernels that need more dynamic LDS than
+// the default get it set once per device they are launched on (thread safe; a lookup per launch afterwards).
+static inline int set_max_dynamic_smem(const void* kern, size_t bytes) {
+    if (bytes <= 48 * 1024) return DCCN_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;      // largest size granted so far
+    int dev = 0;
+    DCCN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[{dev, kern}];
+    if (have >= bytes) return DCCN_OK;
+    DCCN_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return DCCN_OK;
 }
 #define kCUs (dccn::device_cus())
 

@@ -10,6 +10,7 @@
 #include "tail.h"
 #include "gemm16.h"
 #include "gemm_kmajor.h"
+#include "rx_bwd.h"
 #include "equalizer.h"
 #include "datagen.h"
 #include "im2col.h"
@@ -47,9 +48,17 @@ enum TuneKey : int {
     TUNE_SKINNY = 8,            // > 0: GEMMs with <= 96 output rows (the equaliser's 73-frame batch) use small gemm16 tiles
     TUNE_DENSE_BWD_BIG = 9,     // 1: large dense layers run dX and dW (128x128x32 tiles) as one grouped launch
     TUNE_DENSE_FWD_PLAIN = 10,  // 1: the un-fused dense forward (nbits >= 3, layer API) of small layers runs 48x64 gemm16 tiles
-    TUNE_COUNT = 11
+    TUNE_FUSED_BWD = 11,        // 1: small layers: the C-Conv weight gradient rides in the epilogue of the dense dX tiles (rx_bwd.h)
+    TUNE_BWD_PRIO = 12,         // s_setprio level (0-3) of the dX blocks of the fused backward launch
+    TUNE_COUNT = 13
 };
-static int g_tune[TUNE_COUNT] = {9, 7, 0, 7, 0, 0, 0, 1, 1, 1, 1};
+// (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
+struct TuneTable {
+    std::atomic<int> v[TUNE_COUNT];
+    int operator[](int k) const { return v[k].load(std::memory_order_relaxed); }
+    void set(int k, int x) { v[k].store(x, std::memory_order_relaxed); }
+};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {0}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -214,20 +223,24 @@ static size_t splitk_ws_bytes(int Mo, int No, int Kr) {
 
 // split plan of the dense weight gradient dw[K,N] = x[M,K]^T . dy[M,N] (one rule for the stand-alone operator and the
 // grouped launch: the composed and the fused step must sum in the same order)
-static SplitPlan dense_dw_plan(int M, int K, int N) {
+// range_rows: preferred k-range length of the k-major form.  256 (4 k-tiles) next to plain dX tiles: the blocks are cheap
+// to start and pack the grid's tail better than the 320-row ranges of the generic plan (C2: 5 ranges instead of 4, -1 us
+// per step even with one more slab to sum).  448 (7 k-tiles) in the fused backward launch of rx_bwd.h, whose dX tiles carry
+// the C-Conv contraction and run 26 us: fewer, longer dW items amortise their load/store phases and leave two slabs less
+// for the optimizer launch (C2: 3 ranges, -2.0 us per step; 2, 4 and 6 ranges measured +1.2 ... +1.5 us over 3).
+static SplitPlan dense_dw_plan(int M, int K, int N, int range_rows = 256) {
     SplitPlan sp = plan_splitk(K, N, M);
     const int cap = max_splits16(K, N);
     if (g_tune[TUNE_DENSE_BWD_SPLITS] > 0 && sp.splits > 1) {
         sp = plan_splitk_n(M, g_tune[TUNE_DENSE_BWD_SPLITS] < cap ? g_tune[TUNE_DENSE_BWD_SPLITS] : cap, 64);
-    } else if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && sp.splits > 1 && sp.klen > 256) {
-        // k-major dW blocks are cheap to start: 256-row k ranges (4 k-tiles) pack the grid's tail better than the 320-row
-        // ones of the generic plan (C2: 5 ranges instead of 4, -1 us per step even with one more slab to sum)
-        const int want = ceil_div(M, 256);
+    } else if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && sp.splits > 1 && (range_rows > 256 || sp.klen > range_rows)) {
+        const int want = ceil_div(M, range_rows);
         const SplitPlan alt = plan_splitk_n(M, want < cap ? want : cap, 64);
-        if (alt.splits > sp.splits) sp = alt;
+        if (range_rows > 256 || alt.splits > sp.splits) sp = alt;
     }
     return sp;
 }
+constexpr int kFusedBwdRangeRows = 448;
 
 // defer != nullptr: leave the split-K slabs un-reduced (the fused Adam kernel sums them) and report them
 struct DeferredSlabs {
@@ -525,34 +538,18 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         if (g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor && kmajor_ok(p) && tiles <= 2 * kCUs) {
             auto kern = cconv_bwd_w_km_finalize_kernel<64>;
             constexpr size_t smem = kmajor_smem_bytes<64>();
-            static bool attr_done = false;
-            if (!attr_done) {
-                DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr_done = true;
-            }
+            DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
             hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
         } else if (sp.klen == 128 && g_whole_k) {
             // 128 rows per split: the whole k range of a block as one tile (all loads in flight at once, no k-tile barrier)
             auto kern = cconv_bwd_w_finalize_kernel<true, 128, 1>;
             constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 128, 1>();
-            static bool attr_done = false;
-            if (!attr_done) {
-                DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr_done = true;
-            }
+            DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
             hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
         } else {
             auto kern = cconv_bwd_w_finalize_kernel<true>;
             constexpr size_t smem = gemm_smem_bytes<OP_ICONTIG, OP_ICONTIG, 64, 64, 64>();
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (smem > 48 * 1024)
-                    DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr_done = true;
-            }
+            DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
             hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, tiles, gemm_blocks, *fin);
         }
         DCCN_LAUNCH_CHECK();
@@ -573,6 +570,72 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, slabs, sp.splits, p.slab, cs, dw, dbias,
                            kin, F);
     DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// backward of the basic receiver's training step in one launch (rx_bwd.h)
+// ---------------------------------------------------------------------------------------
+static int rx_bwd_fused_tiles(int batch, int S, int F) { return ceil_div(batch, 64) * ceil_div(S * 2 * F, 64); }
+static size_t rx_bwd_fused_ws_bytes(int batch, int S, int kin, int F) {
+    const size_t tiles = (size_t)rx_bwd_fused_tiles(batch, S, F);
+    size_t o = 0;
+    o = carve_size(o, tiles * 2 * kin * 64 * sizeof(float));
+    o = carve_size(o, tiles * 64 * sizeof(float));
+    return align_up(o, 256);
+}
+// applicable: 64x64 dX tiles that lie inside one symbol's 2F columns, 2kin = 128 or 160 (N = 64 without / with the
+// cyclic prefix), the grouped k-major plan for the dense gradients, vector-legal operands
+static bool rx_bwd_fused_ok(int batch, int S, int kin, int F, int D, const float* x_norm, const float* fft_out,
+                            const float* dz, const float* wd) {
+    const int dK = S * 2 * F, dN = 2 * D;
+    if (!g_tune[TUNE_FUSED_BWD] || g_tune[TUNE_DENSE_BWD] != kVariantKmajor) return false;
+    if ((2 * F) % 64 != 0 || (2 * kin != 128 && 2 * kin != 160)) return false;
+    if (dN % 4 != 0 || !aligned16(x_norm) || !aligned16(fft_out) || !aligned16(dz) || !aligned16(wd)) return false;
+    if (!small_enough(batch, (long long)S * 2 * kin) || !small_enough(batch, dK) || !small_enough(dK, dN)) return false;
+    const long long big = (long long)ceil_div(batch, 128) * ceil_div(dK, 128);
+    if (big >= 2 * kCUs) return false;
+    const SplitPlan sp = dense_dw_plan(batch, dK, dN, kFusedBwdRangeRows);
+    return (long long)ceil_div(dK, 128) * ceil_div(dN, 128) * sp.splits < 2 * kCUs;
+}
+
+// dfft nullable: the dX tiles then only feed their epilogue
+static int rx_bwd_fused_impl(const float* x_norm, const float* fft_out, const float* dz, const float* wd, float* dfft,
+                             float* dbias_dense, int batch, int S, int kin, int F, int D, void* ws_dense, size_t ws_dense_bytes,
+                             void* ws_conv, size_t ws_conv_bytes, const NormRideArgs& nr, const TailFinalizeArgs& fin,
+                             dccn_adam_hparams hp, hipStream_t s, DeferredSlabs* ds, FoldDefer* fd, int* fold_tilew) {
+    const int dK = S * 2 * F, dN = 2 * D;
+    if (!ws_dense || ws_dense_bytes < splitk_ws_bytes(dK, dN, batch)) return DCCN_ERR_WORKSPACE;
+    if (!ws_conv || ws_conv_bytes < rx_bwd_fused_ws_bytes(batch, S, kin, F)) return DCCN_ERR_WORKSPACE;
+    GemmParams px = dense_bwd_x_params(dz, wd, dfft, batch, dK, dN);
+    GemmParams pw = gp_zero();                // dw[K,N] = x[M,K]^T . dy[M,N]
+    pw.A = fft_out; pw.B = dz;
+    pw.M = dK; pw.N = dN; pw.K = batch;
+    pw.lda = dK; pw.ldb = dN; pw.ldc = dN;
+    pw.slab = (long long)dK * dN;
+    pw.vecA = 1; pw.vecB = 1;
+    const SplitPlan sp = dense_dw_plan(batch, dK, dN, kFusedBwdRangeRows);
+    Carver c(ws_dense, ws_dense_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * dK * dN);
+    float* cs = c.take<float>((size_t)sp.splits * dN);
+    pw.C = slabs; pw.colsum = dbias_dense ? cs : nullptr;
+    pw.klen = sp.klen;
+    if (!kmajor_ok(pw)) return DCCN_ERR_INVALID_ARG;
+    const int tiles = rx_bwd_fused_tiles(batch, S, F);
+    Carver cc(ws_conv, ws_conv_bytes);
+    DweffArgs de;
+    de.xn = x_norm;
+    de.partial = cc.take<float>((size_t)tiles * 2 * kin * 64);
+    de.colsum = cc.take<float>((size_t)tiles * 64);
+    de.batch = batch; de.ldx = S * 2 * kin; de.two_kin = 2 * kin; de.two_F = 2 * F;
+    de.prio = g_tune[TUNE_BWD_PRIO];
+    if (2 * kin == 160) DCCN_TRY(launch_rx_bwd_fused<5>(px, pw, de, sp.splits, nr, fin, hp, s));
+    else DCCN_TRY(launch_rx_bwd_fused<4>(px, pw, de, sp.splits, nr, fin, hp, s));
+    ds->dw_slabs = slabs; ds->db_slabs = dbias_dense ? cs : nullptr; ds->splits = sp.splits;
+    fd->slabs = de.partial; fd->colsum = de.colsum;
+    fd->splits = ceil_div(batch, 64) * S;                       // terms per element: (row tile, symbol)
+    fd->slab = (long long)((2 * F) / 64) * 2 * kin * 64;        // distance between consecutive terms
+    *fold_tilew = 64;
     return DCCN_OK;
 }
 
@@ -674,9 +737,12 @@ static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
     o = carve_size(o, nb * tail_param_count(nbits) * sizeof(float));
     return align_up(o, 256);
 }
-static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
-    return g_tune[TUNE_DENSE_FWD] > 0 && nbits <= 2 && (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w) &&
+static bool dense_tail_shape_ok(int M, int K, int N, int nbits) {
+    return g_tune[TUNE_DENSE_FWD] > 0 && nbits >= 1 && nbits <= 2 && M > 0 && K > 0 && N > 0 && (K % 4 == 0) && (N % 4 == 0) &&
            small_enough(M, K) && small_enough(K, N) && (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs;
+}
+static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
+    return dense_tail_shape_ok(M, K, N, nbits) && aligned16(x) && aligned16(w);
 }
 
 template <int NB, bool BWD>
@@ -800,6 +866,10 @@ static RxLayout rx_layout(const dccn_rx_shape* sh) {
     }
     L.ws_dense_bw = splitk_ws_bytes(L.dK, L.dN, sh->batch);
     L.ws_conv_bw = cconv_bw_ws_bytes(L.rows, sh->kin, sh->F);
+    {
+        const size_t f = rx_bwd_fused_ws_bytes(sh->batch, sh->S, sh->kin, sh->F);
+        if (2LL * sh->kin <= 192 && f > L.ws_conv_bw) L.ws_conv_bw = f;
+    }
     return L;
 }
 static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
@@ -820,8 +890,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                         hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (!shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
     if (!b->x || !b->bits || !b->params || !b->x_norm || !b->fft_out || !b->metrics) return DCCN_ERR_INVALID_ARG;
-    if (train && (!b->grads || !b->adam_m || !b->adam_v || !b->adam || !b->dz || !b->dfft))
-        return DCCN_ERR_INVALID_ARG;
+    if (train && (!b->grads || !b->adam_m || !b->adam_v || !b->adam || !b->dz)) return DCCN_ERR_INVALID_ARG;
     if (!b->workspace || b->workspace_bytes < rx_ws_bytes(sh, train ? 1 : 0)) return DCCN_ERR_WORKSPACE;
     const RxLayout L = rx_layout(sh);
     Carver c(b->workspace, b->workspace_bytes);
@@ -863,8 +932,21 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     fin.hp = hp;
 
     DeferredSlabs ds;
-
-    if (side) {
+    FoldDefer fd;
+    fd.slabs = nullptr;
+    int fold_tilew = 0;
+    const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
+    // small layers: dX tiles + C-Conv weight-gradient partials in their epilogue + dW items + tail finalize: one launch
+    const bool fuse_bw = !side && can_defer &&
+                         rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, b->x_norm, b->fft_out, b->dz, P + L.o_dense_w);
+    if (!fuse_bw && !b->dfft) return DCCN_ERR_INVALID_ARG;
+    if (fuse_bw) {
+        NormRideArgs nr;
+        memset(&nr, 0, sizeof(nr));
+        DCCN_TRY(rx_bwd_fused_impl(b->x_norm, b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_b, sh->batch, sh->S,
+                                   sh->kin, sh->F, sh->D, ws_dbw, L.ws_dense_bw, ws_cbw, L.ws_conv_bw, nr, fin, hp, s, &ds, &fd,
+                                   &fold_tilew));
+    } else if (side) {
         // two-stream variant: dense dW/db on `side`, dX -> C-Conv dW on the main stream
         DCCN_HIP(hipEventRecord(ev_fork, s));
         DCCN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
@@ -879,12 +961,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
-    FoldDefer fd;
-    fd.slabs = nullptr;
-
-    const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
-    DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
-                              L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
+    if (!fuse_bw)
+        DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
+                                  L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     AdamRxArgs aa;
@@ -895,7 +974,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.o_dw = L.o_dense_w; aa.n_dw = (long long)L.dK * L.dN; aa.o_db = L.o_dense_b; aa.n_db = L.dN;
     aa.cw_slabs = fd.slabs; aa.cw_colsum = fd.slabs ? fd.colsum : nullptr;
     aa.cw_splits = fd.slabs ? fd.splits : 0; aa.cw_slab = fd.slabs ? fd.slab : 0;
-    aa.kin = sh->kin; aa.F = sh->F; aa.o_cw = L.o_conv_w;
+    aa.kin = sh->kin; aa.F = sh->F; aa.o_cw = L.o_conv_w; aa.cw_tilew = fd.slabs ? fold_tilew : 0;
     aa.n_conv = L.o_dense_w;                      // C-Conv kernel + bias come first in the arena
     aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, kRedLanes) : 0;
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
@@ -1086,11 +1165,69 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
 
 int dccn_set_tuning(int key, int value) {
     if (key < 0 || key >= TUNE_COUNT || value < 0) return DCCN_ERR_INVALID_ARG;
-    g_tune[key] = value;
+    g_tune.set(key, value);
     if (key == TUNE_WHOLE_K) g_whole_k = value;
     return DCCN_OK;
 }
 int dccn_get_tuning(int key) { return (key < 0 || key >= TUNE_COUNT) ? DCCN_ERR_INVALID_ARG : g_tune[key]; }
+
+size_t dccn_rx_backward_workspace_size(int batch, int S, int kin, int F, int D) {
+    if (batch <= 0 || S <= 0 || kin <= 0 || F <= 0 || D <= 0) return 0;
+    size_t o = 0;
+    o = carve_size(o, splitk_ws_bytes(S * 2 * F, 2 * D, batch));
+    o = carve_size(o, rx_bwd_fused_ws_bytes(batch, S, kin, F));
+    return align_up(o, 256);
+}
+int dccn_rx_backward(const float* x_norm, const float* fft_out, const float* dz, const float* w_dense, float* dfft,
+                     float* dw_dense, float* db_dense, float* dw_conv, float* db_conv, int batch, int S, int kin, int F,
+                     int D, int reduce, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!x_norm || !fft_out || !dz || !w_dense || batch <= 0 || S <= 0 || kin <= 0 || F <= 0 || D <= 0)
+        return DCCN_ERR_INVALID_ARG;
+    if (reduce && (!dw_dense || !dw_conv)) return DCCN_ERR_INVALID_ARG;
+    if (!rx_bwd_fused_ok(batch, S, kin, F, D, x_norm, fft_out, dz, w_dense)) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_rx_backward_workspace_size(batch, S, kin, F, D)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int dK = S * 2 * F, dN = 2 * D;
+    const size_t nd = splitk_ws_bytes(dK, dN, batch), nc = rx_bwd_fused_ws_bytes(batch, S, kin, F);
+    Carver c(workspace, workspace_bytes);
+    void* ws_d = c.take<char>(nd);
+    void* ws_c = c.take<char>(nc);
+    NormRideArgs nr;
+    memset(&nr, 0, sizeof(nr));
+    TailFinalizeArgs fin;
+    memset(&fin, 0, sizeof(fin));
+    dccn_adam_hparams hp;
+    memset(&hp, 0, sizeof(hp));
+    DeferredSlabs ds;
+    FoldDefer fd;
+    int tilew = 0;
+    DCCN_TRY(rx_bwd_fused_impl(x_norm, fft_out, dz, w_dense, dfft, db_dense ? db_dense : dw_dense, batch, S, kin, F, D, ws_d, nd,
+                               ws_c, nc, nr, fin, hp, s, &ds, &fd, &tilew));
+    if (!reduce) return DCCN_OK;
+    const long long n = (long long)dK * dN;
+    if (db_dense) DCCN_TRY(launch_splitk_reduce2(ds.dw_slabs, ds.splits, n, dw_dense, n, ds.db_slabs, (long long)dN, db_dense, (long long)dN, s));
+    else DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw_dense, n, s));
+    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
+    hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, fd.slabs, fd.splits, fd.slab, fd.colsum, dw_conv,
+                       db_conv, kin, F, tilew);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+#ifdef DCCN_TRACE
+/* trace build only (tools/blocktrace.py): where the instrumented kernels leave their per-block time stamps */
+int dccn_debug_set_trace(unsigned long long* buf) {
+    DCCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)));
+    return DCCN_OK;
+}
+#endif
+
+int dccn_dense_tail_supported(int M, int K, int N, int nbits) { return dense_tail_shape_ok(M, K, N, nbits) ? 1 : 0; }
+int dccn_rx_bwd_fused_supported(const dccn_rx_shape* sh) {
+    if (!shape_ok(sh)) return 0;
+    // (pointer alignment is checked again at launch time; the query assumes 16-byte aligned buffers)
+    return rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, nullptr, nullptr, nullptr, nullptr) ? 1 : 0;
+}
 
 size_t dccn_dense_tail_workspace_size(int M, int N, int nbits) {
     if (M <= 0 || N <= 0 || nbits < 1 || nbits > 2) return 0;

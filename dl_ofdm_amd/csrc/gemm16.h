@@ -633,11 +633,8 @@ __global__ __launch_bounds__(256) void gemm16_bwd_w_finalize_kernel(const GemmPa
 }
 
 template <typename K>
-static int set_smem_attr(K kern, size_t smem) {
-    if (smem > 48 * 1024)
-        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem));
-    return DCCN_OK;
+static int set_smem_attr(K kern, size_t smem) {         // once per (device, kernel, size): common.h
+    return set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem);
 }
 
 // plain launch of one configuration; smem_pad lets a caller force fewer resident blocks per CU (experiments)
@@ -647,11 +644,7 @@ static int launch_gemm16(const GemmParams& p, int splits, hipStream_t s, size_t 
     auto kern = gemm16_kernel<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI_STORE, 1, false, TAG, PD>;
     size_t smem = CF::smem_bytes(0);
     if (smem < smem_min) smem = smem_min;
-    static size_t attr_for = 0;
-    if (attr_for < smem) {
-        DCCN_TRY(set_smem_attr(kern, smem));
-        attr_for = smem;
-    }
+    DCCN_TRY(set_smem_attr(kern, smem));
     TailEpiParams none{};
     dim3 grid(ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), 1, splits);
     hipLaunchKernelGGL(kern, grid, dim3(CF::NT), smem, s, p, none);
@@ -666,11 +659,7 @@ static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hip
     auto kern = gemm16_kernel<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS, 0, EPI_TAIL, NB, BWD, TAG_DENSE_FWD, PD>;
     size_t smem = CF::smem_bytes(tail_reduce_lds_floats<NB, BWD>(CF::NT));
     if (smem < smem_min) smem = smem_min;
-    static size_t attr_for = 0;
-    if (attr_for < smem) {
-        DCCN_TRY(set_smem_attr(kern, smem));
-        attr_for = smem;
-    }
+    DCCN_TRY(set_smem_attr(kern, smem));
     dim3 grid(ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(CF::NT), smem, s, p, tp);
     DCCN_LAUNCH_CHECK();
@@ -685,11 +674,7 @@ static int launch_dense_bwd16(const GemmParams& px, const GemmParams& pw, int sp
     auto kern = dense_bwd16_kernel<WGM, WGN, TM, TN, BK, WWGM, WWGN, WTM, WTN>;
     size_t smem = CX::smem_bytes(0) > CW::smem_bytes(0) ? CX::smem_bytes(0) : CW::smem_bytes(0);
     if (smem < smem_min) smem = smem_min;
-    static size_t attr_for = 0;
-    if (attr_for < smem) {
-        DCCN_TRY(set_smem_attr(kern, smem));
-        attr_for = smem;
-    }
+    DCCN_TRY(set_smem_attr(kern, smem));
     const int nx = ceil_div(px.N, CX::BN) * ceil_div(px.M, CX::BM);
     const int tw = ceil_div(pw.N, CW::BN) * ceil_div(pw.M, CW::BM);
     hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(256), smem, s, px, pw, nx, tw);
@@ -702,11 +687,7 @@ static int launch_bwd_w16_finalize(const GemmParams& p, int splits, const TailFi
     using CF = Cfg16<OP_ICONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, 1>;
     auto kern = gemm16_bwd_w_finalize_kernel<WGM, WGN, TM, TN, BK>;
     const size_t smem = CF::smem_bytes(0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        DCCN_TRY(set_smem_attr(kern, smem));
-        attr_done = true;
-    }
+    DCCN_TRY(set_smem_attr(kern, smem));
     const int tiles = ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), gemm_blocks = tiles * splits;
     hipLaunchKernelGGL(kern, dim3(gemm_blocks + tail_finalize_blocks(fin.P)), dim3(256), smem, s, p, tiles, gemm_blocks,
                        fin);

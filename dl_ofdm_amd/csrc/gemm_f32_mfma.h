@@ -246,11 +246,21 @@ constexpr size_t gemm_smem_bytes() {
 }
 
 enum PrefetchMode : int { PF_NONE = 0, PF_FAST = 1, PF_MASKED = 2 };
-static int g_whole_k = 1;      // tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges
 
-// One 64x64 / 128x128 output tile (block `L` of `T` tiles, split `z`) of C = A.B
+// XCD-aware tile order: the dispatcher places block L on XCD L % 8 (speed only, never correctness); each XCD gets a
+// contiguous run of row-major tiles so its private L2 holds one slice of A rows plus the B panel instead of everything
+__device__ __forceinline__ int xcd_tile(const int L, const int T) {
+    const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+static std::atomic<int> g_whole_k{1};      // tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges
+
+// The k-loop of one 64x64 / 128x128 output tile (block `L` of `T` tiles, split `z`) of C = A.B: leaves the tile in
+// `acc` (32x32 MFMA C layout per wave), its origin in (m0, n0) and the COLSUM partial in `cs`.  Ends with a block
+// barrier: the dynamic LDS is free for the caller's epilogue.
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC, int NBUF = 2>
-__device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, const int T, const int z) {
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, const int T, const int z,
+                                              f32x16 (&acc)[BM / 64][BN / 64], int& m0_out, int& n0_out, float& cs_out) {
     using TA = Tile<KA, BM, BK>;
     using TB = Tile<KB, BN, BK>;
     constexpr int LDA = TA::LD, LDB = TB::LD;
@@ -263,22 +273,14 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
-    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (speed only, never
-    // correctness); give each XCD a contiguous run of row-major tiles so its private L2 holds one
-    // slice of A rows plus the B panel instead of everything.
     const int ntn = (p.N + BN - 1) / BN;
-    int tile;
-    {
-        const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
+    const int tile = xcd_tile(L, T);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int kbeg = z * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     const int nfull = VEC ? (kend - kbeg) / BK : 0;     // k-tiles the fast loader may fetch
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -398,8 +400,21 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
         for (; t + 1 < ntiles; ++t) ktile(std::integral_constant<int, PF_MASKED>{});
     }
     if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
+    m0_out = m0;
+    n0_out = n0;
+    cs_out = cs;
+}
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// store epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int BM, int BN, int COLSUM>
+__device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, const f32x16 (&acc)[BM / 64][BN / 64],
+                                           const int m0, const int n0, const float cs) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+    const bool do_cs = COLSUM && p.colsum != nullptr && m0 == 0 && tid < BN;
     float* Cz = p.C + (size_t)z * p.slab;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -434,6 +449,16 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, con
     }
 }
 
+// One output tile of C = A.B: k-loop + store
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC, int NBUF = 2>
+__device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, const int T, const int z) {
+    f32x16 acc[BM / 64][BN / 64];
+    int m0, n0;
+    float cs;
+    gemm_mainloop<KA, KB, BM, BN, BK, COLSUM, VEC, NBUF>(p, L, T, z, acc, m0, n0, cs);
+    gemm_store<BM, BN, COLSUM>(p, z, acc, m0, n0, cs);
+}
+
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int NBUF = 2>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
@@ -463,13 +488,7 @@ template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC,
 static int launch_gemm_cfg2(const GemmParams& p, int splits, hipStream_t s) {
     auto kern = gemm_f32_mfma_kernel<KA, KB, BM, BN, BK, COLSUM, TAG, VEC, NBUF>;
     constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK, NBUF>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (smem > 48 * 1024)
-            DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     dim3 grid(ceil_div(p.N, BN) * ceil_div(p.M, BM), 1, splits);
     hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p);
     DCCN_LAUNCH_CHECK();
@@ -488,12 +507,7 @@ template <bool VEC, int BM = 64, int BN = 64, int BK = 64>
 static int launch_dense_bwd_grouped(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
     auto kern = dense_bwd_grouped_kernel<BM, BN, BK, VEC>;
     constexpr size_t smem = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, BM, BN, BK>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem));
-        attr_done = true;
-    }
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     const int nx = ceil_div(px.N, BN) * ceil_div(px.M, BM);
     const int tw = ceil_div(pw.N, BN) * ceil_div(pw.M, BM);
     hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
@@ -649,10 +663,13 @@ static int launch_splitk_reduce2(const float* pa, int splits, long long slab_a, 
 // element index e in [0, kin*F) -> (n,f); e in [kin*F, kin*F+F) -> bias f
 // out2/gout (optional, per thread): the two element offsets (relative to dw; the bias follows the kernel) and
 // gradient values this thread produced, -1 when none -- lets a caller apply the optimizer update in the same pass
+// tilew > 0: the slabs are stored as column tiles of width tilew (the dX-epilogue partials of rx_bwd.h: term z, column
+// tile h at partial + (z*nh + h)*2kin*tilew, rows of tilew floats; colsum [z*nh + h][tilew]); `slab` is then the
+// distance between consecutive terms (nh tiles).  tilew == 0: full-width [2kin, 2F] slabs (split-K GEMM output).
 __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partial, int splits, long long slab,
                                                 const float* __restrict__ colsum, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int kin, int F, int block,
-                                                long long* out2 = nullptr, float* gout = nullptr) {
+                                                long long* out2 = nullptr, float* gout = nullptr, int tilew = 0) {
     if (out2) { out2[0] = -1; out2[1] = -1; }
     __shared__ float2 red[kRedGroups][kRedLanes];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -661,14 +678,19 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     const bool is_w = e < total, is_b = (!is_w) && (e < total + F) && (dbias != nullptr);
     const int n = is_w ? e / F : 0, f = is_w ? e % F : (e - total);
     float a = 0.f, b = 0.f;
+    // element (row, col = 2f) of term z: partial + z*slab + eoff + row*ld
+    const int ld = tilew > 0 ? tilew : N2;
+    const size_t eoff = tilew > 0 ? (size_t)((2 * f) / tilew) * (size_t)(2 * kin) * tilew + (2 * f) % tilew : (size_t)(2 * f);
+    const size_t coff = tilew > 0 ? (size_t)((2 * f) / tilew) * tilew + (2 * f) % tilew : (size_t)(2 * f);
+    const size_t cstride = tilew > 0 ? (size_t)(N2 / tilew) * tilew : (size_t)N2;
     if (is_w) {
         for (int zb = grp; zb < splits; zb += 8 * kRedGroups) {
             float2 top[8], bot[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float* P = partial + (size_t)min(zb + u * kRedGroups, splits - 1) * slab;
-                top[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * N2 + 2 * f);
-                bot[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * N2 + 2 * f);
+                const float* P = partial + (size_t)min(zb + u * kRedGroups, splits - 1) * slab + eoff;
+                top[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * ld);
+                bot[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * ld);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -682,7 +704,7 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     } else if (is_b) {
 #pragma unroll 8
         for (int z = grp; z < splits; z += kRedGroups) {
-            const float2 c = *reinterpret_cast<const float2*>(colsum + (size_t)z * N2 + 2 * f);
+            const float2 c = *reinterpret_cast<const float2*>(colsum + (size_t)z * cstride + coff);
             a += c.x - c.y;
         }
     }
@@ -707,8 +729,8 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
 __global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict__ partial, int splits,
                                                          long long slab, const float* __restrict__ colsum,
                                                          float* __restrict__ dw, float* __restrict__ dbias,
-                                                         int kin, int F) {
-    cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x);
+                                                         int kin, int F, int tilew = 0) {
+    cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x, nullptr, nullptr, tilew);
 }
 
 }  // namespace dccn

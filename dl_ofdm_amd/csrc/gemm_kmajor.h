@@ -2,15 +2,18 @@
 // natural layout of dW = X^T . dY (k = batch row): no operand is transposed anywhere.
 //
 // A k-tile (64 rows of A and of B, 64 columns each) goes to LDS as it lies in memory (float4 copies, unpadded 256-byte
-// rows).  v_mfma_f32_16x16x4_f32 wants lane (c = l%16, kq = l/16) to supply A[i=c][k=kq] and B[k=kq][j=c]; one
-// ds_read_b128 of row k0+kq at column 4c hands the lane FOUR columns of that row, used as the operand of four
-// different 16-wide sub-tiles: sub-tile s of A holds the rows m = 4c+s, sub-tile t of B the columns n = 4c+t.  Wave w
-// of a block owns the row class s = w of the 64x64 tile (16 rows x 64 columns, 4 accumulators): per k-step it reads its
-// one A column (ds_read_b32) and the B float4 and issues 4 MFMAs; nothing is exchanged between the waves.
-// With unpadded rows the B reads are conflict free: the 16-lane service groups of ds_read_b128 ({0-3,12-15,20-27}, ...)
-// take 8 lanes of one row and 8 of the next, which cover complementary halves of the 64 banks.
-// Accumulator t, register r of lane l in wave w is C[m0 + 16*(l/16) + 4r + w][n0 + 4*(l%16) + t]: the four t of a lane
-// are one float4 of the output row, the 16 lanes of a row one 256-byte segment.
+// rows) -- except that ODD rows are stored with their two 32-column halves swapped (word offset ^ 32: an address-only
+// swizzle, the float4 stays a float4).  v_mfma_f32_16x16x4_f32 wants lane (c = l%16, kq = l/16) to supply A[i=c][k=kq]
+// and B[k=kq][j=c]; the lane reads TWO adjacent columns of row k0+kq with one ds_read_b64 and uses them as the operands
+// of two 16-wide sub-tiles: wave (hA, hB) owns the 32x32 quarter of the 64x64 tile, sub-tile s of A holds its rows
+// m = 32 hA + 2c + s, sub-tile t of B its columns n = 32 hB + 2c + t (4 accumulators, 4 MFMAs per k-step for two
+// ds_read_b64; nothing is exchanged between the waves).  ds_read_b64 is serviced in the lane groups {0-31}, {32-63}
+// = (kq 0,1) and (kq 2,3): the even row's lanes cover the 32 banks of their half, the odd row's lanes -- swizzled --
+// the other 32: every read is conflict free (round 2 read A with ds_read_b32 at column 4c+w: the four kq groups of a
+// wave met on the same bank, SQ_LDS_BANK_CONFLICT = 25 % of the LDS cycles).  The ds_write_b128 of the staging stay
+// conflict free (an 8-lane group = 32 consecutive words of one row).
+// Accumulator (s,t), register r of lane l in wave (hA,hB) is C[m0 + 32hA + 8(l/16) + 2r + s][n0 + 32hB + 2(l%16) + t]:
+// the two t of a lane are one float2, the 16 lanes of a row one 128-byte segment.
 //
 // Vector-legal operands only (M, N multiples of 4, 16-byte aligned, < 2 GiB); callers fall back to the
 // gemm_f32_mfma.h path otherwise.
@@ -37,30 +40,31 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, kq = lane >> 4;
+    const int hA = w >> 1, hB = w & 1;
     const int ntn = (p.N + BT - 1) / BT;
-    int tile;
-    {
-        const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
+    const int tile = xcd_tile(L, T);
     const int m0 = (tile / ntn) * BT, n0 = (tile % ntn) * BT;
     const int kbeg = z * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
 
-    kf32x4 acc[4];
+    kf32x4 acc[2][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][t][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_cs = COLSUM && p.colsum != nullptr && m0 == 0 && w == 0;       // wave-uniform
 
-    // staging: piece v of a thread = row (tid + 256 v) / 16, float4 column (tid + 256 v) % 16 of the k-tile
+    // staging: piece v of a thread = row (tid + 256 v) / 16, float4 column (tid + 256 v) % 16 of the k-tile; the row
+    // parity is bit 4 of tid for every piece, so the swizzle is one thread constant
     unsigned offA[NV], offB[NV];
     float4 ra[NV], rb[NV];
     unsigned okm = 0u;                                  // masked path: bit v = row of piece v lies inside the k range
+    const unsigned sw = ((unsigned)(tid >> 4) & 1u) << 5;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
@@ -93,7 +97,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             const bool ok = (okm >> v) & 1u;
             val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
         }
-        *reinterpret_cast<float4*>((q < NV ? An : Bn) + 4 * (tid + 256 * v)) = val;
+        *reinterpret_cast<float4*>((q < NV ? An : Bn) + ((unsigned)(4 * (tid + 256 * v)) ^ sw)) = val;
     };
     using TFalse = std::false_type;
     using TTrue = std::true_type;
@@ -114,24 +118,25 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
 
     // one k-tile = BK/4 k-steps (rows 4ks + kq) x 4 MFMAs per wave; the next k-tile's 8 global loads go out during the
     // first 8 steps, their LDS writes (other buffer) during the last 8
+    const int rdA = kq * BT + ((32 * hA + 2 * c) ^ ((kq & 1) << 5));
+    const int rdB = kq * BT + ((32 * hB + 2 * c) ^ ((kq & 1) << 5));
     int t = 0;
     auto ktile = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const int cur = t & 1;
         const int k0n = kbeg + (t + 1) * BK;
-        const float* As = sA + cur * BK * BT + kq * BT + 4 * c + w;
-        const float* Bs = sB + cur * BK * BT + kq * BT + 4 * c;
+        const float* As = sA + cur * BK * BT + rdA;
+        const float* Bs = sB + cur * BK * BT + rdB;
         float* An = sA + (cur ^ 1) * BK * BT;
         float* Bn = sB + (cur ^ 1) * BK * BT;
-        float fa[2];
-        float4 fb[2];
-        fa[0] = As[0];
-        fb[0] = *reinterpret_cast<const float4*>(Bs);
+        float2 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const float2*>(As);
+        fb[0] = *reinterpret_cast<const float2*>(Bs);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks + 1 < NKS) {
-                fa[(ks + 1) & 1] = As[4 * (ks + 1) * BT];
-                fb[(ks + 1) & 1] = *reinterpret_cast<const float4*>(Bs + 4 * (ks + 1) * BT);
+                fa[(ks + 1) & 1] = *reinterpret_cast<const float2*>(As + 4 * (ks + 1) * BT);
+                fb[(ks + 1) & 1] = *reinterpret_cast<const float2*>(Bs + 4 * (ks + 1) * BT);
             }
             if constexpr (MODE != PF_NONE) {
                 if (ks < 2 * NV) {
@@ -140,9 +145,13 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1], f4c(fb[ks & 1], tt), acc[tt], 0, 0, 0);
+            {
+                const float2 a = fa[ks & 1], b = fb[ks & 1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[1][1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MODE != PF_NONE) {
                 if (ks >= NKS - 2 * NV) {
@@ -152,11 +161,13 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             }
         }
         // bias gradient: wave 0 of the m0 == 0 tiles re-reads the B rows it just multiplied (a real branch around LDS
-        // loads: as selects inside the loop above the compiler executed these adds in every wave of every block)
+        // loads: as selects inside the loop above the compiler executed these adds in every wave of every block).
+        // The swizzled address hands lane (c, kq) the logical columns 4c..4c+3 of row 4ks + kq.
         if (COLSUM && do_cs) {
+            const float* Bc = sB + cur * BK * BT + kq * BT + ((4 * c) ^ ((kq & 1) << 5));
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const float4 b = *reinterpret_cast<const float4*>(Bs + 4 * ks * BT);
+                const float4 b = *reinterpret_cast<const float4*>(Bc + 4 * ks * BT);
                 bsum.x += b.x; bsum.y += b.y; bsum.z += b.z; bsum.w += b.w;
             }
         }
@@ -168,19 +179,24 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
     if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
 
     float* Cz = p.C + (size_t)z * p.slab;
-    const int col = n0 + 4 * c;
+    const int col = n0 + 32 * hB + 2 * c;
+    const int rowb = m0 + 32 * hA + 8 * kq;
     if (m0 + BT <= p.M && n0 + BT <= p.N) {                // interior tile (block-uniform): stores without exec masks
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float4*>(Cz + (size_t)(m0 + 16 * kq + 4 * r + w) * p.ldc + col) =
-                make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                *reinterpret_cast<float2*>(Cz + (size_t)(rowb + 2 * r + s) * p.ldc + col) =
+                    make_float2(acc[s][0][r], acc[s][1][r]);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 16 * kq + 4 * r + w;
-            if (row < p.M && col < p.N)
-                *reinterpret_cast<float4*>(Cz + (size_t)row * p.ldc + col) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row = rowb + 2 * r + s;
+                if (row < p.M && col < p.N)
+                    *reinterpret_cast<float2*>(Cz + (size_t)row * p.ldc + col) = make_float2(acc[s][0][r], acc[s][1][r]);
+            }
     }
     if (COLSUM && do_cs) {
         // wave 0 has seen every element of the B rows once: lanes c, c+16, c+32, c+48 hold the same four columns
@@ -191,7 +207,8 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             bsum.z += __shfl_xor(bsum.z, m, 64);
             bsum.w += __shfl_xor(bsum.w, m, 64);
         }
-        if (lane < 16 && col < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)z * p.N + col) = bsum;
+        const int cc = n0 + 4 * c;
+        if (lane < 16 && cc < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)z * p.N + cc) = bsum;
     }
 }
 
@@ -209,12 +226,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kmajor_kernel(const GemmPar
 template <int COLSUM, int TAG>
 static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
     auto kern = gemm_kmajor_kernel<COLSUM, TAG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kmajor_smem_bytes<64>()));
-        attr_done = true;
-    }
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), kmajor_smem_bytes<64>()));
     dim3 grid(ceil_div(p.N, 64) * ceil_div(p.M, 64), 1, splits);
     hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), kmajor_smem_bytes<64>(), s, p);
     DCCN_LAUNCH_CHECK();
@@ -242,12 +254,7 @@ template <int BK>
 static int launch_dense_bwd_grouped_km(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
     constexpr size_t sx = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, 64, 64, BK>();
     constexpr size_t smem = sx > kmajor_smem_bytes<BK>() ? sx : kmajor_smem_bytes<BK>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        DCCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_grouped_km_kernel<BK>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(dense_bwd_grouped_km_kernel<BK>), smem));
     const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
     const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
     hipLaunchKernelGGL(dense_bwd_grouped_km_kernel<BK>, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);

@@ -460,6 +460,7 @@ struct AdamRxArgs {
     // them (cconv_fold_body) and update those parameters; the other blocks start at element n_conv
     const float* cw_slabs; const float* cw_colsum;
     int cw_splits, kin, F, fold_blocks;
+    int cw_tilew;                          // > 0: the slabs are the column-tiled dX-epilogue partials (rx_bwd.h)
     long long cw_slab, o_cw, n_conv;       // o_cw: arena offset of the C-Conv kernel (its bias follows)
     // R0 of the NEXT batch riding on this launch (norm_blocks > 0): the leading blocks normalise nx -> ny, which no
     // kernel of the current step reads any more (software pipelining across steps: one boundary less per step)
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
         long long idx[2];
         float gv[2];
         cconv_fold_body(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
-                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv);
+                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv, a.cw_tilew);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (idx[e] < 0) continue;

@@ -86,7 +86,7 @@ class RxEngine:
 
     def __init__(self, dims: RxDims, batch: int, device="cuda", train: bool = True, seed: int = 1,
                  params: Optional[Dict[str, np.ndarray]] = None, lr0: float = 1e-3, want_prob: bool = True,
-                 want_tx_power: bool = True, want_z: bool = True):
+                 want_tx_power: bool = True, want_z: bool = True, want_dfft: bool = True):
         self.lib = _lib.load()
         self.dims, self.batch, self.train = dims, int(batch), bool(train)
         self.device = torch.device(device)
@@ -106,7 +106,8 @@ class RxEngine:
         self.x_norm = torch.empty(B, d.S, d.kin, 2, **f32)
         self.fft_out = torch.empty(B, d.S, d.F, 2, **f32)
         # the dense output: for nbits <= 2 the tail runs inside the dense launch and z only exists when asked for
-        fused_tail = d.nbits <= 2 and (-(-B // 128)) * (-(-2 * d.D // 128)) < 512 and self.lib.dccn_get_tuning(0) > 0
+        # (the library's own plan queries decide which intermediate buffers a step can do without)
+        fused_tail = bool(self.lib.dccn_dense_tail_supported(B, d.S * d.F * 2, 2 * d.D, d.nbits))
         self.z = torch.empty(B, 2 * d.D, **f32) if (want_z or not fused_tail) else None
         self.prob = torch.empty(B, d.D, d.nbits, 2, **f32) if want_prob else None
         self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=self.device)
@@ -121,7 +122,10 @@ class RxEngine:
                 self.reg_coef[o:o + int(np.prod(shp))] = REG_COEFF * 2.0 * REG_L2
             self.adam_state = torch.tensor([0.0, 0.9, 0.999, 0.0], **f32)     # dccn_adam_state
             self.dz = torch.empty(B, 2 * d.D, **f32)
-            self.dfft = torch.empty(B, d.S, d.F, 2, **f32)
+            # the gradient w.r.t. fft_out: its only consumer is the C-Conv weight gradient, which the fused backward
+            # launch computes in the epilogue of the tiles that produce it -- materialised only on request then
+            fused_bwd = bool(self.lib.dccn_rx_bwd_fused_supported(C.byref(self.shape)))
+            self.dfft = torch.empty(B, d.S, d.F, 2, **f32) if (want_dfft or not fused_bwd) else None
         else:
             self.grads = self.adam_m = self.adam_v = self.reg_coef = self.adam_state = self.dz = self.dfft = None
         nws = self.lib.dccn_rx_workspace_size(C.byref(self.shape), 1 if train else 0)
@@ -328,6 +332,11 @@ def op_launchers(eng: RxEngine):
     ws = workspace(nws, eng.device, "bench")
     s = eng._stream
     zbuf = eng.z if eng.z is not None else torch.empty(B, dN, dtype=torch.float32, device=eng.device)
+    dfft = eng.dfft if eng.dfft is not None else torch.empty(B, d.S, d.F, 2, dtype=torch.float32, device=eng.device)
+    fused_bwd = bool(lib.dccn_rx_bwd_fused_supported(C.byref(eng.shape)))
+    if fused_bwd:
+        nws = max(nws, lib.dccn_rx_backward_workspace_size(B, d.S, d.kin, d.F, d.D))
+        ws = workspace(nws, eng.device, "bench")
     tail_flops = 3.0 * cells * (4.0 * d.m + 4.0 * (d.m + 2) * d.nbits)
     ops = {
         "batch_moment_norm": (lambda: lib.dccn_batch_moment_norm_fwd(
@@ -345,26 +354,35 @@ def op_launchers(eng: RxEngine):
             seg(G, "demodulation/conv2d/kernel"), cells, d.nbits, ws.data_ptr(), nws, s()),
             tail_flops, "demod_tail"),
         "dense_bwd_x": (lambda: lib.dccn_dense_bwd_x(
-            eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(), B, dK, dN, s()),
+            eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), dfft.data_ptr(), B, dK, dN, s()),
             2.0 * B * dK * dN, "gemm<dense_bwd_x>"),
         "dense_bwd_w": (lambda: lib.dccn_dense_bwd_w(
             eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(G, "demodulation/dense/kernel"),
             seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
             2.0 * B * dK * dN, "gemm<dense_bwd_w>+reduce"),
         "dense_bwd": (lambda: lib.dccn_dense_bwd(
-            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
+            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), dfft.data_ptr(),
             seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, s()),
             4.0 * B * dK * dN, "dense_bwd_grouped(dX+dW)+reduce"),
         "dense_bwd_slabs": (lambda: lib.dccn_dense_bwd_slabs(
-            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), eng.dfft.data_ptr(),
+            eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), dfft.data_ptr(),
             seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), B, dK, dN, ws.data_ptr(), nws, None,
             s()), 4.0 * B * dK * dN, "dense_bwd_grouped_km_kernel (dX 32x32x2 tiles + dW k-major 16x16x4 tiles)"),
         "cconv_bwd_w": (lambda: lib.dccn_cconv_gemm_bwd_w(
-            eng.x_norm.data_ptr(), eng.dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
+            eng.x_norm.data_ptr(), dfft.data_ptr(), seg(G, "fft_like/conv3d/kernel"),
             seg(G, "fft_like/conv3d/bias"), rows, d.kin, d.F, ws.data_ptr(), nws, s()),
             8.0 * rows * d.kin * d.F, "gemm_kmajor<cconv_bwd_w>+fold"),
     }
-    if d.nbits <= 2 and lib.dccn_get_tuning(0) > 0:
+    if fused_bwd:
+        # the backward half of the training step as it runs inside dccn_rx_train_step: dX tiles with the C-Conv weight
+        # gradient in their epilogue (dfft not materialised) + dense dW items, slabs / partials left for the optimizer
+        ops["rx_backward"] = (lambda: lib.dccn_rx_backward(
+            eng.x_norm.data_ptr(), eng.fft_out.data_ptr(), eng.dz.data_ptr(), seg(P, "demodulation/dense/kernel"), None,
+            seg(G, "demodulation/dense/kernel"), seg(G, "demodulation/dense/bias"), seg(G, "fft_like/conv3d/kernel"),
+            seg(G, "fft_like/conv3d/bias"), B, d.S, d.kin, d.F, d.D, 0, ws.data_ptr(), nws, s()),
+            4.0 * B * dK * dN + 8.0 * rows * d.kin * d.F,
+            "rx_bwd_fused_kernel (dense dX 32x32x2 tiles + C-Conv dWeff partials in their epilogue + dense dW k-major tiles)")
+    if bool(lib.dccn_dense_tail_supported(B, dK, dN, d.nbits)):
         ops["dense_tail_fwd_bwd"] = (lambda: lib.dccn_dense_tail_fwd_bwd(
             eng.fft_out.data_ptr(), seg(P, "demodulation/dense/kernel"), seg(P, "demodulation/dense/bias"), None,
             eng.bits.data_ptr(), seg(P, "demodulation/conv2d/kernel"),

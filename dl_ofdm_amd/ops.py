@@ -358,8 +358,9 @@ def dense_tail_supported(x: torch.Tensor, w: torch.Tensor, nbits: int) -> bool:
     """The fused launch needs nbits <= 2 and vector-legal operands (else use dense() + demod_tail_loss())."""
     M, K = x.shape[0], x.shape[-1]
     N = w.shape[1]
-    return (nbits <= 2 and K % 4 == 0 and N % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
-            and _lib.load().dccn_get_tuning(0) > 0 and (-(-M // 128)) * (-(-N // 128)) < 512)
+    # the shape rule is the library's own (dccn_dense_tail_supported); the pointers are checked here as the launch does
+    return bool(_lib.load().dccn_dense_tail_supported(int(M), int(K), int(N), int(nbits))
+                and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 def dense_demod_tail_loss(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], tailp: torch.Tensor,

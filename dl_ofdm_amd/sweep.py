@@ -73,6 +73,23 @@ def run_sweep(points: Sequence[SweepPoint], evaluate: Callable[[SweepPoint], Seq
     return table.cpu().numpy()
 
 
+def run_sweep_device(points: Sequence[SweepPoint], evaluate_into: Callable[[SweepPoint, torch.Tensor], None],
+                     rank: int = 0, world: int = 1, device: Optional[torch.device] = None, group=None,
+                     table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same sharding with the table kept on the device: ``evaluate_into(point, row)`` ENQUEUES the point's work on
+    the current stream and accumulates its six values into ``row`` (a float64 view of the table, e.g. through
+    dccn_metrics_table_add) -- no host round trip per point, so a rank's whole shard and the final all-reduce (RCCL) are
+    one stream-ordered sequence.  Returns the reduced device table (the caller synchronises when it reads it)."""
+    if table is None:
+        table = torch.zeros(len(points), len(TABLE_COLS), dtype=torch.float64, device=device)
+    else:
+        table.zero_()
+    for p in shard(points, rank, world):
+        evaluate_into(p, table[p.index])
+    reduce_table(table, world, group)
+    return table
+
+
 def ber_loss(table: np.ndarray):
     """(BER, mean cross entropy) per point from the reduced table, float64."""
     conf = table[:, :4]

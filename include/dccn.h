@@ -180,13 +180,23 @@ int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal
  * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
 
-/* Kernel-configuration knobs for experiments and profiling (process-wide, not thread-safe against concurrent
- * launches): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
+/* Kernel-configuration knobs for experiments and profiling (process-wide; individually atomic, but a change
+ * while another thread plans a launch may be seen half-way through that plan): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
  * (0 = 32x32x2 tile family, >0 = a 16x16x4 configuration), 4/5 split-K counts of the two weight gradients
- * (0 = automatic), 6 minimum LDS per block in KiB, 7 single-tile launches for short k ranges (default 1).
+ * (0 = automatic), 6 minimum LDS per block in KiB, 7 single-tile launches for short k ranges (default 1),
+ * 8 skinny dispatch, 9 grouped backward of large layers, 10 gemm16 tiles for the un-fused dense forward,
+ * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
+
+/* Plan queries: which launch plan the library will take for a shape under the current knobs, so that callers size
+ * their buffers from the library's own rule instead of restating it.
+ *   dccn_dense_tail_supported   1: dccn_dense_tail_fwd[_bwd] accepts (M, K, N, nbits) with 16-byte aligned operands
+ *                               (the fused receiver step then runs R2..R6 as one launch and `z` may be NULL);
+ *   dccn_rx_bwd_fused_supported 1: the training step runs its backward half as one launch (dense dX tiles with the
+ *                               C-Conv weight gradient in their epilogue + dense dW items): `dfft` may be NULL. */
+int dccn_dense_tail_supported(int M, int K, int N, int nbits);
 
 /* ---- R7: optimizer -----------------------------------------------------------------
  * dev/py/ofdmreceiver_np.py:185-189  exponential_decay(1e-3, step, 500, 0.98, staircase)
@@ -246,7 +256,8 @@ typedef struct dccn_rx_buffers {
     float* z;                  /* [batch, 2D] (nullable for nbits <= 2: the fused dense+tail launch skips it) */
     float* prob;               /* [batch, D, nbits, 2] `output:0` (nullable) */
     float* dz;                 /* [batch, 2D] train only */
-    float* dfft;               /* [batch, S, F, 2] train only */
+    float* dfft;               /* [batch, S, F, 2] train only (nullable when dccn_rx_bwd_fused_supported: the dense dX
+                                  tiles then only feed the C-Conv weight gradient in their own epilogue) */
     dccn_metrics* metrics;     /* ce_mean / conf_matrix / linear_ber / log_ber */
     float* tx_power;           /* device float[1] `tx_power:0` (nullable: skip R8) */
     void* workspace;
@@ -263,6 +274,20 @@ typedef struct dccn_rx_buffers {
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
+int dccn_rx_bwd_fused_supported(const dccn_rx_shape* shape);
+/* The backward half of the basic receiver's training step as one launch (small layers, see the query above):
+ *   dfft = dz . Wd^T                     (dev/py/model.py:1268-1275 backward; written only when dfft != NULL)
+ *   dWd  = fft_out^T . dz, dbd = colsum  (k-major tiles, split-K slabs)
+ *   dWeff = x_norm^T . dfft              (dev/py/complex.py:183-192 backward; contracted in the epilogue of the tiles
+ *                                         that produce dfft, one [2kin,64] partial per tile)
+ * reduce != 0: a second and third launch sum the slabs / fold the partials into dw_dense [S*2F, 2D], db_dense [2D]
+ * (nullable), dw_conv [kin, 2F] = [Wa|Wb], db_conv [2F] (nullable); reduce == 0 leaves them in the workspace (what the
+ * fused training step does: its optimizer launch reduces them).  x_norm [batch,S,kin,2], fft_out [batch,S,F,2],
+ * dz [batch,2D], w_dense [S*2F, 2D]. */
+size_t dccn_rx_backward_workspace_size(int batch, int S, int kin, int F, int D);
+int dccn_rx_backward(const float* x_norm, const float* fft_out, const float* dz, const float* w_dense, float* dfft,
+                     float* dw_dense, float* db_dense, float* dw_conv, float* db_conv, int batch, int S, int kin, int F,
+                     int D, int reduce, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train);
 /* eager launch sequences */
 int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream);

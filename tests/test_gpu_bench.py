@@ -39,3 +39,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in o:
         assert o[k]["ms_per_step"] > 0 and abs(o[k]["mfma_frac"] - o[k]["achieved_tflops"] / 157.3) < 1e-9
     assert o["c4"]["mfma_frac"] > 0.3 and o["c4"]["algorithmic_gflop"] > 470
+    # configs[2]: the 40-point 16-QAM / EVA SNR sweep, sharded like every sweep of the harness (here: 1 rank owns all points)
+    w = d["sweep"]
+    assert w["points"] == 40 and w["frames_per_point"] == 20000 and w["scaling"] == "strong" and w["points_per_rank"] == [40]
+    assert w["bits_counted"] == 40 * 20000 * 320 * 4 and w["seconds"] > 0
+    assert abs(w["points_per_s"] - 40 / w["seconds"]) < 1e-6 * w["points_per_s"] and w["symbols_per_s"] > 1e6
+    assert r["op"] in d["kernels"] and d["kernels"][r["op"]]["us"] > 0
+

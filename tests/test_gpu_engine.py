@@ -167,9 +167,17 @@ def test_graph_replay_equals_eager():
             eng.train_step(x, bits, graph=graph, fork=fork)
         torch.cuda.synchronize()
         outs.append((eng.params.clone(), eng.prob.clone(), eng.metrics()))
-    for o in outs[1:]:
-        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
-        assert o[2]["conf"] == outs[0][2]["conf"]
+    # captured replay = the same launches: bitwise.  The forked two-stream graph runs the round-2 plan (dX, dW and the
+    # C-Conv weight gradient as separate launches instead of the fused backward launch): fp32 sums regrouped only.
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    assert outs[1][2]["conf"] == outs[0][2]["conf"]
+    assert float((outs[2][0] - outs[0][0]).abs().max()) <= 2e-6 * float(outs[0][0].abs().max())
+    assert float((outs[2][1] - outs[0][1]).abs().max()) <= 2e-6
+    e = RxEngine(dims, 300, params=p, train=True)             # and the forked graph is deterministic in itself
+    for _ in range(3):
+        e.train_step(x, bits, graph=True, fork=True)
+    torch.cuda.synchronize()
+    assert torch.equal(e.params, outs[2][0]) and torch.equal(e.prob, outs[2][1])
 
 
 def test_eval_step_deterministic_and_matches_train_forward():
@@ -200,25 +208,69 @@ def test_large_fft_config_c4_slice():
     staged_checks(eng, p, x, bits, cfg, rtol=2e-5, grad_rtol=2e-5, cos_tol=1e-4)    # K up to 14336: a little more fp32 rounding
 
 
-@pytest.mark.parametrize("frames,nbits", [(1170, 2), (300, 2), (64, 4), (2000, 1)])
-def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits):
+def test_fused_backward_without_dfft_and_against_the_separate_launches():
+    """The backward half as one launch (rx_bwd.h): with or without the dfft store the step is the same bits; against
+    the round-2 plan (tuning key 11 = 0: dX, then the C-Conv weight gradient as its own split-K launch) it regroups
+    fp32 sums only.  Shapes: QPSK with the cyclic prefix (2kin = 160: the odd 32-row unit), 8-QAM without (2kin = 128),
+    a last row tile of 18 frames (1170 = 18*64 + 18) and of 36."""
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import RxEngine
+    lib = _lib.load()
+    for batch, nbits, kin in ((1170, 2, 80), (100, 3, 64), (36, 1, 80)):
+        dims, cfg, x, bits, p = make_case(batch, nbits, kin=kin, seed=21)
+        assert lib.dccn_rx_bwd_fused_supported(__import__("ctypes").byref(RxEngine(dims, batch, params=p).shape)) == 1
+
+        def run(**kw):
+            e = RxEngine(dims, batch, params=p, train=True, want_prob=True, **kw)
+            for _ in range(2):
+                e.train_step(x, bits)
+            torch.cuda.synchronize()
+            return e
+        a, b = run(want_dfft=True), run(want_dfft=False)
+        assert b.dfft is None
+        assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads) and torch.equal(a.adam_m, b.adam_m)
+        try:
+            assert lib.dccn_set_tuning(11, 0) == 0
+            c = run(want_dfft=True)
+        finally:
+            lib.dccn_set_tuning(11, 1)
+        # (step 2 runs on parameters that already differ in the last bits)
+        assert float((a.dfft - c.dfft).abs().max()) <= 2e-5 * float(c.dfft.abs().max())
+        for name in ("fft_like/conv3d/kernel", "fft_like/conv3d/bias", "demodulation/dense/kernel"):
+            ga, gc = a.view(name, a.grads), c.view(name, c.grads)
+            assert float((ga - gc).abs().max()) <= 2e-6 * float(gc.abs().max()), (batch, name)
+        assert float((a.params - c.params).abs().max()) <= 2e-6 * float(c.params.abs().max())
+
+
+PIPE_CASES = [  # (frames, nbits, kin, F, D): N=64 shapes + the geometries bench.py times (BASELINE configs[1..3])
+    (1170, 2, 80, 64, 320), (300, 2, 80, 64, 320), (64, 4, 80, 64, 320), (2000, 1, 80, 64, 320),
+    (1170, 4, 80, 64, 320),            # C3: 16-QAM, 1170 frames (separate tail launch)
+    (300, 2, 64, 64, 320),             # cp=False: the C-Conv sees the 64 samples behind the prefix
+    (585, 2, 1096, 1024, 4000),        # C4: N=1024/CP=72, 585 frames (128x128x32 tiles, R0 over 30 688 columns)
+]
+
+
+@pytest.mark.parametrize("frames,nbits,kin,F,D", PIPE_CASES)
+def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits, kin, F, D):
     """dccn_rx_buffers.x_next / x_prenormalised: R0 of batch t+1 rides on the Adam launch of step t.  Same kernels, same
     order of arithmetic -> parameters, gradients, probabilities, metrics and the optimizer state are bit-identical to
     plain steps fed the same batches (2000 frames: the two-kernel normalisation; step 3-4: hipGraph replay; the label
     slots alternate like in receiver.train's device-data loop; last=True ends the pipeline)."""
     from dl_ofdm_amd.engine import RxDims, RxEngine
-    dims = RxDims(S=7, kin=80, F=64, D=320, nbits=nbits)
+    dims = RxDims(S=7, kin=kin, F=F, D=D, nbits=nbits)
     rng = np.random.RandomState(5)
-    xs = [rng.standard_normal((frames, 7, 80, 2)).astype(np.float32) * (1 + 0.1 * t) for t in range(6)]
-    bs = [rng.randint(0, 2, (frames, 320, nbits)).astype(np.int32) for t in range(6)]
+    nb = 6 if F <= 64 else 4                                  # the N=1024 case: four batches of 180 MB are enough
+    xs = [rng.standard_normal((frames, 7, kin, 2)).astype(np.float32) * (1 + 0.1 * t) for t in range(nb)]
+    bs = [rng.randint(0, 2, (frames, D, nbits)).astype(np.int32) for t in range(nb)]
     a = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True)
-    b = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True)
+    # the pipelined engine as bench.py builds it: no z, no dfft
+    b = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True, want_z=False, want_dfft=False)
     b.prime(xs[0])
-    for t in range(6):
+    for t in range(nb):
         a.train_step(xs[t], bs[t])
-        if t < 3:        # labels through the alternating slots, next input copied by the call
+        if t < nb - 3:   # labels through the alternating slots, next input copied by the call
             b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], slot=t & 1)
-        elif t < 5:      # captured replay (slot 0)
+        elif t < nb - 1:  # captured replay (slot 0)
             b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], graph=True)
         else:            # end of the epoch: nothing is prefetched, the next call would prime again
             b.train_step_pipelined(bits=bs[t], last=True)
@@ -230,11 +282,11 @@ def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits):
     a.train_step(xs[1], bs[1])
     b.train_step_pipelined(next_x=xs[2], bits=bs[1])          # primes itself from eng.x ...
     torch.cuda.synchronize()
-    assert not torch.equal(a.params, b.params)                # ... which still holds xs[5]: a different batch, by design
+    assert not torch.equal(a.params, b.params)                # ... which still holds the last batch: a different one, by design
 
 
 @pytest.mark.parametrize("key,value", [(0, 2), (0, 1), (0, 0), (1, 0), (1, 3), (2, 1), (3, 0), (3, 1), (4, 3), (5, 32), (7, 0), (8, 0),
-                                       (9, 0), (10, 0)])
+                                       (9, 0), (10, 0), (11, 0)])
 def test_every_tuning_setting_computes_the_same_step(key, value):
     """dccn_set_tuning only selects tile configurations: two training steps under any setting agree with the default
     ones to rounding (the settings that keep the summation order are bitwise equal; the others regroup fp32 sums)."""

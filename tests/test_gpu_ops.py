@@ -120,6 +120,50 @@ def test_cconv_known_answer_dft(ops):
     assert_close(out[..., 1], -X[:, (-np.arange(N)) % N].imag, "-Im X_{N-k}", tol=2e-5)
 
 
+# ---- backward half of the step as one launch (dense dX + C-Conv dWeff in its epilogue + dense dW) ----------------
+@pytest.mark.parametrize("batch,kin,D", [(1170, 80, 320), (64, 64, 320), (37, 80, 50), (200, 64, 322)])
+def test_rx_backward_fused(ops, batch, kin, D):
+    """dccn_rx_backward against the float64 oracle of its three contractions (model.py:1268-1275 and
+    complex.py:183-192 backward), with and without the dfft store."""
+    import ctypes as C
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    S, F = 7, 64
+    rng = np.random.RandomState(batch + kin + D)
+    xn = rng.randn(batch, S, kin, 2).astype(np.float32)
+    a = rng.randn(batch, S * 2 * F).astype(np.float32)
+    dz = rng.randn(batch, 2 * D).astype(np.float32)
+    w = (rng.randn(S * 2 * F, 2 * D) / 30).astype(np.float32)
+    shape = _lib.RxShape(batch, S, kin, F, D, 2)
+    assert lib.dccn_rx_bwd_fused_supported(C.byref(shape)) == 1
+    nws = lib.dccn_rx_backward_workspace_size(batch, S, kin, F, D)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    xt, at, dzt, wt = dev(xn), dev(a), dev(dz), dev(w)
+    outs = []
+    for want_dfft in (True, False):
+        dfft = torch.zeros(batch, S * 2 * F, device="cuda")
+        dw, db = torch.zeros_like(wt), torch.zeros(2 * D, device="cuda")
+        dcw, dcb = torch.zeros(kin, 2 * F, device="cuda"), torch.zeros(2 * F, device="cuda")
+        _lib.check(lib.dccn_rx_backward(xt.data_ptr(), at.data_ptr(), dzt.data_ptr(), wt.data_ptr(),
+                                        dfft.data_ptr() if want_dfft else None, dw.data_ptr(), db.data_ptr(), dcw.data_ptr(),
+                                        dcb.data_ptr(), batch, S, kin, F, D, 1, ws.data_ptr(), nws, None), "dccn_rx_backward")
+        torch.cuda.synchronize()
+        outs.append((dfft, dw, db, dcw, dcb))
+    dfft, dw, db, dcw, dcb = outs[0]
+    for u, v in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(u, v)
+    assert float(outs[1][0].abs().max()) == 0.0
+    dz64, a64, w64 = dz.astype(np.float64), a.astype(np.float64), w.astype(np.float64)
+    assert_close(dfft.cpu().numpy(), dz64 @ w64.T, "dfft")
+    assert_close(dw.cpu().numpy(), a64.T @ dz64, "dense dW")
+    assert_close(db.cpu().numpy(), dz64.sum(0), "dense dbias")
+    # the C-Conv gradient on the GPU's own dfft (the stage's input)
+    _, gw, gb = O.cconv_gemm_bwd(xn.astype(np.float64).reshape(batch * S, kin, 2), np.zeros((kin, 2 * F)),
+                                 dfft.cpu().numpy().astype(np.float64).reshape(batch * S, F, 2))
+    assert_close(dcw.cpu().numpy(), gw, "C-Conv dW")
+    assert_close(dcb.cpu().numpy(), gb, "C-Conv dbias")
+
+
 # ---- R2 -------------------------------------------------------------------------------------
 DENSE_SHAPES = [(36, 896, 640), (1170, 896, 640), (7, 13, 5), (300, 2048, 1024), (65, 130, 67), (1, 896, 640),
                 (600, 260, 132), (2000, 64, 64),       # k-major weight gradient: ragged tiles / ragged last k range
