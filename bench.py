@@ -40,6 +40,8 @@ CONFIGS = {
                workload="QPSK, N=64/CP=16, batch=8192 OFDM symbols (1170 frames x 7), fwd+bwd+Adam"),
     "c3": dict(frames=1170, nbits=4, nfft=64, cp=16, F=64, D=320,
                workload="16-QAM, N=64/CP=16, batch=8192 OFDM symbols (1170 frames x 7), fwd+bwd+Adam"),
+    "c8": dict(frames=1170, nbits=3, nfft=64, cp=16, F=64, D=320,
+               workload="8-QAM, N=64/CP=16, batch=8192 OFDM symbols (1170 frames x 7), fwd+bwd+Adam"),
     "c4": dict(frames=585, nbits=2, nfft=1024, cp=72, F=1024, D=4000,
                workload="QPSK, N=1024/CP=72, batch=4096 OFDM symbols (585 frames x 7), fwd+bwd+Adam"),
 }
@@ -111,7 +113,7 @@ def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True):
     c = CONFIGS[name]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
     eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False,
-                   want_dfft=False)
+                   want_dfft=False, want_grads=False)
     g = torch.Generator(device=dev)
     g.manual_seed(4321)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
@@ -156,6 +158,7 @@ def measure_sweep(dev, rank, world, reps=2, frames=None):
     o = ofdm.ofdm_tx(F)
     eng = RxEngine(R.rx_dims(F, o), frames, device=dev, train=False, seed=1, want_prob=False, want_tx_power=True, want_z=True)
     gen = DeviceDataGen(F, o, device=dev, seed=1)
+    gen.want_noise_power = False
     pts = sweep.make_points([F.nbits], [F.channel], range(SWEEP["snr_lo"], SWEEP["snr_hi"] + 1), base_seed=1)
     table = torch.zeros(len(pts), 6, dtype=torch.float64, device=dev)
 
@@ -194,6 +197,45 @@ def measure_sweep(dev, rank, world, reps=2, frames=None):
             "collective": "one all-reduce of the [40, 6] float64 table" if world > 1 else "none (1 rank)"}
 
 
+def measure_e2e(dev, c, steps=200, warmup=30, channel="EPA", snr_db=10.0):
+    """The training loop as dl_ofdm_amd.receiver.train runs it with --device_data: every step draws its own batch on the
+    GPU (label bits -> constellation grid -> IFFT + CP as one GEMM -> per-frame Rayleigh taps -> 'same' FIR -> power
+    normalisation + AWGN at `snr_db`; BASELINE configs[1]: QPSK, Rayleigh EPA, SNR = 5*nbits dB, run_local_ofdm.py:66,69)
+    straight into the engine's resident buffers, then runs the pipelined training step on it: batch i+1 is generated before
+    step i is issued and normalised behind step i's optimizer launch.  Nothing crosses PCIe."""
+    import torch
+    from dl_ofdm_amd import ofdm, receiver as R
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    from dl_ofdm_amd.engine import RxEngine
+    F = R.Flags(nbits=c["nbits"], nfilter=c["F"], channel=channel, SNR=snr_db, seed=1)
+    o = ofdm.ofdm_tx(F)
+    frames = c["frames"]
+    eng = RxEngine(R.rx_dims(F, o), frames, device=dev, train=True, seed=1, want_prob=False, want_z=False, want_dfft=False)
+    gen = DeviceDataGen(F, o, device=dev, seed=1)
+    gen.want_noise_power = False
+
+    def run(n, first):
+        if first:
+            gen.make_batch(frames, snr_db, out_x=eng.x, out_bits=eng.label_slot(0))
+            eng.prime()
+        for i in range(n):
+            gen.make_batch(frames, snr_db, out_x=eng.x, out_bits=eng.label_slot((i + 1) & 1))
+            eng.train_step_pipelined(slot=i & 1)
+    run(warmup, True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps, False)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    m = eng.metrics()
+    eng.drop_prefetch()
+    return {"workload": "%s + device-side generator: Rayleigh %s at %.0f dB, a fresh %d-frame batch per step" %
+                        (c["workload"], channel, snr_db, frames),
+            "steps": steps, "ms_per_step": dt * 1e3, "symbols_per_s": frames * 7 / dt,
+            "launches_per_step": "5 generator (grid, IFFT+CP GEMM, taps, FIR, AWGN) + 4 training step",
+            "ce_mean_last": m["ce_mean"], "ber_last": m["berlin"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +253,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short C3 / C4 measurements of the `configs` object")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the `e2e` object (training loop with the device-side generator)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the `sweep` object (configs[2]: 40-point SNR sweep sharded over the ranks)")
     ap.add_argument("--sweep-frames", type=int, default=0, help="frames per sweep point (default 20 000, the reference's)")
     args = ap.parse_args()
@@ -248,7 +291,7 @@ def main():
     S, kin = 7, c["nfft"] + c["cp"]
     dims = RxDims(S=S, kin=kin, F=c["F"], D=c["D"], nbits=c["nbits"])
     eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1 + rank, want_prob=True, want_tx_power=True,
-                   want_z=False, want_dfft=False)   # z / dfft are consumed inside the launches that produce them (fused
+                   want_z=False, want_dfft=False, want_grads=False)   # z / dfft are consumed inside the launches that produce them (fused
     #                                                  dense+tail forward, fused backward) whenever the library's plan allows
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -321,7 +364,7 @@ def main():
         "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
                    "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
                    "launch": (("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph
-                              else "stream launches") + (", R0 of the next batch behind the Adam update (4 launches per step: C-Conv fwd, dense fwd + tail, fused backward, optimizer)"
+                              else "stream launches") + (", software-pipelined across steps (3 launches per step: dense fwd + tail | fused backward + R0 of the next batch | optimizer + C-Conv fwd of the next batch)"
                                                           if pipeline else ", 6 launches per step"),
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }
@@ -362,6 +405,10 @@ def main():
             eng = None
             torch.cuda.empty_cache()
             result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph, pipeline=pipeline) for k in ("c3", "c4")}
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_e2e:
+        eng = None
+        torch.cuda.empty_cache()
+        result["e2e"] = measure_e2e(dev, c)
     sweep_res = None
     if args.config == "c2" and not args.no_sweep:
         # configs[2] on every rank count the driver launches: this is the curve north_star calls "1/2/4/8-GPU SNR-sweep

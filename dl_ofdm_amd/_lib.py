@@ -50,7 +50,8 @@ class RxBuffers(C.Structure):
                 ("x_norm", c_void_p), ("fft_out", c_void_p), ("z", c_void_p), ("prob", c_void_p),
                 ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-                ("x_next", c_void_p), ("x_prenormalised", c_int)]
+                ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
+                ("keep_dense_grad", c_int)]
 
 
 class EqShape(C.Structure):
@@ -115,6 +116,8 @@ SIGNATURES = {
     "dccn_get_tuning": (_i, [_i]),
     "dccn_dense_tail_supported": (_i, [_i, _i, _i, _i]),
     "dccn_rx_bwd_fused_supported": (_i, [POINTER(RxShape)]),
+    "dccn_rx_dense_tail_fused": (_i, [POINTER(RxShape), _i]),
+    "dccn_rx_norm_rides_backward": (_i, [POINTER(RxShape)]),
     "dccn_rx_backward_workspace_size": (_sz, [_i, _i, _i, _i, _i]),
     "dccn_rx_backward": (_i, [_vp] * 9 + [_i] * 6 + [_vp, _sz, _vp]),
     "dccn_adam_tf_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, AdamHParams, _ll, _vp]),

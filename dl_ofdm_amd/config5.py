@@ -153,6 +153,7 @@ def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str
             fl = copy.deepcopy(hf)
             fl.channel = p.channel
             gens[key] = DeviceDataGen(fl, ofdm.ofdm_tx(fl), device=tr.device, seed=p.seed)
+            gens[key].want_noise_power = False
         g, pl = gens[key], tr.resident(frames)
         g.seed, g.offset = p.seed, 0
         g.make_batch(frames, p.snr_db, out_x=pl.x, out_bits=pl.bits)

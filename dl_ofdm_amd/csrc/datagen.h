@@ -143,47 +143,69 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
 // radio.py:360-366: y = np.convolve(frame, g, 'same') over the frame's T = n_sym*n_sc samples
 // (y[t] = sum_l g[l] x[t + off - l], off = (L-1)//2, zero outside the frame) + per-block partial sums of
 // |y|^2 for the AWGN stage's power normalisation.  grid = (ceil(T/256), frames).
+// Persistent form: the grid is a fixed number of blocks (<= kChanPartials) that walk the (frame, 256-sample chunk) items
+// with a grid stride and leave ONE partial sum of |y|^2 each, in a fixed order -- few enough for the AWGN kernel to add
+// them up itself (the separate sum_partials launch of rounds 1-2 is gone).  pbase: this launch's first slot in `partial`.
+constexpr int kChanPartials = 512;
 __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                        float2* __restrict__ y, double* __restrict__ partial, int T,
-                                                       int L, const int* __restrict__ frames, int g_stride) {
+                                                       int L, const int* __restrict__ frames, int g_stride, int n_frames,
+                                                       int pbase) {
     __shared__ double sh[4];
     __shared__ float2 gs[64];
-    const int fr = frames ? frames[blockIdx.y] : (int)blockIdx.y;
-    if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
-    __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bx = (T + 255) / 256;
     const int off = (L - 1) / 2;
     double pw = 0.0;
-    if (t < T) {
-        const float2* xf = x + (size_t)fr * T;
-        float2 a = make_float2(0.f, 0.f);
-        for (int l = 0; l < L; ++l) {
-            const int u = t + off - l;
-            if (u < 0 || u >= T) continue;
-            const float2 v = xf[u];
-            a.x += gs[l].x * v.x - gs[l].y * v.y;
-            a.y += gs[l].x * v.y + gs[l].y * v.x;
+    for (int item = blockIdx.x; item < n_frames * bx; item += gridDim.x) {
+        const int fi = item / bx, cb = item - fi * bx;
+        const int fr = frames ? frames[fi] : fi;
+        __syncthreads();                                  // previous item's taps are no longer read
+        if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
+        __syncthreads();
+        const int t = cb * 256 + threadIdx.x;
+        if (t < T) {
+            const float2* xf = x + (size_t)fr * T;
+            float2 a = make_float2(0.f, 0.f);
+            for (int l = 0; l < L; ++l) {
+                const int u = t + off - l;
+                if (u < 0 || u >= T) continue;
+                const float2 v = xf[u];
+                a.x += gs[l].x * v.x - gs[l].y * v.y;
+                a.y += gs[l].x * v.y + gs[l].y * v.x;
+            }
+            y[(size_t)fr * T + t] = a;
+            pw += (double)a.x * a.x + (double)a.y * a.y;
         }
-        y[(size_t)fr * T + t] = a;
-        pw = (double)a.x * a.x + (double)a.y * a.y;
     }
     pw = wave_sum(pw);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)fr * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[pbase + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // radio.py:513-526 AWGN_channel_np: out = y / sqrt(mean |y|^2 over the batch) + noise * sqrt(0.5) 10^(-SNR/20),
-// SNR per frame; mean_power[0] = mean |y|^2 (sum_partials_kernel over the FIR stage's partials).
+// SNR per frame; mean |y|^2 = sum of the FIR stage's block partials / total, added up by every block itself.
 // noise_in (standard normals [n, T, 2]) == nullptr: draw them.  Also emits the per-block partial sums of the
 // noise power (finished by sum_partials_kernel).  grid = (ceil(T/256), frames).
-__global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y, const float* __restrict__ mean_power,
+__global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y, const double* __restrict__ power_partial,
+                                                   int n_partial, double total,
                                                    const float* __restrict__ snr_db,
                                                    const float* __restrict__ noise_in, float2* __restrict__ out,
                                                    double* __restrict__ noise_partial, int T, unsigned offset,
                                                    unsigned long long seed) {
     __shared__ double sh[4];
-    const float inv_scale = 1.0f / sqrtf(mean_power[0]);
+    __shared__ float s_inv;
+    {   // mean |y|^2 over the batch from the FIR stage's <= kChanPartials block sums: every block adds them in the
+        // same fixed order (thread t: t, t+256; DPP wave sum; four wave sums), so all blocks get the same bits
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n_partial; i += 256) a += power_partial[i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) s_inv = 1.0f / sqrtf((float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / total));
+        __syncthreads();
+    }
+    const float inv_scale = s_inv;
     const int fr = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     double pw = 0.0;
     if (t < T) {
@@ -202,11 +224,13 @@ __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y,
         out[i] = make_float2(v.x * inv_scale + z.x, v.y * inv_scale + z.y);
         pw = (double)z.x * z.x + (double)z.y * z.y;
     }
-    pw = wave_sum(pw);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
-    __syncthreads();
-    if (threadIdx.x == 0 && noise_partial)
-        noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (noise_partial) {                                 // (kernel argument: block-uniform)
+        pw = wave_sum(pw);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
+        __syncthreads();
+        if (threadIdx.x == 0) noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
 }
 
 // radio.py:62-88 AWGN_channel, the *in-graph* monitor branch of the receiver graph (ofdmreceiver_np.py:136,151-152):
@@ -320,32 +344,36 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
 __global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                           float2* __restrict__ y, double* __restrict__ partial, int T,
                                                           int L, int n_sc, int n_taps, const int* __restrict__ frames,
-                                                          int g_stride) {
+                                                          int g_stride, int n_frames, int pbase) {
     __shared__ double sh[4];
-    const int fr = frames ? frames[blockIdx.y] : (int)blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bx = (T + 255) / 256;
     const int off = (L - 1) / 2;
     double pw = 0.0;
-    if (t < T) {
-        const int sym = t / n_sc, tl = t - sym * n_sc;
-        const float2* xf = x + (size_t)fr * T;
-        const float2* gf = g + (size_t)fr * g_stride + sym * L;
-        float2 a = make_float2(0.f, 0.f);
-        for (int l = 0; l < L; ++l) {
-            const int r = tl + off - l;                     // position relative to the symbol start
-            const int u = sym * n_sc + r;
-            if (r < -n_taps || r >= n_sc || u < 0) continue;
-            const float2 v = xf[u], c = gf[l];
-            a.x += c.x * v.x - c.y * v.y;
-            a.y += c.x * v.y + c.y * v.x;
+    for (int item = blockIdx.x; item < n_frames * bx; item += gridDim.x) {      // persistent: see fir_same_kernel
+        const int fi = item / bx, cb = item - fi * bx;
+        const int fr = frames ? frames[fi] : fi;
+        const int t = cb * 256 + threadIdx.x;
+        if (t < T) {
+            const int sym = t / n_sc, tl = t - sym * n_sc;
+            const float2* xf = x + (size_t)fr * T;
+            const float2* gf = g + (size_t)fr * g_stride + sym * L;
+            float2 a = make_float2(0.f, 0.f);
+            for (int l = 0; l < L; ++l) {
+                const int r = tl + off - l;                     // position relative to the symbol start
+                const int u = sym * n_sc + r;
+                if (r < -n_taps || r >= n_sc || u < 0) continue;
+                const float2 v = xf[u], c = gf[l];
+                a.x += c.x * v.x - c.y * v.y;
+                a.y += c.x * v.y + c.y * v.x;
+            }
+            y[(size_t)fr * T + t] = a;
+            pw += (double)a.x * a.x + (double)a.y * a.y;
         }
-        y[(size_t)fr * T + t] = a;
-        pw = (double)a.x * a.x + (double)a.y * a.y;
     }
     pw = wave_sum(pw);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
     __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)fr * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[pbase + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 }  // namespace dccn

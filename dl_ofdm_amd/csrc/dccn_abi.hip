@@ -37,7 +37,7 @@ static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) +
 // Kernel-configuration knobs (dccn_set_tuning): which tile configuration the GEMM-shaped operators launch.
 // 0 = the 32x32x2 family of gemm_f32_mfma.h, > 0 = a gemm16.h configuration (see the *_impl functions).
 enum TuneKey : int {
-    TUNE_DENSE_FWD = 0,         // fused dense forward + tail (nbits <= 2)
+    TUNE_DENSE_FWD = 0,         // fused dense forward + tail
     TUNE_DENSE_BWD = 1,         // grouped dX + dW
     TUNE_CCONV_FWD = 2,
     TUNE_CCONV_BWD_W = 3,
@@ -50,7 +50,13 @@ enum TuneKey : int {
     TUNE_DENSE_FWD_PLAIN = 10,  // 1: the un-fused dense forward (nbits >= 3, layer API) of small layers runs 48x64 gemm16 tiles
     TUNE_FUSED_BWD = 11,        // 1: small layers: the C-Conv weight gradient rides in the epilogue of the dense dX tiles (rx_bwd.h)
     TUNE_BWD_PRIO = 12,         // s_setprio level (0-3) of the dX blocks of the fused backward launch
-    TUNE_COUNT = 13
+    TUNE_TAIL_FUSE_HI = 13,     // 8-QAM / 16-QAM tail inside the dense forward launch: bit 0 lane-per-cell forms, bit 1 quad-lane training
+    TUNE_DW_GRADED = 14,        // > 0: graded k ranges for the dense dW items of the fused backward launch (preset number)
+    TUNE_FWD_PREFETCH = 15,     // 1: double-buffered pipelining also runs the next batch's C-Conv forward on the optimizer launch
+    TUNE_ADAM_IN_DW = 16,       // 1: large layers (unsplit dW tiles): the dense kernel's Adam update runs in the dW epilogue
+    TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
+    TUNE_NORM_ON_BWD = 18,      // 1: double-buffered pipelining: R0 of the next batch rides on the backward launch
+    TUNE_COUNT = 19
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -58,7 +64,22 @@ struct TuneTable {
     int operator[](int k) const { return v[k].load(std::memory_order_relaxed); }
     void set(int k, int x) { v[k].store(x, std::memory_order_relaxed); }
 };
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {0}}};
+// defaults = the fastest measured (A/B runs of tools/ab.py inside one process on one box, medians of 4-6 rounds of 300 steps;
+// boxes of the pool differ by up to 9 % in absolute time, so only same-process comparisons decide):
+//   12 = 3  dX tiles at wave priority 3: -0.4 us per C2 step;
+//   13 = 1  8-QAM training 86.7 -> 84.4 us with the tail in the dense launch; the quad-lane form of 16-QAM training is
+//           built and parity-tested but slower than its own launch (104.8 vs 98.8 us: one wave per SIMD cannot hide the
+//           transcendental / DPP latencies of 24 cells per quad), so bit 1 stays off;
+//   14 = 1  graded dense-dW ranges {8,6,3,2}/19 of the batch: 80.2 -> 77.4 us per C2 step over three uniform ranges;
+//   15 = 0  the optimizer launch that also runs the next batch's C-Conv forward (in-launch hand-off of the updated kernel,
+//           3 launches per step) is built and bitwise-tested but measured +1.4 us: poll + acquire + the serial fold -> tile
+//           chain (19.6 us) cost what the saved launch boundary gave (10.0 + 8.0 us as two launches);
+//   16 = 0  Adam in the dW epilogue of large layers: built, bitwise-tested, +4.7 % on the C4 step (5.21 vs 4.98 ms): the
+//           epilogue's per-row 128-byte accesses to p/m/v cost more than the 0.94 GB gradient round trip they save.
+//   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
+//   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
+//           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -93,7 +114,7 @@ static size_t norm_power_slots(int batch, int cols) {
 static size_t norm_ws_bytes(int batch, int cols) {
     size_t o = 0;
     o = carve_size(o, (size_t)kNormRowChunks * cols * 2 * sizeof(double));
-    o = carve_size(o, norm_power_slots(batch, cols) * sizeof(double));
+    o = carve_size(o, 2 * norm_power_slots(batch, cols) * sizeof(double));      // two slots: dccn_rx_buffers.norm_slot
     return align_up(o, 256);
 }
 
@@ -111,23 +132,23 @@ struct PowerPartials {      // where normalise left the R8 partial sums (finishe
 // optimizer bookkeeping of the fused training step rides on the first kernel
 // where norm_impl leaves the R8 partial sums for a [batch, cols] input in workspace `ws` (no launch)
 static void norm_power_partials(int batch, int cols, void* ws, size_t ws_bytes, const float* x, const float* y,
-                                PowerPartials* pp) {
+                                PowerPartials* pp, int slot = 0) {
     Carver c(ws, ws_bytes);
     c.take<double>((size_t)kNormRowChunks * cols * 2);
-    pp->partial = c.take<double>(norm_power_slots(batch, cols));
+    pp->partial = c.take<double>(2 * norm_power_slots(batch, cols)) + (slot ? norm_power_slots(batch, cols) : 0);
     pp->n = norm_fused_ok(x, y, batch, cols) ? norm_fused_blocks(cols) : norm_grid_x(cols) * norm_grid_y(batch);
     pp->denom = (double)batch * (double)(cols / 2);
 }
 
 static int norm_impl(const float* x, float* y, float* mean, float* var, bool want_power, PowerPartials* pp, int batch,
                      int cols, float eps, float peak, dccn_adam_state* adam, dccn_adam_hparams hp, void* ws,
-                     size_t ws_bytes, hipStream_t s) {
+                     size_t ws_bytes, hipStream_t s, int slot = 0) {
     if (!x || !y || batch <= 0 || cols <= 0 || (want_power && (cols & 1))) return DCCN_ERR_INVALID_ARG;
     if (ws_bytes < norm_ws_bytes(batch, cols) || !ws) return DCCN_ERR_WORKSPACE;
     Carver c(ws, ws_bytes);
     double* partial = c.take<double>((size_t)kNormRowChunks * cols * 2);
     const int gx = norm_grid_x(cols), gy = norm_grid_y(batch);
-    double* pw = c.take<double>(norm_power_slots(batch, cols));
+    double* pw = c.take<double>(2 * norm_power_slots(batch, cols)) + (slot ? norm_power_slots(batch, cols) : 0);
     if (norm_fused_ok(x, y, batch, cols)) {
         // the whole batch of a column strip fits in one block's registers: single pass, single launch
         const int blocks = norm_fused_blocks(cols);
@@ -241,12 +262,41 @@ static SplitPlan dense_dw_plan(int M, int K, int N, int range_rows = 256) {
     return sp;
 }
 constexpr int kFusedBwdRangeRows = 448;
+// graded k ranges (in 64-row k-tiles, as shares of the total): the items are dispatched range by range, so the last ones
+// handed out are the short ones
+static int graded_ranges(int preset, int M, int off[9]) {
+    static const int shares[][6] = {{0}, {8, 6, 3, 2, 0}, {9, 6, 4, 0}, {7, 5, 4, 3, 0}, {10, 9, 0}, {8, 7, 4, 0}, {6, 5, 4, 3, 1, 0},
+                                    {9, 7, 3, 0}};
+    if (preset < 1 || preset > 7) return 0;
+    const int nt = ceil_div(M, 64);
+    int tot = 0, n = 0;
+    while (shares[preset][n]) tot += shares[preset][n++];
+    int used = 0, acc = 0, cnt = 0;
+    off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        acc += shares[preset][i];
+        int upto = (int)((long long)acc * nt / tot);
+        if (i == n - 1) upto = nt;
+        if (upto <= used) continue;
+        used = upto;
+        off[++cnt] = upto * 64 < M ? upto * 64 : M;
+    }
+    return cnt;
+}
 
 // defer != nullptr: leave the split-K slabs un-reduced (the fused Adam kernel sums them) and report them
 struct DeferredSlabs {
     const float* dw_slabs;
     const float* db_slabs;
     int splits;
+    bool adam_done = false;     // the dense kernel's optimizer update already ran in the dW epilogue
+};
+struct AdamEpi {               // what the dW epilogue needs to apply the update (arena pointers at the dense kernel)
+    float* p; float* m; float* v;
+    const float* reg; const float* gate;
+    const dccn_adam_state* state;
+    dccn_adam_hparams hp;
+    bool keep_grad;
 };
 static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
                             size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr, int ldx = 0) {
@@ -317,8 +367,10 @@ static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
 // (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
 static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
-                                  int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer) {
+                                  int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer,
+                                  const AdamEpi* ae = nullptr) {
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
+    defer->adam_done = false;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
     GemmParams px = dense_bwd_x_params(dy, w, dx, M, K, N);
     GemmParams pw = gp_zero();                // dw[K,N] = x[M,K]^T . dy[M,N]
@@ -329,6 +381,15 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     pw.vecA = (K % 4 == 0) && aligned16(x) && small_enough(M, K);
     pw.vecB = (N % 4 == 0) && aligned16(dy) && small_enough(M, N);
     const bool vec = px.vecA && px.vecB && pw.vecA && pw.vecB;
+    // few rows (the equaliser's 73-frame batch): dX on 16x64 tiles and the unsplit dW (k = the few rows: one or two
+    // k-tiles) in ONE grid -- round 2 ran them as two launches of 6-10 us each, almost all of it launch ramp and drain
+    if (g_tune[TUNE_SKINNY] > 0 && g_tune[TUNE_SKINNY_GROUPED] && vec && M <= 96 && (K % 4 == 0) && (N % 4 == 0)) {
+        pw.klen = round_k(M);
+        pw.C = dw; pw.colsum = dbias; pw.slab = 0;
+        DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2>(px, pw, 1, s, tune_smem_min())));
+        defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1;
+        return DCCN_OK;
+    }
     const int variant = g_tune[TUNE_DENSE_BWD] == kVariantKmajor ? 0 : g_tune[TUNE_DENSE_BWD];
     const long long big = (long long)ceil_div(M, 128) * ceil_div(K, 128);
     if (variant > 0 && vec && big < 2 * kCUs) {
@@ -364,6 +425,14 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     if (vec && g_tune[TUNE_DENSE_BWD_BIG] && grouped_big_ok(px, pw, sp.splits)) {
         pw.ldc = N;
         if (sp.splits == 1) { pw.C = dw; pw.colsum = dbias; pw.slab = 0; }
+        if (sp.splits == 1 && ae != nullptr && g_tune[TUNE_ADAM_IN_DW]) {
+            // unsplit tiles hold the whole gradient: the optimizer update of the kernel happens in their epilogue
+            pw.ad_p = ae->p; pw.ad_m = ae->m; pw.ad_v = ae->v; pw.ad_reg = ae->reg; pw.ad_gate = ae->gate;
+            pw.ad_state = ae->state;
+            pw.ad_omb1 = 1.0f - ae->hp.beta1; pw.ad_omb2 = 1.0f - ae->hp.beta2; pw.ad_eps = ae->hp.eps;
+            if (!ae->keep_grad) pw.C = nullptr;
+            defer->adam_done = true;
+        }
         DCCN_TRY((launch_dense_bwd_grouped<true, 128, 128, 32>(px, pw, sp.splits, s)));
         defer->dw_slabs = sp.splits > 1 ? slabs : nullptr;
         defer->db_slabs = (sp.splits > 1 && dbias) ? cs : nullptr;
@@ -615,11 +684,17 @@ static int rx_bwd_fused_impl(const float* x_norm, const float* fft_out, const fl
     pw.slab = (long long)dK * dN;
     pw.vecA = 1; pw.vecB = 1;
     const SplitPlan sp = dense_dw_plan(batch, dK, dN, kFusedBwdRangeRows);
-    Carver c(ws_dense, ws_dense_bytes);
-    float* slabs = c.take<float>((size_t)sp.splits * dK * dN);
-    float* cs = c.take<float>((size_t)sp.splits * dN);
-    pw.C = slabs; pw.colsum = dbias_dense ? cs : nullptr;
     pw.klen = sp.klen;
+    int nsplit = sp.splits;
+    if (g_tune[TUNE_DW_GRADED] > 0 && sp.splits > 1 && batch >= 768) {        // (>= 12 k-tiles: else the last ranges get too short)
+        const int n = graded_ranges(g_tune[TUNE_DW_GRADED], batch, pw.koff);
+        if (n > 1 && n <= max_splits16(dK, dN)) { pw.nranges = n; nsplit = n; }
+    }
+    Carver c(ws_dense, ws_dense_bytes);                   // (sized for max_splits16 slabs: splitk_ws_bytes)
+    float* slabs = c.take<float>((size_t)nsplit * dK * dN);
+    float* cs = c.take<float>((size_t)nsplit * dN);
+    if (!c.ok()) return DCCN_ERR_WORKSPACE;
+    pw.C = slabs; pw.colsum = dbias_dense ? cs : nullptr;
     if (!kmajor_ok(pw)) return DCCN_ERR_INVALID_ARG;
     const int tiles = rx_bwd_fused_tiles(batch, S, F);
     Carver cc(ws_conv, ws_conv_bytes);
@@ -629,9 +704,9 @@ static int rx_bwd_fused_impl(const float* x_norm, const float* fft_out, const fl
     de.colsum = cc.take<float>((size_t)tiles * 64);
     de.batch = batch; de.ldx = S * 2 * kin; de.two_kin = 2 * kin; de.two_F = 2 * F;
     de.prio = g_tune[TUNE_BWD_PRIO];
-    if (2 * kin == 160) DCCN_TRY(launch_rx_bwd_fused<5>(px, pw, de, sp.splits, nr, fin, hp, s));
-    else DCCN_TRY(launch_rx_bwd_fused<4>(px, pw, de, sp.splits, nr, fin, hp, s));
-    ds->dw_slabs = slabs; ds->db_slabs = dbias_dense ? cs : nullptr; ds->splits = sp.splits;
+    if (2 * kin == 160) DCCN_TRY(launch_rx_bwd_fused<5>(px, pw, de, nsplit, nr, fin, hp, s));
+    else DCCN_TRY(launch_rx_bwd_fused<4>(px, pw, de, nsplit, nr, fin, hp, s));
+    ds->dw_slabs = slabs; ds->db_slabs = dbias_dense ? cs : nullptr; ds->splits = nsplit;
     fd->slabs = de.partial; fd->colsum = de.colsum;
     fd->splits = ceil_div(batch, 64) * S;                       // terms per element: (row tile, symbol)
     fd->slab = (long long)((2 * F) / 64) * 2 * kin * 64;        // distance between consecutive terms
@@ -712,7 +787,7 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     fa.blk_metrics = bm; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
-    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp));
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -723,7 +798,8 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
 }
 
 // ---------------------------------------------------------------------------------------
-// dense forward with the tail fused into its epilogue (gemm16.h EPI_TAIL; nbits <= 2)
+// dense forward with the tail fused into its epilogue (gemm16.h EPI_TAIL: register layout for nbits <= 2, tile staged
+// through LDS for nbits >= 3)
 // ---------------------------------------------------------------------------------------
 static void dense_tail_tiles(int variant, int& bm, int& bn) {
     bn = 64;
@@ -738,11 +814,19 @@ static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
     return align_up(o, 256);
 }
 static bool dense_tail_shape_ok(int M, int K, int N, int nbits) {
-    return g_tune[TUNE_DENSE_FWD] > 0 && nbits >= 1 && nbits <= 2 && M > 0 && K > 0 && N > 0 && (K % 4 == 0) && (N % 4 == 0) &&
+    // nbits >= 3 (tail weights in LDS; nbits = 4 training in the quad-lane form): knob 13
+    return g_tune[TUNE_DENSE_FWD] > 0 && nbits >= 1 && nbits <= 4 && M > 0 && K > 0 && N > 0 && (K % 4 == 0) && (N % 4 == 0) &&
            small_enough(M, K) && small_enough(K, N) && (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs;
 }
 static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
     return dense_tail_shape_ok(M, K, N, nbits) && aligned16(x) && aligned16(w);
+}
+// which steps take the fused launch for 8-QAM / 16-QAM (knob 13: bit 0 = the lane-per-cell forms -- nbits 3, and nbits 4
+// evaluation; bit 1 = the quad-lane form of 16-QAM training).  The operator dccn_dense_tail_* itself accepts every nbits.
+static bool dense_tail_planned(int nbits, bool train) {
+    if (nbits <= 2) return true;
+    const int k = g_tune[TUNE_TAIL_FUSE_HI];
+    return (nbits == 4 && train) ? (k & 2) != 0 : (k & 1) != 0;
 }
 
 template <int NB, bool BWD>
@@ -763,12 +847,20 @@ static int dense_tail_launch(int variant, const GemmParams& p, const TailEpiPara
     }
 }
 
+// nbits >= 3: the two tile shapes the training / sweep steps use (every other variant number runs 48x64)
+template <int NB, bool BWD>
+static int dense_tail_hi_launch(int variant, const GemmParams& p, const TailEpiParams& tp, hipStream_t s) {
+    const size_t sm = tune_smem_min();
+    if (variant == 13) return launch_dense_tail16<1, 4, 5, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);      // 80x64 (large layers)
+    return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);                          // 48x64
+}
+
 // z nullable (not materialised then).  defer: as tail_impl.
 static int dense_tail_impl(bool bwd, const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
                            const float* tailp, float* prob, dccn_metrics* metrics, float* dz, float* dtailp, int M,
                            int K, int N, int nbits, const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes,
                            hipStream_t s, TailFinalizeArgs* defer = nullptr) {
-    if (!x || !w || !bits || !tailp || !metrics || M <= 0 || K <= 0 || N <= 0 || (N & 1) || nbits < 1 || nbits > 2)
+    if (!x || !w || !bits || !tailp || !metrics || M <= 0 || K <= 0 || N <= 0 || (N & 1) || nbits < 1 || nbits > 4)
         return DCCN_ERR_INVALID_ARG;
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!dense_tail_ok(x, w, M, K, N, nbits)) return DCCN_ERR_INVALID_ARG;
@@ -777,6 +869,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     // large layers (several rounds of 48x64 tiles): 80x64 tiles re-use the B tile for five row blocks instead of three
     // (C4: 1.42 -> 1.34 ms); the lane's ten cells go through the tail in two batches of five
     if (variant == 9 && (long long)ceil_div(M, 48) * ceil_div(N, 64) >= 4LL * kCUs) variant = 13;
+    if (nbits >= 3 && variant != 13) variant = 9;
     int bm, bn;
     dense_tail_tiles(variant, bm, bn);
     const int nblk = ceil_div(M, bm) * ceil_div(N, bn);
@@ -795,7 +888,9 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     tp.inv_count = 1.0f / (float)(cells * nbits);
     int st;
     if (nbits == 1) st = bwd ? dense_tail_launch<1, true>(variant, p, tp, s) : dense_tail_launch<1, false>(variant, p, tp, s);
-    else st = bwd ? dense_tail_launch<2, true>(variant, p, tp, s) : dense_tail_launch<2, false>(variant, p, tp, s);
+    else if (nbits == 2) st = bwd ? dense_tail_launch<2, true>(variant, p, tp, s) : dense_tail_launch<2, false>(variant, p, tp, s);
+    else if (nbits == 3) st = bwd ? dense_tail_hi_launch<3, true>(variant, p, tp, s) : dense_tail_hi_launch<3, false>(variant, p, tp, s);
+    else st = bwd ? dense_tail_hi_launch<4, true>(variant, p, tp, s) : dense_tail_hi_launch<4, false>(variant, p, tp, s);
     DCCN_TRY(st);
     const int P = bwd ? tail_param_count(nbits) : 0;
     const bool pw = pp != nullptr && power_out != nullptr;
@@ -803,7 +898,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
-    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp));
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -842,7 +937,7 @@ struct RxLayout {
     long long o_conv_w, o_conv_b, o_dense_w, o_dense_b, o_tail, total;
     int rows, cols, dK, dN;
     long long cells;
-    size_t ws_norm, ws_tail, ws_dense_bw, ws_conv_bw;
+    size_t ws_norm, ws_tail, ws_dense_bw, ws_conv_bw, ws_sync;
 };
 static RxLayout rx_layout(const dccn_rx_shape* sh) {
     RxLayout L;
@@ -860,11 +955,13 @@ static RxLayout rx_layout(const dccn_rx_shape* sh) {
     L.cells = (long long)sh->batch * sh->D;
     L.ws_norm = norm_ws_bytes(sh->batch, L.cols);
     L.ws_tail = tail_ws_bytes(L.cells, sh->nbits);
-    if (sh->nbits <= 2) {
+    {
         const size_t f = dense_tail_ws_bytes(sh->batch, L.dN, sh->nbits);
         if (f > L.ws_tail) L.ws_tail = f;
     }
     L.ws_dense_bw = splitk_ws_bytes(L.dK, L.dN, sh->batch);
+    // hand-off words of the update + prefetch launch: arrival counter + one flag per C-Conv forward tile, 256 B apart
+    L.ws_sync = 256 + (size_t)ceil_div(L.rows, 64) * ceil_div(2 * sh->F, 64) * kFlagStride * sizeof(unsigned);
     L.ws_conv_bw = cconv_bw_ws_bytes(L.rows, sh->kin, sh->F);
     {
         const size_t f = rx_bwd_fused_ws_bytes(sh->batch, sh->S, sh->kin, sh->F);
@@ -880,6 +977,7 @@ static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
     if (train) {
         o = carve_size(o, L.ws_dense_bw);
         o = carve_size(o, L.ws_conv_bw);
+        o = carve_size(o, L.ws_sync);
     }
     return align_up(o, 256);
 }
@@ -898,23 +996,27 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     void* ws_tail = c.take<char>(L.ws_tail);
     void* ws_dbw = train ? c.take<char>(L.ws_dense_bw) : nullptr;
     void* ws_cbw = train ? c.take<char>(L.ws_conv_bw) : nullptr;
+    unsigned* ws_sync = train ? reinterpret_cast<unsigned*>(c.take<char>(L.ws_sync)) : nullptr;
     float* P = b->params;
     float* G = b->grads;
 
     // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
     const bool pre = train && b->x_prenormalised != 0;
+    const int nslot = b->norm_slot ? 1 : 0;
     if (pre) {
         if (L.cols & 1) return DCCN_ERR_INVALID_ARG;
-        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next ? b->x_next : b->x, b->x_norm, &pp);
+        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next ? b->x_next : b->x, b->x_norm, &pp, nslot);
     } else {
         DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, sh->batch, L.cols, 1e-9f, 8.0f,
-                           nullptr, hp, ws_norm, L.ws_norm, s));
+                           nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
-    // R1
-    DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
+    // R1 -- unless the previous call's optimizer launch already ran it on this batch (x_prenormalised == 2)
+    if (!(pre && b->x_prenormalised == 2))
+        DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     TailFinalizeArgs fin;
-    if (dense_tail_ok(b->fft_out, P + L.o_dense_w, sh->batch, L.dK, L.dN, sh->nbits)) {
+    if (dense_tail_planned(sh->nbits, train) &&
+        dense_tail_ok(b->fft_out, P + L.o_dense_w, sh->batch, L.dK, L.dN, sh->nbits)) {
         // R2 with R3-R6 (+ tail backward) in its epilogue; z is materialised only when the caller gave a buffer
         DCCN_TRY(dense_tail_impl(train, b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, b->bits, P + L.o_tail, b->prob,
                                  b->metrics, b->dz, train ? G + L.o_tail : nullptr, sh->batch, L.dK, L.dN, sh->nbits, &pp,
@@ -940,9 +1042,23 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     const bool fuse_bw = !side && can_defer &&
                          rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, b->x_norm, b->fft_out, b->dz, P + L.o_dense_w);
     if (!fuse_bw && !b->dfft) return DCCN_ERR_INVALID_ARG;
+    // R0 of the next batch: on leading blocks of the fused backward launch when the caller gave the second x_norm buffer
+    const bool ride_bw = fuse_bw && b->x_next != nullptr && b->x_norm_next != nullptr && kNormFusedCG == 2 &&
+                         norm_fused_ok(b->x_next, b->x_norm_next, sh->batch, L.cols);
+    if (b->x_norm_next != nullptr && b->x_next != nullptr && !ride_bw) return DCCN_ERR_INVALID_ARG;   // ask dccn_rx_norm_rides_backward first
     if (fuse_bw) {
         NormRideArgs nr;
         memset(&nr, 0, sizeof(nr));
+        if (ride_bw) {
+            // the update + prefetch launch of this step counts arrivals from zero and publishes into cleared flag words
+            fin.zero_word = ws_sync; fin.zero_flags = ws_sync + 64; fin.zero_stride = kFlagStride;
+            fin.n_zero_flags = ceil_div(L.rows, 64) * ceil_div(2 * sh->F, 64);
+            PowerPartials np;
+            norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm_next, &np, nslot ^ 1);
+            nr.x = b->x_next; nr.y = b->x_norm_next; nr.power = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
+            nr.batch = sh->batch; nr.cols = L.cols; nr.blocks = norm_fused_blocks(L.cols);
+            nr.eps = 1e-9f; nr.peak = 8.0f;
+        }
         DCCN_TRY(rx_bwd_fused_impl(b->x_norm, b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_b, sh->batch, sh->S,
                                    sh->kin, sh->F, sh->D, ws_dbw, L.ws_dense_bw, ws_cbw, L.ws_conv_bw, nr, fin, hp, s, &ds, &fd,
                                    &fold_tilew));
@@ -956,8 +1072,30 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
     } else {
         // default: dense dX and dW/db in one grouped launch (independent GEMMs packed on the same grid)
+        // Large layers whose dW tiles are unsplit (N = 1024: 585 rows are one k range) apply the dense kernel's Adam update
+        // in the dW epilogue: the optimizer launch then skips 98 % of the arena and the 468 MB gradient never makes its
+        // round trip through HBM.  The update needs this step's alpha and BER gate, so the tail's slab reduction (which
+        // otherwise rides on the C-Conv weight-gradient launch further down) runs first, as a launch of its own.
+        AdamEpi ae;
+        const AdamEpi* aep = nullptr;
+        {
+            const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
+            const long long bigx = (long long)ceil_div(sh->batch, 128) * ceil_div(L.dK, 128);
+            const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
+            if (g_tune[TUNE_ADAM_IN_DW] && g_tune[TUNE_DENSE_BWD_BIG] && sp.splits == 1 && bigx >= 2 * kCUs && bigw >= 2 * kCUs &&
+                (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0) {
+                hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
+                DCCN_LAUNCH_CHECK();
+                fin.metrics = nullptr;                       // the riding copy of this stage below becomes a no-op
+                ae.p = P + L.o_dense_w; ae.m = b->adam_m + L.o_dense_w; ae.v = b->adam_v + L.o_dense_w;
+                ae.reg = b->reg_coef ? b->reg_coef + L.o_dense_w : nullptr;
+                ae.gate = b->reg_coef ? &b->metrics->berlin : nullptr;
+                ae.state = b->adam; ae.hp = hp; ae.keep_grad = b->keep_dense_grad != 0;
+                aep = &ae;
+            }
+        }
         DCCN_TRY(dense_bwd_grouped_impl(b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_w, G + L.o_dense_b,
-                                        sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds));
+                                        sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds, aep));
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
@@ -976,20 +1114,34 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.cw_splits = fd.slabs ? fd.splits : 0; aa.cw_slab = fd.slabs ? fd.slab : 0;
     aa.kin = sh->kin; aa.F = sh->F; aa.o_cw = L.o_conv_w; aa.cw_tilew = fd.slabs ? fold_tilew : 0;
     aa.n_conv = L.o_dense_w;                      // C-Conv kernel + bias come first in the arena
-    aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, kRedLanes) : 0;
+    aa.skip_lo = aa.skip_hi = 0;
+    if (ds.adam_done) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
+    aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, fold_tilew > 0 ? kFoldLanesTiled : kRedLanes) : 0;
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
     if (blocks > 8 * kCUs) blocks = 8 * kCUs;
     blocks += aa.fold_blocks;
     // R0 of the next batch on the leading blocks of this launch (dccn_rx_buffers.x_next)
     aa.nx = nullptr; aa.ny = nullptr; aa.npower = nullptr; aa.nbatch = 0; aa.ncols = 0; aa.norm_blocks = 0;
     aa.neps = 1e-9f; aa.npeak = 8.0f;
-    const bool ride = b->x_next != nullptr && kNormFusedCG == 2 && norm_fused_ok(b->x_next, b->x_norm, sh->batch, L.cols);
+    const bool ride = !ride_bw && b->x_next != nullptr && kNormFusedCG == 2 && norm_fused_ok(b->x_next, b->x_norm, sh->batch, L.cols);
     if (ride) {
         PowerPartials np;
-        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm, &np);
+        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm, &np, nslot);
         aa.nx = b->x_next; aa.ny = b->x_norm; aa.npower = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
         aa.nbatch = sh->batch; aa.ncols = L.cols; aa.norm_blocks = norm_fused_blocks(L.cols);
         blocks += aa.norm_blocks;
+    }
+    if (ride_bw && aa.fold_blocks > 0 && g_tune[TUNE_FWD_PREFETCH]) {
+        // the C-Conv forward of the batch the backward launch has just normalised rides on this launch (rx_bwd.h)
+        PrefetchFwdArgs f;
+        f.pc = gp_zero();
+        f.pc.A = b->x_norm_next; f.pc.B = P + L.o_conv_w; f.pc.C = b->fft_out; f.pc.bias = P + L.o_conv_b; f.pc.cbias = 1;
+        f.pc.M = L.rows; f.pc.N = 2 * sh->F; f.pc.K = 2 * sh->kin;
+        f.pc.lda = 2 * sh->kin; f.pc.ldb = 2 * sh->F; f.pc.ldc = 2 * sh->F;
+        f.pc.klen = round_k(2 * sh->kin); f.pc.cF = sh->F; f.pc.vecA = 1; f.pc.vecB = 1;
+        f.tiles = ceil_div(f.pc.M, 64) * ceil_div(f.pc.N, 64);
+        f.hw.counter = ws_sync; f.hw.flags = ws_sync + 64; f.hw.expected = (unsigned)aa.fold_blocks; f.hw.n_flags = f.tiles;
+        return launch_rx_update_prefetch(aa, hp, f, (int)(blocks - aa.fold_blocks), s);
     }
     switch (ds.splits) {
         case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
@@ -1000,11 +1152,11 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         default: hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
     }
     DCCN_LAUNCH_CHECK();
-    if (b->x_next != nullptr && !ride) {
+    if (b->x_next != nullptr && !ride && !ride_bw) {
         // shapes the single-pass kernel does not take: the same normalisation as launches of their own
         PowerPartials np;
         DCCN_TRY(norm_impl(b->x_next, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &np, sh->batch, L.cols, 1e-9f,
-                           8.0f, nullptr, hp, ws_norm, L.ws_norm, s));
+                           8.0f, nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
     return DCCN_OK;
 }
@@ -1207,7 +1359,7 @@ int dccn_rx_backward(const float* x_norm, const float* fft_out, const float* dz,
     const long long n = (long long)dK * dN;
     if (db_dense) DCCN_TRY(launch_splitk_reduce2(ds.dw_slabs, ds.splits, n, dw_dense, n, ds.db_slabs, (long long)dN, db_dense, (long long)dN, s));
     else DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw_dense, n, s));
-    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
+    const int fold_blocks = ceil_div(kin * F + F, tilew > 0 ? kFoldLanesTiled : kRedLanes);
     hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, fd.slabs, fd.splits, fd.slab, fd.colsum, dw_conv,
                        db_conv, kin, F, tilew);
     DCCN_LAUNCH_CHECK();
@@ -1223,6 +1375,18 @@ int dccn_debug_set_trace(unsigned long long* buf) {
 #endif
 
 int dccn_dense_tail_supported(int M, int K, int N, int nbits) { return dense_tail_shape_ok(M, K, N, nbits) ? 1 : 0; }
+int dccn_rx_dense_tail_fused(const dccn_rx_shape* sh, int train) {
+    if (!shape_ok(sh)) return 0;
+    return dense_tail_planned(sh->nbits, train != 0) &&
+           dense_tail_shape_ok(sh->batch, sh->S * 2 * sh->F, 2 * sh->D, sh->nbits) ? 1 : 0;
+}
+int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {
+    if (!shape_ok(sh)) return 0;
+    const int cols = sh->S * sh->kin * 2;
+    const bool ok = g_tune[TUNE_NORM_ON_BWD] && rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, nullptr, nullptr, nullptr, nullptr) &&
+                    kNormFusedCG == 2 && norm_fused_ok(nullptr, nullptr, sh->batch, cols);
+    return ok ? (g_tune[TUNE_FWD_PREFETCH] ? 2 : 1) : 0;
+}
 int dccn_rx_bwd_fused_supported(const dccn_rx_shape* sh) {
     if (!shape_ok(sh)) return 0;
     // (pointer alignment is checked again at launch time; the query assumes 16-byte aligned buffers)
@@ -1230,7 +1394,7 @@ int dccn_rx_bwd_fused_supported(const dccn_rx_shape* sh) {
 }
 
 size_t dccn_dense_tail_workspace_size(int M, int N, int nbits) {
-    if (M <= 0 || N <= 0 || nbits < 1 || nbits > 2) return 0;
+    if (M <= 0 || N <= 0 || nbits < 1 || nbits > 4) return 0;
     return dense_tail_ws_bytes(M, N, nbits);
 }
 int dccn_dense_tail_fwd(const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
@@ -1305,7 +1469,7 @@ int dccn_rx_normalise(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dc
     dccn_adam_hparams hp;
     memset(&hp, 0, sizeof(hp));
     return norm_impl(buf->x, buf->x_norm, nullptr, nullptr, buf->tx_power != nullptr, &pp, shape->batch, L.cols, 1e-9f,
-                     8.0f, nullptr, hp, ws_norm, L.ws_norm, (hipStream_t)stream);
+                     8.0f, nullptr, hp, ws_norm, L.ws_norm, (hipStream_t)stream, buf->norm_slot ? 1 : 0);
 }
 
 // mode: bit0 = train, bit1 = fork the dense weight-gradient branch onto a second stream
@@ -1549,12 +1713,18 @@ int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t
     return dense_fwd_impl(grid_ws, idft, nullptr, tx, frames * S, 2 * K, 2 * (K + CP), s);
 }
 static int chan_blocks_x(int T) { return ceil_div(T, 256); }
+// persistent FIR grid: all items when they are few, else two blocks per CU; never more than the partial slots
+static int fir_blocks(int items, int cap) {
+    int b = items < 2 * kCUs ? items : 2 * kCUs;
+    if (b > cap) b = cap;
+    return b < 1 ? 1 : b;
+}
 size_t dccn_channel_awgn_workspace_size(int frames, int T, int L) {
     if (frames <= 0 || T <= 0 || L <= 0) return 0;
     size_t o = 0;
     o = carve_size(o, (size_t)frames * L * 2 * sizeof(float));
     o = carve_size(o, (size_t)frames * T * 2 * sizeof(float));
-    o = carve_size(o, (size_t)frames * chan_blocks_x(T) * sizeof(double));
+    o = carve_size(o, (size_t)kChanPartials * sizeof(double));
     o = carve_size(o, (size_t)frames * chan_blocks_x(T) * sizeof(double));
     o = carve_size(o, 4 * sizeof(float));
     return align_up(o, 256);
@@ -1572,21 +1742,18 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
     float* g = c.take<float>((size_t)frames * L * 2);
     float* y = c.take<float>((size_t)frames * T * 2);
     const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)frames * bx);
+    double* partial = c.take<double>((size_t)kChanPartials);
     double* npartial = c.take<double>((size_t)frames * bx);
-    float* mean_power = c.take<float>(4);
     hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
                        n_taps, L, nfft, identity, offset, seed, (const int*)nullptr, n_taps, L, 1);
     DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fir_same_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, (const int*)nullptr, L);
+    const int nfb = fir_blocks(frames * bx, kChanPartials);
+    hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                       (float2*)y, partial, T, L, (const int*)nullptr, L, frames, 0);
     DCCN_LAUNCH_CHECK();
     const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
-                       mean_power);
-    DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
-                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, nfb, total,
+                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
     DCCN_LAUNCH_CHECK();
     if (noise_power) {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
@@ -1616,21 +1783,18 @@ int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const floa
     float* g = c.take<float>((size_t)frames * S * L * 2);
     float* y = c.take<float>((size_t)frames * T * 2);
     const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)frames * bx);
+    double* partial = c.take<double>((size_t)kChanPartials);
     double* npartial = c.take<double>((size_t)frames * bx);
-    float* mean_power = c.take<float>(4);
     hipLaunchKernelGGL(doppler_taps_kernel, dim3(frames), dim3(64), 0, s, theta_in, coeff, alpha, (float2*)g, (float2*)H,
                        n_taps, L, nfft, S, Fd, t_sym, offset, seed, (const int*)nullptr, n_taps, S * L);
     DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fir_doppler_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, n_sc, n_taps, (const int*)nullptr, S * L);
+    const int nfb = fir_blocks(frames * bx, kChanPartials);
+    hipLaunchKernelGGL(fir_doppler_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                       (float2*)y, partial, T, L, n_sc, n_taps, (const int*)nullptr, S * L, frames, 0);
     DCCN_LAUNCH_CHECK();
     const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
-                       mean_power);
-    DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
-                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, nfb, total,
+                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
     DCCN_LAUNCH_CHECK();
     if (noise_power) {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
@@ -1669,9 +1833,12 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
     float* g = c.take<float>((size_t)frames * gstride * 2);
     float* y = c.take<float>((size_t)frames * T * 2);
     const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)frames * bx);
+    double* partial = c.take<double>((size_t)kChanPartials);
     double* npartial = c.take<double>((size_t)frames * bx);
-    float* mean_power = c.take<float>(4);
+    int live = 0;
+    for (int i = 0; i < n_groups; ++i) live += groups[i].n_frames > 0 ? 1 : 0;
+    const int pcap = kChanPartials / (live > 0 ? live : 1);       // partial slots per group launch
+    int pbase = 0;
     for (int i = 0; i < n_groups; ++i) {
         const dccn_channel_group& q = groups[i];
         if (q.n_frames == 0) continue;
@@ -1680,24 +1847,25 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
             hipLaunchKernelGGL(channel_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, taps_in, q.coeff, q.alpha, (float2*)g,
                                (float2*)H, q.n_taps, L, nfft, q.identity, offset, seed, q.frames, 16, gstride, S);
             DCCN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(fir_same_kernel, dim3(bx, q.n_frames), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                               (float2*)y, partial, T, L, q.frames, gstride);
+            const int nfb = fir_blocks(q.n_frames * bx, pcap);
+            hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
+                               (float2*)y, partial, T, L, q.frames, gstride, q.n_frames, pbase);
             DCCN_LAUNCH_CHECK();
+            pbase += nfb;
         } else {
             hipLaunchKernelGGL(doppler_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, theta_in, q.coeff, q.alpha, (float2*)g,
                                (float2*)H, q.n_taps, q.L, nfft, S, q.Fd, t_sym, offset, seed, q.frames, 16, gstride);
             DCCN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(fir_doppler_kernel, dim3(bx, q.n_frames), dim3(256), 0, s, (const float2*)tx,
-                               (const float2*)g, (float2*)y, partial, T, q.L, n_sc, q.n_taps, q.frames, gstride);
+            const int nfb = fir_blocks(q.n_frames * bx, pcap);
+            hipLaunchKernelGGL(fir_doppler_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx,
+                               (const float2*)g, (float2*)y, partial, T, q.L, n_sc, q.n_taps, q.frames, gstride, q.n_frames, pbase);
             DCCN_LAUNCH_CHECK();
+            pbase += nfb;
         }
     }
     const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * bx, total,
-                       mean_power);
-    DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const float*)mean_power, snr_db,
-                       noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
+    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, pbase, total,
+                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
     DCCN_LAUNCH_CHECK();
     if (noise_power) {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,

@@ -60,7 +60,7 @@ static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool t
     const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
     w.n_norm = norm_ws_bytes(d.B, d.S * d.nsc * 2);
     w.n_tail = tail_ws_bytes((long long)d.B * d.D, sh->nbits);
-    if (sh->nbits <= 2) {
+    {
         const size_t f = dense_tail_ws_bytes(d.B, 2 * d.D, sh->nbits);
         if (f > w.n_tail) w.n_tail = f;
     }
@@ -193,7 +193,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
     // frozen basic receiver (model.py:1222-1292) + loss/BER
     DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
-    if (dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
+    if (dense_tail_planned(sh->nbits, train) &&
+        dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
         DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
                                  b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, L.dK, L.dN, sh->nbits,
                                  &pp, b->tx_power, w.ws_tail, w.n_tail, s));

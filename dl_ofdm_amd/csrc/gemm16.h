@@ -240,8 +240,31 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
     // EPI_TAIL: the label bits of this lane's cells are requested before the k-loop (no exposed latency afterwards).
     // Cell (tile a,b ; c): row 4*kg + (odd ? 2+c : c) of the tile, data cell col/2; KS == 2: set s owns c == s.
     constexpr int NCELL = (EPI == EPI_TAIL) ? TM * TN * 2 / KS : 1;
-    int labs[NCELL][NB];
-    if constexpr (EPI == EPI_TAIL) {
+    // NB >= 3: the tail does not run on the MFMA register layout (90 / 200 gradient accumulators per cell-lane leave no
+    // room for it): the finished tile goes through LDS and the block walks its BM x BN/2 cells like the stand-alone
+    // tail kernels do -- a lane per cell (8-QAM, 16-QAM evaluation) or a quad of lanes per cell (16-QAM training,
+    // tail.h tail_quad4_cell).  Each thread requests the label bits of CPT cells (cell c = tid + NT i of the tile, row
+    // major) before the k-loop and keeps them packed, one int per cell.
+    constexpr bool TAIL_LDS = (EPI == EPI_TAIL) && NB >= 3;
+    constexpr bool QUAD4 = TAIL_LDS && NB == 4 && BWD;
+    static_assert(!TAIL_LDS || KS == 1, "LDS-staged tail: one wave set");
+    constexpr int TCELLS = BM * (BN / 2);
+    constexpr int CPT = TAIL_LDS ? (TCELLS + NT - 1) / NT : 1;
+    int plab[CPT];
+    if constexpr (TAIL_LDS) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = min(tid + NT * i, TCELLS - 1);
+            const int row = min(m0 + c / (BN / 2), p.M - 1), dc = min((n0 >> 1) + c % (BN / 2), (p.N >> 1) - 1);
+            const int32_t* lb = tp.bits + ((long long)row * (p.N >> 1) + dc) * NB;
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v |= (lb[j] != 0 ? 1 : 0) << j;
+            plab[i] = v;
+        }
+    }
+    int labs[NCELL][NB];                                 // lane-cell labels of the register-layout tail (NB <= 2)
+    if constexpr (EPI == EPI_TAIL && !TAIL_LDS) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -482,6 +505,79 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
         // lane's two.  Either way a lane ends up with TM*TN*2/KS cells.
         const int odd = lane & 1;
         const int Dn = p.N >> 1;                           // cells per row
+        if constexpr (TAIL_LDS) {
+            // ---- tile -> LDS, then the tail over the tile's cells (see the label prefetch above) ----
+            constexpr int PW = tail_param_count(NB);
+            constexpr int ZS = BN + 2;                          // row stride of the staged tile (even: float2 reads)
+            float* zt = smem;                                   // [BM][ZS]
+            int* lt = reinterpret_cast<int*>(smem + BM * ZS);   // [TCELLS] packed label bits
+            float* swl = smem + BM * ZS + TCELLS;               // [PW] tail weights (90 / 200 do not fit the SGPR file)
+            float* red = swl + ((PW + 3) & ~3);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int col = n0 + wn0 + b * 16 + l15;
+                    const float bj = bjv[b];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[a][b][r] + bj;
+                        const int rl = wm0 + a * 16 + 4 * kg + r;
+                        zt[rl * ZS + wn0 + b * 16 + l15] = v;
+                        if (p.C != nullptr && m0 + rl < p.M && col < p.N) p.C[(size_t)(m0 + rl) * p.ldc + col] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                if (tid + NT * i < TCELLS) lt[tid + NT * i] = plab[i];
+            for (int i = tid; i < PW; i += NT) swl[i] = tp.tailp[i];
+            __syncthreads();
+            if constexpr (QUAD4) {
+                const int q = lane & 3;
+                TailQuad4W W;
+                W.load(swl, q);                                  // this lane's 92 weights: registers for the whole loop
+                TailQuad4Acc A;
+                A.clear();
+                for (int c = tid >> 2; c < TCELLS; c += NT / 4) {
+                    const int rl = c / (BN / 2), dl = c % (BN / 2);
+                    const int row = m0 + rl, dcol = (n0 >> 1) + dl;
+                    const bool ok = row < p.M && dcol < Dn;
+                    const float2 zv = *reinterpret_cast<const float2*>(zt + rl * ZS + 2 * dl);
+                    const long long cell = (long long)min(row, p.M - 1) * Dn + min(dcol, Dn - 1);
+                    float* pq = (tp.prob != nullptr && ok) ? tp.prob + (cell * NB + q) * 2 : nullptr;
+                    const float2 d = tail_quad4_cell(zv.x, zv.y, (lt[c] >> q) & 1, ok, W, tp.inv_count, pq, q, A);
+                    if (q == 0 && ok) *reinterpret_cast<float2*>(tp.dz + cell * 2) = d;
+                }
+                tail_quad4_block_reduce<NT>(A, red, tp.blk_metrics, tp.blk_grads, slab);
+            } else {
+                TailLaneAcc<NB, BWD> A;
+                A.clear();
+                for (int c = tid; c < TCELLS; c += NT) {
+                    asm volatile("" ::: "memory");
+                    const int rl = c / (BN / 2), dl = c % (BN / 2);
+                    const int row = m0 + rl, dcol = (n0 >> 1) + dl;
+                    const float2 zv = *reinterpret_cast<const float2*>(zt + rl * ZS + 2 * dl);
+                    const int pk = lt[c];
+                    const float a0[1] = {zv.x}, a1[1] = {zv.y};
+                    int lb[1][NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) lb[0][j] = (pk >> j) & 1;
+                    const bool vd[1] = {row < p.M && dcol < Dn};
+                    const long long cell = (long long)min(row, p.M - 1) * Dn + min(dcol, Dn - 1);
+                    float* const pc[1] = {(tp.prob != nullptr && vd[0]) ? tp.prob + cell * NB * 2 : nullptr};
+                    float2 dv[1];
+                    tail_cells<NB, BWD, 1>(a0, a1, lb, vd, swl, tp.inv_count, pc, A, dv);
+                    if constexpr (BWD) {
+                        if (vd[0]) *reinterpret_cast<float2*>(tp.dz + cell * 2) = dv[0];
+                    }
+                }
+                tail_block_reduce<NB, BWD, NT>(A, red, tp.blk_metrics, tp.blk_grads, slab);
+            }
+            return;
+        }
+        const float* __restrict__ sw = tp.tailp;
+        float* red = smem + (KS > 1 ? (int)(CF::xchg_bytes / sizeof(float)) : 0);
         TailLaneAcc<NB, BWD> A;
         A.clear();
         float cz0[NCELL], cz1[NCELL];
@@ -561,7 +657,7 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
             constexpr int TW = NCELL <= 8 ? NCELL : (NCELL % 8 == 0 ? 8 : (NCELL % 6 == 0 ? 6 : (NCELL % 5 == 0 ? 5 : 4)));
             static_assert(NCELL % TW == 0, "tail batches");
             if constexpr (TW == NCELL) {
-                tail_cells<NB, BWD, NCELL>(cz0, cz1, labs, cvalid, tp.tailp, tp.inv_count, cprob, A, cdzv);
+                tail_cells<NB, BWD, NCELL>(cz0, cz1, labs, cvalid, sw, tp.inv_count, cprob, A, cdzv);
             } else {
 #pragma unroll
                 for (int g0 = 0; g0 < NCELL; g0 += TW) {
@@ -576,7 +672,7 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
 #pragma unroll
                         for (int j = 0; j < NB; ++j) lb[u][j] = labs[g0 + u][j];
                     }
-                    tail_cells<NB, BWD, TW>(a0, a1, lb, vd, tp.tailp, tp.inv_count, pc, A, dv);
+                    tail_cells<NB, BWD, TW>(a0, a1, lb, vd, sw, tp.inv_count, pc, A, dv);
 #pragma unroll
                     for (int u = 0; u < TW; ++u) cdzv[g0 + u] = dv[u];
                 }
@@ -587,7 +683,6 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
             for (int ci = 0; ci < NCELL; ++ci)
                 if (cvalid[ci]) *reinterpret_cast<float2*>(cdz[ci]) = cdzv[ci];
         }
-        float* red = smem + (KS > 1 ? (int)(CF::xchg_bytes / sizeof(float)) : 0);
         // (KS == 1: the k-loop ended with a barrier, nobody reads the tile buffers any more; KS > 1: red lies behind the
         // exchange region, which is only read above)
         tail_block_reduce<NB, BWD, NT>(A, red, tp.blk_metrics, tp.blk_grads, slab);
@@ -657,7 +752,10 @@ template <int WGM, int WGN, int TM, int TN, int BK, int KS, int NB, bool BWD, in
 static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hipStream_t s, size_t smem_min = 0) {
     using CF = Cfg16<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS>;
     auto kern = gemm16_kernel<OP_KCONTIG, OP_ICONTIG, WGM, WGN, TM, TN, BK, KS, 0, EPI_TAIL, NB, BWD, TAG_DENSE_FWD, PD>;
-    size_t smem = CF::smem_bytes(tail_reduce_lds_floats<NB, BWD>(CF::NT));
+    // after the k-loop: NB >= 3: [staged tile][packed labels][tail weights] + the block reduction's scratch
+    constexpr int wfl = NB >= 3 ? CF::BM * (CF::BN + 2) + CF::BM * (CF::BN / 2) + ((tail_param_count(NB) + 3) & ~3) : 0;
+    constexpr int rfl = (NB == 4 && BWD) ? tail_quad4_lds_floats(CF::NT) : tail_reduce_lds_floats<NB, BWD>(CF::NT);
+    size_t smem = CF::smem_bytes(wfl + rfl);
     if (smem < smem_min) smem = smem_min;
     DCCN_TRY(set_smem_attr(kern, smem));
     dim3 grid(ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), 1, 1);

@@ -48,6 +48,17 @@ struct GemmParams {
     int cF;              // F of the cconv operand kinds
     int vecA, vecB;      // vector (16 B) global loads legal for the operand
     int cbias;           // 1: bias is the C-Conv [ba|bb] pair -> col 2f: ba-bb, col 2f+1: bb-ba
+    // k-major weight gradients only: nranges > 0 = split z covers rows [koff[z], koff[z+1]) instead of z*klen ...
+    // (graded ranges: long items first, short ones last, so that the grid's tail is made of short items)
+    int nranges;
+    int koff[9];
+    // optional optimizer epilogue (an UNSPLIT weight gradient of a large layer: the stored tile is the gradient of
+    // ad_p[row*ldc + col]): the TF-Adam update of norm_adam.h, same operations in the same order, applied to the tile while
+    // it is in registers -- the gradient needs no round trip through HBM and the optimizer launch skips the segment.
+    float* ad_p; float* ad_m; float* ad_v;
+    const float* ad_reg; const float* ad_gate;
+    const dccn_adam_state* ad_state;
+    float ad_omb1, ad_omb2, ad_eps;
 };
 
 constexpr int kGemmThreads = 256;
@@ -430,7 +441,25 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, con
                     bj = p.bias[col];
                 }
             }
-            if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
+            if (p.ad_p != nullptr) {                           // (kernel argument: uniform) optimizer epilogue
+                const float alpha = p.ad_state->alpha;
+                const float gate = p.ad_gate ? p.ad_gate[0] : 1.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < p.M && col < p.N) {
+                        const size_t i = (size_t)row * p.ldc + col;
+                        const float g = acc[a][b][r] + bj;
+                        if (p.C != nullptr) Cz[i] = g;
+                        float pp = p.ad_p[i], mm = p.ad_m[i], vv = p.ad_v[i];
+                        const float ge = g + (gate * (p.ad_reg ? p.ad_reg[i] : 0.f)) * pp;
+                        mm += (ge - mm) * p.ad_omb1;
+                        vv += (ge * ge - vv) * p.ad_omb2;
+                        pp -= (mm * alpha) / (sqrtf(vv) + p.ad_eps);
+                        p.ad_p[i] = pp; p.ad_m[i] = mm; p.ad_v[i] = vv;
+                    }
+                }
+            } else if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
                 float* Cc = Cz + (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Cc[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[a][b][r] + bj;
@@ -666,14 +695,21 @@ static int launch_splitk_reduce2(const float* pa, int splits, long long slab_a, 
 // tilew > 0: the slabs are stored as column tiles of width tilew (the dX-epilogue partials of rx_bwd.h: term z, column
 // tile h at partial + (z*nh + h)*2kin*tilew, rows of tilew floats; colsum [z*nh + h][tilew]); `slab` is then the
 // distance between consecutive terms (nh tiles).  tilew == 0: full-width [2kin, 2F] slabs (split-K GEMM output).
+// LANES element-lanes x 256/LANES term groups per block: 64 x 4 for the split-K slabs (<= 128 terms of a few MB each:
+// few, long rows), 16 x 16 for the dX-epilogue partials (133 short terms per element: with four groups a thread walked
+// five dependent batches of loads and the fold was the long pole of the optimizer launch, 10 us; with sixteen it is one
+// batch + one short one)
+constexpr int kFoldLanesTiled = 16;
+template <int LANES = kRedLanes>
 __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partial, int splits, long long slab,
                                                 const float* __restrict__ colsum, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int kin, int F, int block,
                                                 long long* out2 = nullptr, float* gout = nullptr, int tilew = 0) {
     if (out2) { out2[0] = -1; out2[1] = -1; }
-    __shared__ float2 red[kRedGroups][kRedLanes];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int e = block * kRedLanes + lane;
+    constexpr int GROUPS = 256 / LANES;
+    __shared__ float2 red[GROUPS][LANES];
+    const int lane = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+    const int e = block * LANES + lane;
     const int total = kin * F, N2 = 2 * F;
     const bool is_w = e < total, is_b = (!is_w) && (e < total + F) && (dbias != nullptr);
     const int n = is_w ? e / F : 0, f = is_w ? e % F : (e - total);
@@ -684,18 +720,18 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     const size_t coff = tilew > 0 ? (size_t)((2 * f) / tilew) * tilew + (2 * f) % tilew : (size_t)(2 * f);
     const size_t cstride = tilew > 0 ? (size_t)(N2 / tilew) * tilew : (size_t)N2;
     if (is_w) {
-        for (int zb = grp; zb < splits; zb += 8 * kRedGroups) {
+        for (int zb = grp; zb < splits; zb += 8 * GROUPS) {
             float2 top[8], bot[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float* P = partial + (size_t)min(zb + u * kRedGroups, splits - 1) * slab + eoff;
+                const float* P = partial + (size_t)min(zb + u * GROUPS, splits - 1) * slab + eoff;
                 top[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * ld);
                 bot[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * ld);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (zb + u * kRedGroups < splits) {
+                if (zb + u * GROUPS < splits) {
                     a += top[u].x - bot[u].y;
                     b += top[u].y - bot[u].x;
                 }
@@ -703,7 +739,7 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
         }
     } else if (is_b) {
 #pragma unroll 8
-        for (int z = grp; z < splits; z += kRedGroups) {
+        for (int z = grp; z < splits; z += GROUPS) {
             const float2 c = *reinterpret_cast<const float2*>(colsum + (size_t)z * cstride + coff);
             a += c.x - c.y;
         }
@@ -713,7 +749,7 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     if (grp == 0) {
         float2 t = red[0][lane];
 #pragma unroll
-        for (int g = 1; g < kRedGroups; ++g) { t.x += red[g][lane].x; t.y += red[g][lane].y; }
+        for (int g = 1; g < GROUPS; ++g) { t.x += red[g][lane].x; t.y += red[g][lane].y; }
         if (is_w) {
             dw[(size_t)n * N2 + f] = t.x;
             dw[(size_t)n * N2 + F + f] = t.y;
@@ -730,7 +766,8 @@ __global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict
                                                          long long slab, const float* __restrict__ colsum,
                                                          float* __restrict__ dw, float* __restrict__ dbias,
                                                          int kin, int F, int tilew = 0) {
-    cconv_fold_body(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x, nullptr, nullptr, tilew);
+    if (tilew > 0) cconv_fold_body<kFoldLanesTiled>(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x, nullptr, nullptr, tilew);
+    else cconv_fold_body<kRedLanes>(partial, splits, slab, colsum, dw, dbias, kin, F, blockIdx.x, nullptr, nullptr, 0);
 }
 
 }  // namespace dccn

@@ -44,8 +44,8 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
     const int ntn = (p.N + BT - 1) / BT;
     const int tile = xcd_tile(L, T);
     const int m0 = (tile / ntn) * BT, n0 = (tile % ntn) * BT;
-    const int kbeg = z * p.klen;
-    const int kend = min(p.K, kbeg + p.klen);
+    const int kbeg = p.nranges > 0 ? p.koff[z] : z * p.klen;
+    const int kend = p.nranges > 0 ? p.koff[z + 1] : min(p.K, kbeg + p.klen);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
 

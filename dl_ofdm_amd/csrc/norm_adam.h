@@ -467,44 +467,80 @@ struct AdamRxArgs {
     const float* nx; float* ny; double* npower;
     int nbatch, ncols, norm_blocks;
     float neps, npeak;
+    // [skip_lo, skip_hi): elements whose update already happened in the epilogue of their weight-gradient GEMM
+    long long skip_lo, skip_hi;
 };
 
+// C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here.
+// PUBLISH: the updated parameters are handed to other workgroups of the SAME launch (the C-Conv forward of the next
+// batch, rx_update_prefetch_kernel): write-through (agent-scope relaxed atomic = sc1) stores, every wave drains its
+// stores, one lane bumps the arrival counter (cdna_hip_programming.md Guideline 16, recipe R1).
+// Hand-off words: ONE arrival counter for the producers; the last arriver fans the news out to one flag word per
+// consumer block, 256 bytes apart (256 blocks polling one address serialise on that address's memory channel: measured
+// 37 us for the launch instead of 13).  Flag value = the step's epoch (bits of the advanced global_step), so the flags
+// never need clearing; the counter is reset by the backward launch of the same step.
+struct HandoffWords {
+    unsigned* counter;
+    unsigned* flags;        // [n_flags] at a stride of kFlagStride words
+    unsigned expected;      // producers
+    int n_flags;
+};
+constexpr int kFlagStride = 64;
+template <bool PUBLISH>
+__device__ __forceinline__ void adam_fold_role(const AdamRxArgs& a, const dccn_adam_hparams& hp, const int bx,
+                                               const HandoffWords hw) {
+    const float alpha = a.state->alpha;
+    const float gate = a.reg_gate ? a.reg_gate[0] : 1.0f;
+    const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
+    long long idx[2];
+    float gv[2];
+    if (a.cw_tilew > 0)
+        cconv_fold_body<kFoldLanesTiled>(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
+                                         a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv, a.cw_tilew);
+    else
+        cconv_fold_body<kRedLanes>(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
+                                   a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (idx[e] < 0) continue;
+        const long long j = a.o_cw + idx[e];
+        float p = a.param[j], mm = a.m[j], vv = a.v[j];
+        const float ge = gv[e] + (gate * (a.reg_coef ? a.reg_coef[j] : 0.f)) * p;
+        mm += (ge - mm) * omb1;
+        vv += (ge * ge - vv) * omb2;
+        p -= (mm * alpha) / (sqrtf(vv) + hp.eps);
+        if constexpr (PUBLISH) __hip_atomic_store(a.param + j, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.param[j] = p;
+        a.m[j] = mm; a.v[j] = vv;
+    }
+    if constexpr (PUBLISH) {
+        __shared__ unsigned s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(hw.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hw.expected - 1u ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {
+            // every producer drained before it counted itself in: all parameters are at the coherence point now
+            const unsigned epoch = __builtin_bit_cast(unsigned, a.state->global_step);
+            for (int i = threadIdx.x; i < hw.n_flags; i += blockDim.x)
+                __hip_atomic_store(hw.flags + (size_t)i * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the rest of the arena (dense kernel / bias with their split-K slabs, tail weights): block bx of nbx streams it
 template <int SPLITS>     // 0: runtime count
-__global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const dccn_adam_hparams hp) {
+__device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn_adam_hparams& hp, const int bx, const int nbx) {
     const float alpha = a.state->alpha;
     const float gate = a.reg_gate ? a.reg_gate[0] : 1.0f;
     const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
     const bool seg4 = ((a.o_dw | a.n_dw | a.o_db | a.n_db) & 3) == 0;
     const int splits = SPLITS > 0 ? SPLITS : a.splits;
-    if ((int)blockIdx.x < a.norm_blocks) {
-        norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, a.neps, a.npeak, a.npower, nullptr, nullptr,
-                                           nullptr, hp, (int)blockIdx.x, a.norm_blocks);
-        return;
-    }
-    const int bx = (int)blockIdx.x - a.norm_blocks, nbx = (int)gridDim.x - a.norm_blocks;
-    if (bx < a.fold_blocks) {
-        // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here
-        long long idx[2];
-        float gv[2];
-        cconv_fold_body(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
-                        a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv, a.cw_tilew);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (idx[e] < 0) continue;
-            const long long j = a.o_cw + idx[e];
-            float p = a.param[j], mm = a.m[j], vv = a.v[j];
-            const float ge = gv[e] + (gate * (a.reg_coef ? a.reg_coef[j] : 0.f)) * p;
-            mm += (ge - mm) * omb1;
-            vv += (ge * ge - vv) * omb2;
-            p -= (mm * alpha) / (sqrtf(vv) + hp.eps);
-            a.param[j] = p; a.m[j] = mm; a.v[j] = vv;
-        }
-        return;
-    }
     const long long first = a.fold_blocks > 0 ? a.n_conv : 0;
-    const long long stride = (long long)(nbx - a.fold_blocks) * blockDim.x * 4;
-    for (long long i = first + ((long long)(bx - a.fold_blocks) * blockDim.x + threadIdx.x) * 4; i < a.n;
-         i += stride) {
+    const long long stride = (long long)nbx * blockDim.x * 4;
+    for (long long i = first + ((long long)bx * blockDim.x + threadIdx.x) * 4; i < a.n; i += stride) {
+        if (i >= a.skip_lo && i + 4 <= a.skip_hi) continue;       // (segment bounds are multiples of 4)
         const int cnt = (int)((a.n - i) < 4 ? (a.n - i) : 4);
         float g[4] = {0.f, 0.f, 0.f, 0.f}, p[4], mm[4], vv[4], cc[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = cnt == 4;
@@ -584,6 +620,21 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
             for (int e = 0; e < cnt; ++e) { a.param[i + e] = p[e]; a.m[i + e] = mm[e]; a.v[i + e] = vv[e]; }
         }
     }
+}
+
+template <int SPLITS>     // 0: runtime count
+__global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const dccn_adam_hparams hp) {
+    if ((int)blockIdx.x < a.norm_blocks) {
+        norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, a.neps, a.npeak, a.npower, nullptr, nullptr,
+                                           nullptr, hp, (int)blockIdx.x, a.norm_blocks);
+        return;
+    }
+    const int bx = (int)blockIdx.x - a.norm_blocks, nbx = (int)gridDim.x - a.norm_blocks;
+    if (bx < a.fold_blocks) {
+        adam_fold_role<false>(a, hp, bx, HandoffWords{nullptr, nullptr, 0u, 0});
+        return;
+    }
+    adam_stream_role<SPLITS>(a, hp, bx - a.fold_blocks, nbx - a.fold_blocks);
 }
 
 }  // namespace dccn

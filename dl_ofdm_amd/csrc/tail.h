@@ -396,152 +396,208 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
 // 50 accumulators per lane.  What a lane does not own it gets from its quad on the DPP crossbar (the backward into
 // the 18 concatenated features and the two dz sums).  The forward uses the same operations in the same order as
 // demod_tail_kernel, so training and evaluation probabilities stay bit-identical.
+// Shared by demod_tail_quad4_kernel (z from memory) and the fused dense-forward epilogue (gemm16.h: z from the
+// accumulators of the quad's lanes).
+struct TailQuad4Acc {
+    static constexpr int M = 16, O = 8;
+    float g2[M + 2][2], gb2[2], gw1a[4], gw1b[4], gb1[4];
+    double ce;
+    int c00, c01, c10, c11;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i) g2[i][0] = g2[i][1] = 0.f;
+        gb2[0] = gb2[1] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gw1a[u] = gw1b[u] = gb1[u] = 0.f;
+        ce = 0.0;
+        c00 = c01 = c10 = c11 = 0;
+    }
+};
+// the tail weights a lane of the quad form needs, in registers for the whole cell loop (92 values: the 1x1 conv and its
+// bias, this lane's two columns of dense_1 and their bias, the conv rows of its four hidden units) -- re-reading them from
+// LDS for every cell (~80 broadcast reads, each a full LDS latency for the single wave of a SIMD) was most of a cell's time
+struct TailQuad4W {
+    static constexpr int M = 16, O = 8;
+    float w1a[M], w1b[M], b1[M];
+    float w2[M + 2][2], b2[2];
+    float own_a[4], own_b[4];
+    __device__ __forceinline__ void load(const float* __restrict__ sw, const int q) {
+        constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
+#pragma unroll
+        for (int j = 0; j < M; ++j) { w1a[j] = sw[oW1 + j]; w1b[j] = sw[oW1 + M + j]; b1[j] = sw[oB1 + j]; }
+#pragma unroll
+        for (int i = 0; i < M + 2; ++i) { w2[i][0] = sw[oW2 + i * O + 2 * q]; w2[i][1] = sw[oW2 + i * O + 2 * q + 1]; }
+        b2[0] = sw[oB2 + 2 * q];
+        b2[1] = sw[oB2 + 2 * q + 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { own_a[u] = sw[oW1 + 4 * q + u]; own_b[u] = sw[oW1 + M + 4 * q + u]; }
+    }
+};
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
+    v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
+    return v;
+}
+constexpr int tail_quad4_lds_floats(int nt) { return (nt / 4) * (tail_param_count(4) | 1) + (nt / 64) * 2 + (nt / 64) * 4 + 2; }
+
+// one cell through R3-R6 and back on a quad of lanes: (z0, z1) and `valid` are quad-uniform, `label` is bit q of the
+// cell, swl the tail weights in LDS, prob_q (nullable) this lane's float2 of `output`; returns dz of the cell (quad-uniform)
+__device__ __forceinline__ float2 tail_quad4_cell(const float z0, const float z1, const int label, const bool valid,
+                                                  const TailQuad4W& W, const float inv_count,
+                                                  float* __restrict__ prob_q, const int q, TailQuad4Acc& A) {
+    constexpr int M = 16;
+    auto pick4 = [&](const float* a, int u) {           // a[4*q + u] without dynamic register indexing
+        return q == 0 ? a[u] : (q == 1 ? a[4 + u] : (q == 2 ? a[8 + u] : a[12 + u]));
+    };
+    float c[M + 2], pre1[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        pre1[j] = __builtin_fmaf(z1, W.w1b[j], __builtin_fmaf(z0, W.w1a[j], W.b1[j]));   // as tail_cells
+        c[j] = leaky_relu(pre1[j]);
+    }
+    c[M] = z0;
+    c[M + 1] = z1;
+    float s0 = W.b2[0], s1 = W.b2[1];                // this lane's two columns of dense_1
+#pragma unroll
+    for (int i = 0; i < M + 2; ++i) {
+        s0 = __builtin_fmaf(c[i], W.w2[i][0], s0);
+        s1 = __builtin_fmaf(c[i], W.w2[i][1], s1);
+    }
+    const float p20 = s0, p21 = s1;
+    const float u0 = leaky_relu(p20), u1 = leaky_relu(p21);
+    const bool u1_big = u1 > u0;
+    const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
+    const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
+    const float res = rcp_fast(e0 + e1);
+    const float p0 = e0 * res, p1 = e1 * res;
+    if (prob_q != nullptr) *reinterpret_cast<float2*>(prob_q) = make_float2(p0, p1);
+    const bool p1_big = p1 > p0;
+    const float mx2 = p1_big ? p1 : p0;
+    const float fo = exp_nonpos(p1_big ? (p0 - p1) : (p1 - p0));
+    const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
+    const float fs = f0 + f1;
+    const float lse = log_1_2(fs) + mx2;
+    const float ce = lse - (label ? p1 : p0);
+    A.ce += (double)(valid ? ce : 0.f);
+    const int pred = (p1 > p0) ? 1 : 0;
+    const int l1 = label != 0 ? 1 : 0;
+    const int vb = valid ? 1 : 0;
+    A.c00 += (1 - l1) & (1 - pred) & vb;
+    A.c01 += (1 - l1) & pred & vb;
+    A.c10 += l1 & (1 - pred) & vb;
+    A.c11 += l1 & pred & vb;
+    // backward of this lane's bit
+    const float inv_eff = valid ? inv_count : 0.f;
+    const float rfs = rcp_fast(fs);
+    const float q0 = f0 * rfs, q1 = f1 * rfs;
+    const float ga = (q0 - (label ? 0.f : 1.f)) * inv_eff;
+    const float gb = (q1 - (label ? 1.f : 0.f)) * inv_eff;
+    const float dot = ga * p0 + gb * p1;
+    const float du0 = p0 * (ga - dot), du1 = p1 * (gb - dot);
+    const float d20 = du0 * (p20 > 0.f ? 1.f : kLeaky), d21 = du1 * (p21 > 0.f ? 1.f : kLeaky);
+    A.gb2[0] += d20;
+    A.gb2[1] += d21;
+    float dc[M + 2];
+#pragma unroll
+    for (int i = 0; i < M + 2; ++i) {
+        A.g2[i][0] = __builtin_fmaf(c[i], d20, A.g2[i][0]);
+        A.g2[i][1] = __builtin_fmaf(c[i], d21, A.g2[i][1]);
+        dc[i] = quad_sum(__builtin_fmaf(d21, W.w2[i][1], d20 * W.w2[i][0]));      // all four bits' contributions
+    }
+    float d0p = 0.f, d1p = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                    // hidden units 4q .. 4q+3
+        const float dp = pick4(dc, u) * (pick4(pre1, u) > 0.f ? 1.f : kLeaky);
+        A.gw1a[u] = __builtin_fmaf(z0, dp, A.gw1a[u]);
+        A.gw1b[u] = __builtin_fmaf(z1, dp, A.gw1b[u]);
+        A.gb1[u] += dp;
+        d0p = __builtin_fmaf(dp, W.own_a[u], d0p);
+        d1p = __builtin_fmaf(dp, W.own_b[u], d1p);
+    }
+    return make_float2(dc[M] + quad_sum(d0p), dc[M + 1] + quad_sum(d1p));
+}
+
+// block reduction of the quad-lane accumulators: every quad row of the LDS matrix gets each parameter column from the
+// lane that owns it; lds holds tail_quad4_lds_floats(NT) floats (8-byte aligned).  Starts with no barrier of its own:
+// the caller must have finished with `lds`; ends without one.
+template <int NT>
+__device__ __forceinline__ void tail_quad4_block_reduce(TailQuad4Acc& A, float* __restrict__ lds,
+                                                        TailBlockMetrics* __restrict__ blk_metrics,
+                                                        float* __restrict__ blk_grads, const int slab) {
+    constexpr int M = 16, O = 8, P = tail_param_count(4);
+    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
+    constexpr int PS = P | 1, NW = NT / 64, NQ = NT / 4;
+    double* sce = reinterpret_cast<double*>(lds);              // [NW]
+    int* sconf = reinterpret_cast<int*>(lds + 2 * NW);         // [NW][4]
+    float* smat = lds + 2 * NW + 4 * NW + 2;                   // [NQ][PS]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, q = threadIdx.x & 3;
+    const double ce = wave_sum(A.ce);
+    const int c00 = wave_sum(A.c00), c01 = wave_sum(A.c01), c10 = wave_sum(A.c10), c11 = wave_sum(A.c11);
+    if (lane == 0) {
+        sce[wid] = ce;
+        sconf[wid * 4 + 0] = c00; sconf[wid * 4 + 1] = c01; sconf[wid * 4 + 2] = c10; sconf[wid * 4 + 3] = c11;
+    }
+    float* row = smat + (threadIdx.x >> 2) * PS;
+#pragma unroll
+    for (int i = 0; i < M + 2; ++i) {
+        row[oW2 + i * O + 2 * q] = A.g2[i][0];
+        row[oW2 + i * O + 2 * q + 1] = A.g2[i][1];
+    }
+    row[oB2 + 2 * q] = A.gb2[0];
+    row[oB2 + 2 * q + 1] = A.gb2[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        row[oW1 + 4 * q + u] = A.gw1a[u];
+        row[oW1 + M + 4 * q + u] = A.gw1b[u];
+        row[oB1 + 4 * q + u] = A.gb1[u];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TailBlockMetrics bm;
+        double t = 0.0;
+        for (int w = 0; w < NW; w += 4) t += (sce[w] + sce[w + 1]) + (sce[w + 2] + sce[w + 3]);
+        bm.ce_sum = t;
+        for (int k = 0; k < 4; ++k) {
+            long long c = 0;
+            for (int w = 0; w < NW; ++w) c += sconf[w * 4 + k];
+            bm.conf[k] = c;
+        }
+        blk_metrics[slab] = bm;
+    }
+    const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
+    for (int col0 = 0; col0 < P; col0 += NQ) {
+        const int col = col0 + slot;
+        const int cc = col < P ? col : P - 1;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < NQ / 4; ++r) v += smat[(part * (NQ / 4) + r) * PS + cc];
+        v = quad_sum(v);
+        if (part == 0 && col < P) blk_grads[(size_t)slab * P + col] = v;
+    }
+}
+
 template <bool WRITE_PROB>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
     const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
     float* __restrict__ prob, float* __restrict__ dz, long long cells,
     TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
-    constexpr int NB = 4, M = 16, O = 8, P = tail_param_count(4);
-    constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
-    constexpr int PS = P | 1;
-    __shared__ float smat[64 * PS];
-    __shared__ float swl[P];
-    __shared__ double sce[4];
-    __shared__ int sconf[4][4];
-    for (int i = threadIdx.x; i < P; i += kTailThreads) swl[i] = tailp[i];
-    __syncthreads();
+    constexpr int NB = 4;
+    __shared__ __attribute__((aligned(8))) float sred[tail_quad4_lds_floats(kTailThreads)];
     const int q = threadIdx.x & 3;
-    auto quad_sum = [](float v) {
-        v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
-        v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
-        return v;
-    };
-    auto pick4 = [&](const float* a, int u) {           // a[4*q + u] without dynamic register indexing
-        return q == 0 ? a[u] : (q == 1 ? a[4 + u] : (q == 2 ? a[8 + u] : a[12 + u]));
-    };
-    float g2[M + 2][2], gb2[2] = {0.f, 0.f}, gw1a[4], gw1b[4], gb1[4];
-#pragma unroll
-    for (int i = 0; i < M + 2; ++i) g2[i][0] = g2[i][1] = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gw1a[u] = gw1b[u] = gb1[u] = 0.f;
-    double ce_acc = 0.0;
-    int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    TailQuad4W W;
+    W.load(tailp, q);
+    TailQuad4Acc A;
+    A.clear();
     const float inv_count = 1.0f / (float)(cells * NB);
     const long long stride = (long long)gridDim.x * (kTailThreads / 4);
     for (long long cell = (long long)blockIdx.x * (kTailThreads / 4) + (threadIdx.x >> 2); cell < cells; cell += stride) {
-        asm volatile("" ::: "memory");                   // keep the LDS weight reads inside the loop
         const float2 zv = *reinterpret_cast<const float2*>(z + 2 * cell);
         const int label = bits[cell * NB + q];
-        const float z0 = zv.x, z1 = zv.y;
-        float c[M + 2], pre1[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            pre1[j] = __builtin_fmaf(z1, swl[oW1 + M + j], __builtin_fmaf(z0, swl[oW1 + j], swl[oB1 + j]));   // as tail_cells
-            c[j] = leaky_relu(pre1[j]);
-        }
-        c[M] = z0;
-        c[M + 1] = z1;
-        float w2[M + 2][2];                              // this lane's two columns of dense_1
-        float s0 = swl[oB2 + 2 * q], s1 = swl[oB2 + 2 * q + 1];
-#pragma unroll
-        for (int i = 0; i < M + 2; ++i) {
-            const float2 w = *reinterpret_cast<const float2*>(swl + oW2 + i * O + 2 * q);
-            w2[i][0] = w.x;
-            w2[i][1] = w.y;
-            s0 = __builtin_fmaf(c[i], w.x, s0);
-            s1 = __builtin_fmaf(c[i], w.y, s1);
-        }
-        const float p20 = s0, p21 = s1;
-        const float u0 = leaky_relu(p20), u1 = leaky_relu(p21);
-        const bool u1_big = u1 > u0;
-        const float eo = exp_nonpos(u1_big ? (u0 - u1) : (u1 - u0));
-        const float e0 = u1_big ? eo : 1.0f, e1 = u1_big ? 1.0f : eo;
-        const float res = rcp_fast(e0 + e1);
-        const float p0 = e0 * res, p1 = e1 * res;
-        if (WRITE_PROB) *reinterpret_cast<float2*>(prob + (cell * NB + q) * 2) = make_float2(p0, p1);
-        const bool p1_big = p1 > p0;
-        const float mx2 = p1_big ? p1 : p0;
-        const float fo = exp_nonpos(p1_big ? (p0 - p1) : (p1 - p0));
-        const float f0 = p1_big ? fo : 1.0f, f1 = p1_big ? 1.0f : fo;
-        const float fs = f0 + f1;
-        const float lse = log_1_2(fs) + mx2;
-        ce_acc += (double)(lse - (label ? p1 : p0));
-        const int pred = (p1 > p0) ? 1 : 0;
-        const int l1 = label != 0 ? 1 : 0;
-        c00 += (1 - l1) & (1 - pred);
-        c01 += (1 - l1) & pred;
-        c10 += l1 & (1 - pred);
-        c11 += l1 & pred;
-        // backward of this lane's bit
-        const float rfs = rcp_fast(fs);
-        const float q0 = f0 * rfs, q1 = f1 * rfs;
-        const float ga = (q0 - (label ? 0.f : 1.f)) * inv_count;
-        const float gb = (q1 - (label ? 1.f : 0.f)) * inv_count;
-        const float dot = ga * p0 + gb * p1;
-        const float du0 = p0 * (ga - dot), du1 = p1 * (gb - dot);
-        const float d20 = du0 * (p20 > 0.f ? 1.f : kLeaky), d21 = du1 * (p21 > 0.f ? 1.f : kLeaky);
-        gb2[0] += d20;
-        gb2[1] += d21;
-        float dc[M + 2];
-#pragma unroll
-        for (int i = 0; i < M + 2; ++i) {
-            g2[i][0] = __builtin_fmaf(c[i], d20, g2[i][0]);
-            g2[i][1] = __builtin_fmaf(c[i], d21, g2[i][1]);
-            dc[i] = quad_sum(__builtin_fmaf(d21, w2[i][1], d20 * w2[i][0]));      // all four bits' contributions
-        }
-        float d0p = 0.f, d1p = 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                    // hidden units 4q .. 4q+3
-            const float dp = pick4(dc, u) * (pick4(pre1, u) > 0.f ? 1.f : kLeaky);
-            gw1a[u] = __builtin_fmaf(z0, dp, gw1a[u]);
-            gw1b[u] = __builtin_fmaf(z1, dp, gw1b[u]);
-            gb1[u] += dp;
-            d0p = __builtin_fmaf(dp, swl[oW1 + 4 * q + u], d0p);
-            d1p = __builtin_fmaf(dp, swl[oW1 + M + 4 * q + u], d1p);
-        }
-        const float d0 = dc[M] + quad_sum(d0p), d1 = dc[M + 1] + quad_sum(d1p);
-        if (q == 0) *reinterpret_cast<float2*>(dz + 2 * cell) = make_float2(d0, d1);
+        const float2 d = tail_quad4_cell(zv.x, zv.y, label, true, W, inv_count,
+                                         WRITE_PROB ? prob + (cell * NB + q) * 2 : nullptr, q, A);
+        if (q == 0) *reinterpret_cast<float2*>(dz + 2 * cell) = d;
     }
-    // ---- block reduction: every quad row of the LDS matrix gets each parameter column from the lane that owns it
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    ce_acc = wave_sum(ce_acc);
-    c00 = wave_sum(c00); c01 = wave_sum(c01); c10 = wave_sum(c10); c11 = wave_sum(c11);
-    if (lane == 0) {
-        sce[wid] = ce_acc;
-        sconf[wid][0] = c00; sconf[wid][1] = c01; sconf[wid][2] = c10; sconf[wid][3] = c11;
-    }
-    float* row = smat + (threadIdx.x >> 2) * PS;
-#pragma unroll
-    for (int i = 0; i < M + 2; ++i) {
-        row[oW2 + i * O + 2 * q] = g2[i][0];
-        row[oW2 + i * O + 2 * q + 1] = g2[i][1];
-    }
-    row[oB2 + 2 * q] = gb2[0];
-    row[oB2 + 2 * q + 1] = gb2[1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        row[oW1 + 4 * q + u] = gw1a[u];
-        row[oW1 + M + 4 * q + u] = gw1b[u];
-        row[oB1 + 4 * q + u] = gb1[u];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        TailBlockMetrics bm;
-        bm.ce_sum = (sce[0] + sce[1]) + (sce[2] + sce[3]);
-        for (int k = 0; k < 4; ++k)
-            bm.conf[k] = (long long)sconf[0][k] + sconf[1][k] + sconf[2][k] + sconf[3][k];
-        blk_metrics[blockIdx.x] = bm;
-    }
-    const int slot = threadIdx.x >> 2, part = threadIdx.x & 3;
-    for (int col0 = 0; col0 < P; col0 += 64) {
-        const int col = col0 + slot;
-        const int cc = col < P ? col : P - 1;
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v += smat[(part * 16 + r) * PS + cc];
-        v = quad_sum(v);
-        if (part == 0 && col < P) blk_grads[(size_t)blockIdx.x * P + col] = v;
-    }
+    tail_quad4_block_reduce<kTailThreads>(A, sred, blk_metrics, blk_grads, (int)blockIdx.x);
 }
 
 // Slab reduction: wave g < P sums gradient column g over the per-block slabs (lane l owns slabs
@@ -564,10 +620,14 @@ struct TailFinalizeArgs {
     // and before this step's.  nullptr elsewhere.
     dccn_adam_state* adam;
     dccn_adam_hparams hp;
+    unsigned* zero_word;        // nullable: hand-off words of a later launch of the same step, reset here: the arrival
+    unsigned* zero_flags;       // counter and n_zero_flags flag words at a stride of zero_stride (fresh or recycled
+    int n_zero_flags, zero_stride;   // workspace memory may hold anything, including a stale epoch)
 };
 static inline int tail_finalize_blocks(int P) { return (P + 3 + 3) / 4; }
 
 __device__ __forceinline__ void demod_tail_finalize_body(const TailFinalizeArgs& a, const int block) {
+    if (a.metrics == nullptr) return;                    // stage already done by an earlier launch of the step
     const TailBlockMetrics* __restrict__ blk_metrics = a.blk_metrics;
     const float* __restrict__ blk_grads = a.blk_grads;
     const int nblocks = a.nblocks, P = a.P, n_power = a.n_power;
@@ -627,6 +687,10 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailFinalizeArgs&
         st->beta1_power = st->beta1_power * a.hp.beta1;
         st->beta2_power = st->beta2_power * a.hp.beta2;
         st->global_step = st->global_step + 1.0f;
+    }
+    if (g == P + 2 && a.zero_word != nullptr) {
+        if (lane == 0) *a.zero_word = 0u;
+        for (int i = lane; i < a.n_zero_flags; i += 64) a.zero_flags[(size_t)i * a.zero_stride] = 0u;
     }
 }
 

@@ -86,7 +86,7 @@ class RxEngine:
 
     def __init__(self, dims: RxDims, batch: int, device="cuda", train: bool = True, seed: int = 1,
                  params: Optional[Dict[str, np.ndarray]] = None, lr0: float = 1e-3, want_prob: bool = True,
-                 want_tx_power: bool = True, want_z: bool = True, want_dfft: bool = True):
+                 want_tx_power: bool = True, want_z: bool = True, want_dfft: bool = True, want_grads: bool = True):
         self.lib = _lib.load()
         self.dims, self.batch, self.train = dims, int(batch), bool(train)
         self.device = torch.device(device)
@@ -105,9 +105,9 @@ class RxEngine:
         self.bits = torch.zeros(B, d.D, d.nbits, dtype=torch.int32, device=self.device)
         self.x_norm = torch.empty(B, d.S, d.kin, 2, **f32)
         self.fft_out = torch.empty(B, d.S, d.F, 2, **f32)
-        # the dense output: for nbits <= 2 the tail runs inside the dense launch and z only exists when asked for
+        # the dense output: the tail runs inside the dense launch and z only exists when asked for
         # (the library's own plan queries decide which intermediate buffers a step can do without)
-        fused_tail = bool(self.lib.dccn_dense_tail_supported(B, d.S * d.F * 2, 2 * d.D, d.nbits))
+        fused_tail = bool(self.lib.dccn_rx_dense_tail_fused(C.byref(self.shape), 1 if train else 0))
         self.z = torch.empty(B, 2 * d.D, **f32) if (want_z or not fused_tail) else None
         self.prob = torch.empty(B, d.D, d.nbits, 2, **f32) if want_prob else None
         self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=self.device)
@@ -137,11 +137,20 @@ class RxEngine:
         self.buffers = RxBuffers(p(self.x), p(self.bits), p(self.params), p(self.grads), p(self.adam_m),
                                  p(self.adam_v), p(self.reg_coef), p(self.adam_state), p(self.x_norm),
                                  p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
-                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0)
+                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0, 0, 0, 1 if want_grads else 0)
+        # pipelined training, double-buffered: the next batch is normalised into the OTHER x_norm buffer by leading blocks of
+        # the backward launch (dccn.h: x_norm_next / norm_slot); `x_norm` stays the buffer plain steps use (parity 0)
+        self._norm_bufs = [self.x_norm, None]
+        self._norm_parity = 0
+        self._fwd_prefetched = False         # fft_out already holds the C-Conv forward of the prefetched batch
+        self._ride = int(self.lib.dccn_rx_norm_rides_backward(C.byref(self.shape))) if train else 0
+        if self._ride:
+            self._norm_bufs[1] = torch.empty_like(self.x_norm)
         # the same buffers in the pipelined mode (dccn.h: x_next / x_prenormalised), built on demand per (label slot, last)
         self._pipe_bufs = {}
         self.bits_alt = None                 # second label buffer: the generator fills it while a step reads the first
         self._norm_ready = False
+        self._prefetch_pending = False       # a pipelined call has normalised a batch that no step has consumed yet
         self.load_params(params if params is not None else glorot_init(dims, seed))
 
     # ---- parameters ----------------------------------------------------------------------
@@ -164,14 +173,29 @@ class RxEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _no_prefetch_pending(self, what: str):
+        """train_step_pipelined leaves the NEXT batch normalised in x_norm; another kind of step on this engine would
+        overwrite it and the following pipelined call would silently pair the wrong input with its labels."""
+        if self._prefetch_pending:
+            raise _lib.DccnError("%s while a prefetched batch is pending on this engine: finish the pipeline with "
+                                 "train_step_pipelined(last=True) or discard it with drop_prefetch()" % what)
+
+    def drop_prefetch(self):
+        """Forget the batch a pipelined call has normalised ahead (the next pipelined call primes itself again)."""
+        self._prefetch_pending = False
+        self._fwd_prefetched = False
+        self._norm_ready = False
+
     def set_batch(self, x, bits):
         """Stage a batch into the engine's resident input buffers (device copy or H2D)."""
+        self._no_prefetch_pending("set_batch")
         self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
         self.bits.copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
 
     def train_step(self, x=None, bits=None, graph: bool = False, fork: bool = False):
         if not self.train:
             raise _lib.DccnError("engine built with train=False")
+        self._no_prefetch_pending("train_step")
         if x is not None:
             self.set_batch(x, bits)
         self._norm_ready = False            # x_norm is about to hold this batch, not a prefetched one
@@ -187,6 +211,9 @@ class RxEngine:
             self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
         check(self.lib.dccn_rx_normalise(C.byref(self.shape), C.byref(self.buffers), self._stream()), "dccn_rx_normalise")
         self._norm_ready = True
+        self._prefetch_pending = False
+        self._fwd_prefetched = False
+        self._norm_parity = 0                # self.buffers names x_norm buffer 0 / partial-sum slot 0
 
     def label_slot(self, slot: int) -> torch.Tensor:
         """Label buffer ``slot`` (0 = ``eng.bits``, 1 = a second buffer of the same shape, allocated on first use)."""
@@ -196,13 +223,16 @@ class RxEngine:
             self.bits_alt = torch.zeros_like(self.bits)
         return self.bits_alt
 
-    def _pipe_buffers(self, slot: int, last: bool) -> RxBuffers:
-        key = (slot, last)
+    def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1) -> RxBuffers:
+        key = (slot, last, parity, double, pre)
         if key not in self._pipe_bufs:
             vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
             vals["bits"] = self.label_slot(slot).data_ptr()
             vals["x_next"] = 0 if last else self.x.data_ptr()
-            vals["x_prenormalised"] = 1
+            vals["x_prenormalised"] = pre
+            vals["x_norm"] = self._norm_bufs[parity].data_ptr()
+            vals["norm_slot"] = parity
+            vals["x_norm_next"] = self._norm_bufs[parity ^ 1].data_ptr() if (double and not last) else 0
             self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
         return self._pipe_bufs[key]
 
@@ -223,17 +253,27 @@ class RxEngine:
             self.label_slot(slot).copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
         if next_x is not None:
             self.x.copy_(torch.as_tensor(next_x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
+        double = self._norm_bufs[1] is not None
         if graph:
             if slot != 0 or last:
                 raise _lib.DccnError("captured pipelined steps use label slot 0 and always prefetch")
-            self._launch_graph(1 | 4)
+            # a captured step replays fixed buffers: it keeps the batch in whichever x_norm buffer holds it now and
+            # normalises the next one into the same buffer on its optimizer launch (the single-buffer form)
+            self._launch_graph(1 | 4 | (8 if self._norm_parity else 0))
+            self._fwd_prefetched = False
         else:
-            check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(self._pipe_buffers(slot, last)), self.hp,
-                                              self._stream()), "dccn_rx_train_step")
+            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1)
+            check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(bufs), self.hp, self._stream()), "dccn_rx_train_step")
+            self._fwd_prefetched = False
+            if double and not last:
+                self._norm_parity ^= 1           # the prefetched batch sits in the other buffer ...
+                self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out
+        self._prefetch_pending = not last
         if last:
             self._norm_ready = False
 
     def eval_step(self, x=None, bits=None, graph: bool = False):
+        self._no_prefetch_pending("eval_step")
         if x is not None:
             self.set_batch(x, bits)
         self._norm_ready = False
@@ -248,7 +288,7 @@ class RxEngine:
             self.close_graph()
             g = C.c_void_p(0)
             torch.cuda.synchronize(self.device)
-            bufs = self._pipe_buffers(0, False) if mode & 4 else self.buffers
+            bufs = self._pipe_buffers(0, False, 1 if mode & 8 else 0, False) if mode & 4 else self.buffers
             check(self.lib.dccn_rx_graph_create(C.byref(self.shape), C.byref(bufs), mode & 3, self.hp,
                                                 self._stream(), C.byref(g)), "dccn_rx_graph_create")
             self._graph, self._graph_mode = g, mode
@@ -327,8 +367,7 @@ def op_launchers(eng: RxEngine):
     nws = max(lib.dccn_dense_bwd_w_workspace_size(B, dK, dN), lib.dccn_cconv_gemm_bwd_w_workspace_size(rows, d.kin, d.F),
               lib.dccn_demod_tail_workspace_size(cells, d.nbits),
               lib.dccn_batch_moment_norm_workspace_size(B, d.S * d.kin * 2))
-    if d.nbits <= 2:
-        nws = max(nws, lib.dccn_dense_tail_workspace_size(B, dN, d.nbits))
+    nws = max(nws, lib.dccn_dense_tail_workspace_size(B, dN, d.nbits))
     ws = workspace(nws, eng.device, "bench")
     s = eng._stream
     zbuf = eng.z if eng.z is not None else torch.empty(B, dN, dtype=torch.float32, device=eng.device)

@@ -177,10 +177,15 @@ class _Im2col(torch.autograd.Function):
 
 def cconv_im2col(x: torch.Tensor, Lo: int, Wo: int, taps_l, taps_w, strides, pads) -> torch.Tensor:
     """x [B, L, Wd, C, 2] -> patch rows [B*Lo*Wo, len(taps_l)*len(taps_w)*C, 2] (zeros in the SAME padding); taps_* are
-    the contiguous live-tap ranges, strides (sL, sW), pads (pad_before_L, pad_before_W).  Differentiable."""
+    the contiguous live-tap ranges, strides (sL, sW), pads (pad_before_L, pad_before_W).  Differentiable.
+
+    Restriction (stated here because the layer API relies on it): the live taps of each axis -- the taps that meet data
+    for at least one output position -- must be a contiguous range.  That holds for every stride / 'valid' / 'same'
+    combination of the reference's layers (complex.py:51-92,140-196: undilated kernels, the taps reachable from output o
+    are an interval that slides by the stride); a dilated kernel would break it and is rejected."""
     tl, tw = list(taps_l), list(taps_w)
     if tl != list(range(tl[0], tl[0] + len(tl))) or tw != list(range(tw[0], tw[0] + len(tw))):
-        raise ValueError("live taps must form a contiguous range")
+        raise ValueError("live taps must form a contiguous range (undilated kernels only: see the docstring)")
     geom = (int(Lo), int(Wo), len(tl), len(tw), int(tl[0]), int(tw[0]), int(strides[0]), int(strides[1]), int(pads[0]),
             int(pads[1]))
     return _Im2col.apply(x.contiguous(), geom)
@@ -355,7 +360,7 @@ class _DenseTailLoss(torch.autograd.Function):
 
 
 def dense_tail_supported(x: torch.Tensor, w: torch.Tensor, nbits: int) -> bool:
-    """The fused launch needs nbits <= 2 and vector-legal operands (else use dense() + demod_tail_loss())."""
+    """The fused launch needs vector-legal operands and a small enough layer (else use dense() + demod_tail_loss())."""
     M, K = x.shape[0], x.shape[-1]
     N = w.shape[1]
     # the shape rule is the library's own (dccn_dense_tail_supported); the pointers are checked here as the launch does
@@ -375,7 +380,7 @@ def dense_demod_tail_loss(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch
     if bits.numel() != M * (N // 2) * nbits or tailp.numel() != tail_param_count(nbits):
         raise ValueError("shape mismatch between x, w, bits and tail params")
     if not dense_tail_supported(x, w, nbits):
-        raise ValueError("fused dense+tail needs nbits <= 2 and 16-byte aligned operands with K, N multiples of 4")
+        raise ValueError("fused dense+tail needs 16-byte aligned operands with K, N multiples of 4 (dccn_dense_tail_supported)")
     prob = torch.empty(M, N // 2, nbits, 2, dtype=torch.float32, device=x.device) if want_prob else None
     mbuf = _new_metrics(x.device)
     ce = _DenseTailLoss.apply(x, w, None if bias is None else bias.contiguous(), tailp.contiguous(), bits.contiguous(),

@@ -20,7 +20,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import ofdm, radio, sweep, util
+from . import _lib, ofdm, radio, sweep, util
 from .engine import PARAM_NAMES, RxDims
 
 
@@ -62,6 +62,8 @@ class Flags:
     snr_hi: int = 30                # inclusive (:72)
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py) instead of NumPy
     tf_checkpoint: bool = False     # also write <save_dir>/<token>.index/.data-00000-of-00001 (tf.train.Saver format)
+    iq_dump: bool = False           # per-epoch <token>_txiq.csv / _rxiq.csv constellation dumps (ofdmreceiver_np.py:264-265),
+    #                                 written into save_dir; off by default: two syncs + two files per epoch
 
 
 def parse_flags(argv=None) -> Flags:
@@ -186,14 +188,20 @@ def test_model(FLAGS: Flags, model, ofdmobj=None, rank: int = 0, world: int = 1,
                                                                              "noise_power:0", "ce_mean:0"))
     fading = radio.rayleigh_chan_lte(FLAGS, ofdmobj.Fs)
     gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
+    if gen is not None:
+        gen.want_noise_power = False          # the sweep table has no noise-power column
 
     def evaluate(p):
         if gen is not None:
-            eng = sess.engine_for(FLAGS.test_frames)
+            eng = sess.engine_for(FLAGS.test_frames, want_prob=False)
             gen.seed, gen.offset = p.seed, 0
             _gen_into(gen, eng, FLAGS, ofdmobj, FLAGS.test_frames, p.snr_db)
             eng.eval_step()
-            confmax, berl, test_loss = sess.fetch([conf_matrix, berlin, ce_mean], eng)
+            m = eng.metrics()          # the float64 / int64 record itself: no fp32 ce_mean * count, no int32 counts
+            if verbose:
+                print("SNR: %.2f, BER: %.8f, Loss: %f" % (p.snr_db, m["berlin"], m["ce_mean"]))
+            c = m["conf"]
+            return [c[0][0], c[0][1], c[1][0], c[1][1], m["ce_sum"], m["count"]]
         else:
             np.random.seed(p.seed)
             test_ys = util.bit_source(FLAGS.nbits, ofdmobj.frame_size, FLAGS.test_frames)
@@ -207,7 +215,19 @@ def test_model(FLAGS: Flags, model, ofdmobj=None, rank: int = 0, world: int = 1,
         count = float(confmax.sum())
         return [confmax[0][0], confmax[0][1], confmax[1][0], confmax[1][1], float(test_loss) * count, count]
 
-    table = sweep.run_sweep(pts, evaluate, rank, world, device=sess.device, group=group)
+    if gen is not None and not verbose:
+        # nothing is printed per point: the whole shard + the final all-reduce stay on the stream (no host round trip)
+        lib = _lib.load()
+
+        def evaluate_into(p, row):
+            eng = sess.engine_for(FLAGS.test_frames, want_prob=False)
+            gen.seed, gen.offset = p.seed, 0
+            _gen_into(gen, eng, FLAGS, ofdmobj, FLAGS.test_frames, p.snr_db)
+            eng.eval_step()
+            _lib.check(lib.dccn_metrics_table_add(eng.metrics_buf.data_ptr(), row.data_ptr(), eng._stream()), "table_add")
+        table = sweep.run_sweep_device(pts, evaluate_into, rank, world, device=sess.device, group=group).cpu().numpy()
+    else:
+        table = sweep.run_sweep(pts, evaluate, rank, world, device=sess.device, group=group)
     sess.close()
     ber, loss = sweep.ber_loss(table)
     csvfile = os.path.join(out_dir, "Test_DCCN_%s.csv" % (FLAGS.token + "_" + FLAGS.channel))
@@ -301,11 +321,14 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
             ev.eval_step(txs, tys)
         em = ev.metrics()
-        # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:256,264-265): first 2048 IQ pairs, fp16
-        from .session import monitor_tensors
-        mon = monitor_tensors(ev, FLAGS.SNR * np.ones(FLAGS.eval_frames), FLAGS.seed, epoch + 1)
-        np.savetxt("%s_txiq.csv" % FLAGS.token, mon["iq_tx"][:2048].cpu().numpy(), delimiter=",")     # cwd, like the reference
-        np.savetxt("%s_rxiq.csv" % FLAGS.token, mon["iq_rx"][:2048].cpu().numpy(), delimiter=",")
+        if FLAGS.iq_dump:
+            # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:256,264-265): first 2048 IQ pairs,
+            # fp16.  The reference writes them into its working directory every epoch; here they go to save_dir, on request.
+            from .session import monitor_tensors
+            mon = monitor_tensors(ev, FLAGS.SNR * np.ones(FLAGS.eval_frames), FLAGS.seed, epoch + 1)
+            os.makedirs(FLAGS.save_dir, exist_ok=True)
+            np.savetxt(os.path.join(FLAGS.save_dir, "%s_txiq.csv" % FLAGS.token), mon["iq_tx"][:2048].cpu().numpy(), delimiter=",")
+            np.savetxt(os.path.join(FLAGS.save_dir, "%s_rxiq.csv" % FLAGS.token), mon["iq_rx"][:2048].cpu().numpy(), delimiter=",")
         history.append(dict(epoch=epoch, train_loss=train_loss_epoch, test_loss=em["ce_mean"], test_ber=em["berlin"],
                             batch_size=batch_size))
         if verbose:

@@ -150,6 +150,7 @@ def test_model_cross(FLAGS, trainer, ofdmobj, rank: int = 0, world: int = 1, out
                 from .datagen import DeviceDataGen
                 fadings[p.channel] = DeviceDataGen(fl, ofdmobj, device=trainer.device, seed=p.seed,
                                                    mobile=FLAGS.mobile)
+                fadings[p.channel].want_noise_power = False
             else:
                 fadings[p.channel] = RayleighChanParallel(fl, ofdmobj.Fs, mobile=FLAGS.mobile)
         if on_device:

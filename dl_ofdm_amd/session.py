@@ -101,7 +101,7 @@ class Session:
         self.params = {n: np.asarray(params[n], dtype=np.float32) for n in PARAM_NAMES}
         self.dims = dims_from_params(self.params, nsymbol)
         self.crop = crop
-        self._engines.clear()
+        self.close()                         # engines of the previous model (and their captured graphs) go first
 
     def get_tensor_by_name(self, name: str) -> Tensor:
         if name not in TENSOR_NAMES:
@@ -114,13 +114,14 @@ class Session:
         self._engines.clear()
 
     # ---- run --------------------------------------------------------------------------------------------
-    def _engine(self, batch: int) -> RxEngine:
-        if batch not in self._engines:
+    def _engine(self, batch: int, want_prob: bool = True) -> RxEngine:
+        key = (batch, bool(want_prob))
+        if key not in self._engines:
             if len(self._engines) >= 4:                        # keep HBM bounded when batch sizes vary
                 self._engines.pop(next(iter(self._engines))).close_graph()
-            self._engines[batch] = RxEngine(self.dims, batch, device=self.device, train=False, params=self.params,
-                                            want_prob=True, want_tx_power=True)
-        return self._engines[batch]
+            self._engines[key] = RxEngine(self.dims, batch, device=self.device, train=False, params=self.params,
+                                          want_prob=want_prob, want_tx_power=True)
+        return self._engines[key]
 
     def run(self, fetches, feed_dict: Dict):
         if self.params is None:
@@ -155,12 +156,13 @@ class Session:
         self._calls += 1
         return monitor_tensors(eng, snr, self.seed, self._calls)
 
-    def engine_for(self, batch: int) -> RxEngine:
+    def engine_for(self, batch: int, want_prob: bool = True) -> RxEngine:
         """The evaluation engine ``run`` would use for this batch size (device-side generators write their batches
-        straight into its resident ``x`` / ``bits`` buffers, then call :meth:`fetch`)."""
+        straight into its resident ``x`` / ``bits`` buffers, then call :meth:`fetch` or read ``eng.metrics()``).
+        ``want_prob=False``: an engine that does not materialise ``output:0`` (sweeps only need the metrics record)."""
         if self.params is None:
             raise _lib.DccnError("Session used before a model was restored")
-        return self._engine(batch)
+        return self._engine(batch, want_prob)
 
     def fetch(self, fetches: Sequence[Tensor], eng: RxEngine, snr=None) -> List:
         """Named tensors of the step ``eng`` ran last (``run`` = stage the feed + ``eng.eval_step()`` + this)."""
@@ -180,6 +182,8 @@ class Session:
         if n == "input:0":
             return eng.x_norm.cpu().numpy()
         if n == "output:0":
+            if eng.prob is None:
+                raise _lib.DccnError("output:0 fetched from an engine built with want_prob=False")
             return eng.prob.cpu().numpy()
         if n == "receiver/fft_like/fft_out:0":
             return eng.fft_out.cpu().numpy()

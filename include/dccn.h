@@ -185,7 +185,11 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
  * (0 = 32x32x2 tile family, >0 = a 16x16x4 configuration), 4/5 split-K counts of the two weight gradients
  * (0 = automatic), 6 minimum LDS per block in KiB, 7 single-tile launches for short k ranges (default 1),
  * 8 skinny dispatch, 9 grouped backward of large layers, 10 gemm16 tiles for the un-fused dense forward,
- * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1).
+ * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1), 12 wave priority of those tiles,
+ * 13 fused dense+tail launch for 8-QAM / 16-QAM steps (bit 0 lane-per-cell forms, bit 1 quad-lane training form),
+ * 14 graded k ranges of the dense weight-gradient items in the fused backward launch (preset number, 0 = uniform),
+ * 15 C-Conv forward of the next batch on the optimizer launch of double-buffered pipelined steps (default 1),
+ * 16 large layers: optimizer update of the dense kernel in the epilogue of its unsplit weight-gradient tiles (default 1).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
@@ -266,15 +270,34 @@ typedef struct dccn_rx_buffers {
        x_next != NULL  the step also normalises x_next into x_norm behind its Adam update (the leading blocks of the
                        optimizer launch; x_norm is dead by then), for the following call;
        x_prenormalised x_norm (and the R8 partial sums in the workspace) already hold this step's batch -- written
-                       by the previous call through x_next -- so the step starts at R1.
+                       by the previous call through x_next -- so the step starts at R1; 2: fft_out holds it as well
+                       (dccn_rx_norm_rides_backward == 2), the step starts at R2.
        x itself is only read by R0: with both set, x and x_next may be the same buffer, refilled between calls.
        The workspace must be the same memory in both calls. */
     const float* x_next;
     int x_prenormalised;
+    /* Double-buffered form of the same pipelining (dccn_rx_norm_rides_backward(shape) == 1): with x_norm_next != NULL the
+       normalisation of x_next is written to x_norm_next by leading blocks of the BACKWARD launch of this step -- hidden
+       behind 30 us of matrix work instead of stretching the optimizer launch -- and the caller passes that buffer as
+       x_norm (and norm_slot ^ 1 as norm_slot) in the following call.  norm_slot (0/1) names the R8 partial-sum slot of
+       the workspace that belongs to x_norm; x_norm is read until the backward launch ends, hence the second buffer. */
+    float* x_norm_next;
+    int norm_slot;
+    /* Large layers (dccn_get_tuning(16), N = 1024): the dense kernel's optimizer update runs in the epilogue of its
+       weight-gradient tiles and its gradient is not written to `grads` unless keep_dense_grad != 0. */
+    int keep_dense_grad;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
 int dccn_rx_bwd_fused_supported(const dccn_rx_shape* shape);
+/* 1: dccn_rx_train_step (train != 0) / dccn_rx_eval_step run R2..R6 as ONE launch for this shape -- the dense forward
+ * with the demodulation tail in its epilogue -- and `z` may be NULL.  (8-QAM / 16-QAM: the tile is staged through LDS and
+ * walked a lane or a quad of lanes per cell; which of those steps take the fused launch is tuning knob 13.) */
+int dccn_rx_dense_tail_fused(const dccn_rx_shape* shape, int train);
+/* > 0: a training step given x_next + x_norm_next normalises the next batch on its backward launch (see dccn_rx_buffers);
+ * 2: its optimizer launch then also runs the C-Conv forward of that batch (into fft_out, after the C-Conv kernel's own
+ * update, handed over inside the launch), and the following call is told so with x_prenormalised = 2 */
+int dccn_rx_norm_rides_backward(const dccn_rx_shape* shape);
 /* The backward half of the basic receiver's training step as one launch (small layers, see the query above):
  *   dfft = dz . Wd^T                     (dev/py/model.py:1268-1275 backward; written only when dfft != NULL)
  *   dWd  = fft_out^T . dz, dbd = colsum  (k-major tiles, split-K slabs)

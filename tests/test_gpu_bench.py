@@ -45,4 +45,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert w["bits_counted"] == 40 * 20000 * 320 * 4 and w["seconds"] > 0
     assert abs(w["points_per_s"] - 40 / w["seconds"]) < 1e-6 * w["points_per_s"] and w["symbols_per_s"] > 1e6
     assert r["op"] in d["kernels"] and d["kernels"][r["op"]]["us"] > 0
+    # the training loop with the device-side generator (configs[1]: QPSK on Rayleigh EPA), timed by the same run
+    e = d["e2e"]
+    assert e["symbols_per_s"] > 1e7 and e["symbols_per_s"] < d["value"] * 1.001 and 0.0 < e["ber_last"] < 0.5
 

@@ -88,6 +88,36 @@ def test_c4_full_size_qpsk_n1024_585_frames():
         outs.append((e.params.clone(), e.prob.clone(), e.metrics()["conf"]))
         del e
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    # the dense kernel's Adam update in the epilogue of its (unsplit) weight-gradient tiles (tuning knob 16; measured slower
+    # than the separate pass, hence off by default) against the separate optimizer pass over the stored gradient: the same operations on the same values -- bitwise,
+    # with the gradient kept (the test engines) or dropped (bench.py's engine: want_grads=False)
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    ref_params = outs[0][0]
+    del outs
+    torch.cuda.empty_cache()
+    e = RxEngine(dims, batch, params=p, train=True, want_prob=True)
+    for _ in range(2):
+        e.train_step(x, bits)
+    torch.cuda.synchronize()
+    sep = (e.params.clone(), e.adam_m.clone(), e.adam_v.clone(), e.grads.clone())
+    del e
+    assert torch.equal(sep[0], ref_params)
+    default = lib.dccn_get_tuning(16)
+    try:
+        assert lib.dccn_set_tuning(16, 1) == 0
+        for kw in (dict(), dict(want_grads=False, want_z=False, want_dfft=False)):
+            e = RxEngine(dims, batch, params=p, train=True, want_prob=True, **kw)
+            for _ in range(2):
+                e.train_step(x, bits)
+            torch.cuda.synchronize()
+            assert torch.equal(e.params, sep[0]) and torch.equal(e.adam_m, sep[1]) and torch.equal(e.adam_v, sep[2])
+            if not kw:
+                assert torch.equal(e.grads, sep[3])
+            del e
+            torch.cuda.empty_cache()
+    finally:
+        lib.dccn_set_tuning(16, default)
 
 
 def test_bench_two_ranks_over_gloo_one_json_line():

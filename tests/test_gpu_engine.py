@@ -278,15 +278,86 @@ def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits, kin, F
         assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads), t
         assert torch.equal(a.prob, b.prob) and torch.equal(a.adam_state, b.adam_state), t
         assert a.metrics() == b.metrics(), t
-    assert not b._norm_ready
+    assert not b._norm_ready and not b._prefetch_pending
     a.train_step(xs[1], bs[1])
     b.train_step_pipelined(next_x=xs[2], bits=bs[1])          # primes itself from eng.x ...
     torch.cuda.synchronize()
     assert not torch.equal(a.params, b.params)                # ... which still holds the last batch: a different one, by design
+    # a prefetched batch is pending now: any other kind of step on this engine would silently clobber it -> loud
+    from dl_ofdm_amd._lib import DccnError
+    for bad in (lambda: b.eval_step(), lambda: b.train_step(), lambda: b.set_batch(xs[0], bs[0])):
+        with pytest.raises(DccnError):
+            bad()
+    b.drop_prefetch()
+    b.train_step(xs[0], bs[0])
+
+
+def test_forward_prefetch_on_the_optimizer_launch_is_bitwise():
+    """Tuning knob 15 (off by default: measured slower): the optimizer launch of a double-buffered pipelined step also runs
+    the C-Conv forward of the next batch, its updated kernel handed over INSIDE the launch (write-through stores, arrival
+    counter, one flag word per consumer block, one agent-scope acquire).  Three launches per step; parameters, gradients,
+    probabilities, metrics and optimizer state stay bit-identical to plain steps over 12 steps (stale data from a missed
+    hand-off would show up as a different trajectory)."""
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    lib = _lib.load()
+    default = lib.dccn_get_tuning(15), lib.dccn_get_tuning(18)
+    try:
+        assert lib.dccn_set_tuning(15, 1) == 0 and lib.dccn_set_tuning(18, 1) == 0
+        for frames, nbits in ((1170, 2), (300, 4)):
+            dims = RxDims(S=7, kin=80, F=64, D=320, nbits=nbits)
+            rng = np.random.RandomState(9)
+            xs = [rng.standard_normal((frames, 7, 80, 2)).astype(np.float32) for _ in range(4)]
+            bs = [rng.randint(0, 2, (frames, 320, nbits)).astype(np.int32) for _ in range(4)]
+            a = RxEngine(dims, frames, train=True, seed=4, want_prob=True)
+            b = RxEngine(dims, frames, train=True, seed=4, want_prob=True, want_z=False, want_dfft=False)
+            assert b._ride == 2
+            b.prime(xs[0])
+            for t in range(12):
+                a.train_step(xs[t % 4], bs[t % 4])
+                b.train_step_pipelined(next_x=xs[(t + 1) % 4], bits=bs[t % 4], slot=t & 1, last=(t == 11))
+                torch.cuda.synchronize()
+                assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads) and torch.equal(a.prob, b.prob), t
+                assert torch.equal(a.adam_state, b.adam_state) and a.metrics() == b.metrics(), t
+    finally:
+        lib.dccn_set_tuning(15, default[0])
+        lib.dccn_set_tuning(18, default[1])
+
+
+def test_double_buffered_normalisation_on_the_backward_launch_is_bitwise():
+    """Tuning knob 18 (off by default: measured neutral): R0 of the next batch rides on the backward launch into a second
+    x_norm buffer instead of the optimizer launch; eager double-buffered steps, captured single-buffer replays of either
+    parity and the closing step interleave freely and stay bit-identical to plain steps."""
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    lib = _lib.load()
+    default = lib.dccn_get_tuning(18)
+    try:
+        assert lib.dccn_set_tuning(18, 1) == 0
+        frames, nbits = 300, 2
+        dims = RxDims(S=7, kin=80, F=64, D=320, nbits=nbits)
+        rng = np.random.RandomState(10)
+        xs = [rng.standard_normal((frames, 7, 80, 2)).astype(np.float32) for _ in range(8)]
+        bs = [rng.randint(0, 2, (frames, 320, nbits)).astype(np.int32) for _ in range(8)]
+        a = RxEngine(dims, frames, train=True, seed=4, want_prob=True)
+        b = RxEngine(dims, frames, train=True, seed=4, want_prob=True, want_z=False, want_dfft=False)
+        assert b._ride == 1 and b._norm_bufs[1] is not None
+        b.prime(xs[0])
+        modes = ["e", "g", "g", "e", "e", "g", "e", "last"]       # eager flips the buffer parity, replays keep it
+        for t, mode in enumerate(modes):
+            a.train_step(xs[t], bs[t])
+            if mode == "last":
+                b.train_step_pipelined(bits=bs[t], last=True)
+            else:
+                b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], graph=(mode == "g"))
+            torch.cuda.synchronize()
+            assert torch.equal(a.params, b.params) and torch.equal(a.prob, b.prob) and a.metrics() == b.metrics(), (t, mode)
+    finally:
+        lib.dccn_set_tuning(18, default)
 
 
 @pytest.mark.parametrize("key,value", [(0, 2), (0, 1), (0, 0), (1, 0), (1, 3), (2, 1), (3, 0), (3, 1), (4, 3), (5, 32), (7, 0), (8, 0),
-                                       (9, 0), (10, 0), (11, 0)])
+                                       (9, 0), (10, 0), (11, 0), (12, 0), (14, 0), (14, 3)])
 def test_every_tuning_setting_computes_the_same_step(key, value):
     """dccn_set_tuning only selects tile configurations: two training steps under any setting agree with the default
     ones to rounding (the settings that keep the summation order are bitwise equal; the others regroup fp32 sums)."""

@@ -80,7 +80,8 @@ def test_awgn_ber_matches_closed_form(nbits, snr_db):
 def test_short_training_run_learns_and_sweeps(tmp_path):
     from dl_ofdm_amd import receiver
     F = flags(nbits=1, SNR=5.0, msg_length=7 * 2048, batch_size=7 * 64, max_epoch_num=12, early_stop=50,
-              save_dir=str(tmp_path / "ckpt"), token="OFDM_t", test_frames=1500, eval_frames=512, snr_lo=0, snr_hi=6)
+              save_dir=str(tmp_path / "ckpt"), token="OFDM_t", test_frames=1500, eval_frames=512, snr_lo=0, snr_hi=6,
+              iq_dump=True)
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
@@ -104,7 +105,7 @@ def test_short_training_run_learns_and_sweeps(tmp_path):
     assert float(z["global_step"]) > 0
     # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:264-265): 2048 fp16 IQ pairs each
     for suffix in ("txiq", "rxiq"):
-        d = np.loadtxt(os.path.join(str(tmp_path), "OFDM_t_%s.csv" % suffix), delimiter=",")
+        d = np.loadtxt(os.path.join(str(tmp_path / "ckpt"), "OFDM_t_%s.csv" % suffix), delimiter=",")     # save_dir, on request
         assert d.shape == (2048, 2) and np.isfinite(d).all()
         assert np.array_equal(d.astype(np.float16).astype(np.float64), d)            # values are fp16-representable
 

@@ -253,7 +253,10 @@ def test_demod_tail_loss(ops, nbits, cells):
 
 # ---- R2 + R3-R6 in one launch (gemm16 EPI_TAIL) -----------------------------------------------------
 @pytest.mark.parametrize("nbits,M,K,N", [(2, 36, 896, 640), (1, 36, 896, 640), (2, 1170, 896, 640), (2, 53, 100, 36),
-                                         (1, 130, 64, 132), (2, 585, 128, 64)])
+                                         (1, 130, 64, 132), (2, 585, 128, 64),
+                                         # 8-QAM / 16-QAM: tile staged through LDS, lane-per-cell / quad-lane tail
+                                         (3, 36, 896, 640), (4, 36, 896, 640), (4, 300, 896, 640), (3, 300, 896, 640),
+                                         (4, 53, 100, 36), (3, 130, 64, 132)])
 def test_dense_tail_fused(ops, nbits, M, K, N):
     """dccn_dense_tail_fwd_bwd vs the float64 oracle (dense, then tail forward/backward): prob, ce_mean, confusion
     counts, dz through its consumers dx/dw/db, and the tail-weight gradients.  Cells whose pre-activations sit within

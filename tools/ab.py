@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
-    defaults = [lib.dccn_get_tuning(k) for k in range(13)]
+    defaults = [lib.dccn_get_tuning(k) for k in range(19)]
     specs = args.tunes.split(";") if args.tunes else [""]
 
     def tune(spec):
@@ -55,6 +55,7 @@ def main():
             eng = engines[spec]
             ops = op_launchers(eng)
             for w in args.what.split(","):
+                eng.drop_prefetch()         # (a pipelined measurement may have left a normalised batch behind)
                 if w == "step":
                     fn = lambda: eng.train_step(graph=args.graph)
                 elif w == "step_pipe":

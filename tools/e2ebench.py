@@ -31,6 +31,7 @@ def main():
     o = ofdm.ofdm_tx(F)
     eng = RxEngine(R.rx_dims(F, o), a.frames, train=True, want_prob=False)
     gen = DeviceDataGen(F, o, seed=1)
+    gen.want_noise_power = False
     # the training loop of dl_ofdm_amd.receiver.train (device_data): batch i+1 is generated into eng.x / the other label
     # slot before step i is issued, and normalised behind step i's Adam update
     def run(n, first):
@@ -50,6 +51,7 @@ def main():
                           symbols_per_s=round(a.frames * 7 / dt), final_ce=round(eng.metrics()["ce_mean"], 4))))
     if a.host_steps <= 0:
         return
+    eng.drop_prefetch()                    # the pipelined loop above left a normalised batch behind
     fading = radio.rayleigh_chan_lte(F, o.Fs)
     np.random.seed(1)
     t0 = time.perf_counter()
