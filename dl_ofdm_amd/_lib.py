@@ -112,6 +112,12 @@ SIGNATURES = {
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
     "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),
     "dccn_ingraph_awgn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
+    "dccn_classical_workspace_size": (_sz, []),
+    "dccn_dense_fwd_ld": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dccn_classical_pilot_ls": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "dccn_classical_gain": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _sz, _vp]),
+    "dccn_classical_estimate": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "dccn_classical_detect": (_i, [_vp] * 8 + [_i] * 7 + [_vp, _sz, _vp]),
     "dccn_set_tuning": (_i, [_i, _i]),
     "dccn_get_tuning": (_i, [_i]),
     "dccn_dense_tail_supported": (_i, [_i, _i, _i, _i]),

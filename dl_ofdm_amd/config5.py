@@ -171,10 +171,12 @@ CLASSICAL_METHODS = ("LMMSE", "LS-Spline", "Perfect")
 
 
 def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: Sequence[int], n_frames: int,
-                     rank: int = 0, world: int = 1, group=None, seed: int = 5, methods: Sequence[str] = CLASSICAL_METHODS):
+                     rank: int = 0, world: int = 1, group=None, seed: int = 5, methods: Sequence[str] = CLASSICAL_METHODS,
+                     device=None):
     """The LMMSE / LS baseline curves (dev/m/OFDM_Benchmark_dev.m:339-456 via dl_ofdm_amd.benchmark), one unit per
     (modulation, channel, estimator, SNR) -- each with its own seeded draws -- dealt round-robin to the ranks; ONE
-    all-reduce of the [units, 2] table {bit errors, bits}.  Returns {(nbits, channel, method): BER per csnr}."""
+    all-reduce of the [units, 2] table {bit errors, bits}.  ``device``: run them on that GPU (benchmark_gpu: device-side
+    generator + libdccn receivers) instead of the host NumPy restatement.  Returns {(nbits, channel, method): BER per csnr}."""
     import torch
     from . import benchmark, receiver as R, sweep
     units = [(b, ch, m, i) for b in nbits_list for ch in channels for m in methods for i in range(len(csnr))]
@@ -185,7 +187,11 @@ def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: S
             continue
         key = (b, ch, m)
         if key not in cache:
-            cache[key] = benchmark.CurvePoints(R.Flags(nbits=b, channel=ch), m, n_frames=n_frames, seed=seed)
+            if device is not None:          # frames from the device generator, receivers as libdccn launches
+                from .benchmark_gpu import CurvePointsGPU
+                cache[key] = CurvePointsGPU(R.Flags(nbits=b, channel=ch, nfilter=64), m, n_frames=n_frames, seed=seed, device=device)
+            else:
+                cache[key] = benchmark.CurvePoints(R.Flags(nbits=b, channel=ch), m, n_frames=n_frames, seed=seed)
         e, n = cache[key].point(i, float(csnr[i]))
         table[u, 0], table[u, 1] = e, n
     if world > 1:
@@ -222,7 +228,7 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
         print("DCCN sweep done: %d points, %.0f s since start" % (len(pts), time.time() - t0), flush=True)
     t2 = time.time()
     csnr = list(snrs)[::classical_every]
-    classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world)
+    classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device)
     timing["classical"] = time.time() - t2
     timing["total"] = time.time() - t0
     all_t = [timing]

@@ -14,6 +14,7 @@
 #include "equalizer.h"
 #include "datagen.h"
 #include "im2col.h"
+#include "classical.h"
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
@@ -56,7 +57,8 @@ enum TuneKey : int {
     TUNE_ADAM_IN_DW = 16,       // 1: large layers (unsplit dW tiles): the dense kernel's Adam update runs in the dW epilogue
     TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
     TUNE_NORM_ON_BWD = 18,      // 1: double-buffered pipelining: R0 of the next batch rides on the backward launch
-    TUNE_COUNT = 19
+    TUNE_EQ_EPILOGUES = 19,     // 1: equaliser step: tanh / tanh-gradient / gradient add in the epilogues of the few-row GEMMs
+    TUNE_COUNT = 20
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -79,12 +81,13 @@ struct TuneTable {
 //   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
-template <int KA, int KB, int TAG>
+template <int KA, int KB, int TAG, int ACT = 1>
 static int skinny_launch(int variant, const GemmParams& p, hipStream_t s) {
+    if constexpr (ACT != 1) return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 1, 0, TAG, 2, ACT>(p, 1, s);   // 16x64 + element-wise stage
     switch (variant) {
         case 1: return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 16x64
         case 2: return launch_gemm16<KA, KB, 1, 4, 2, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 32x64
@@ -188,8 +191,10 @@ static int round_k(int K) { return ceil_div(K, 64) * 64; }
 static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < (1LL << 31); }
 
 // ldx > 0: x is a column window of a wider row-major matrix (row stride ldx)
+// act = 2: y = tanh(x.w + bias) when the launch plan has the stage (few-row 16x64 tiles); *act_done tells
 static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                          hipStream_t s, int ldx = 0) {
+                          hipStream_t s, int ldx = 0, int act = 1, bool* act_done = nullptr) {
+    if (act_done) *act_done = false;
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     const int lda = ldx > 0 ? ldx : K;
     GemmParams p = gp_zero();
@@ -199,7 +204,13 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.klen = round_k(K);
     p.vecA = (K % 4 == 0) && (lda % 4 == 0) && aligned16(x) && small_enough(M, lda);     // KCONTIG: k extent K
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
-    if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD>(g_tune[TUNE_SKINNY], p, s);
+    if (skinny_ok(p)) {
+        if (act == 2 && act_done && g_tune[TUNE_EQ_EPILOGUES]) {
+            *act_done = true;
+            return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD, 2>(1, p, s);
+        }
+        return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD>(g_tune[TUNE_SKINNY], p, s);
+    }
     // small layers (64x64 tiles would leave CUs without a block: 1170x640 = 190 tiles): the 48x64 tiles of the fused
     // kernel, loads two k-tiles ahead
     if (g_tune[TUNE_DENSE_FWD_PLAIN] && p.vecA && p.vecB && (K % 4 == 0) && (N % 4 == 0) && K >= 128 &&
@@ -363,12 +374,20 @@ static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
     if (variant == 6) wn = 128;
 }
 
+// will dense_bwd_grouped_impl take the few-row grid that can carry an element-wise stage on its dX store (16-byte
+// aligned operands assumed: the callers' workspaces are)
+static bool dense_bwd_stage_planned(int M, int K, int N) {
+    return g_tune[TUNE_SKINNY] > 0 && g_tune[TUNE_SKINNY_GROUPED] && g_tune[TUNE_EQ_EPILOGUES] && M <= 96 && (K % 4 == 0) &&
+           (N % 4 == 0) && small_enough(M, K) && small_enough(M, N) && small_enough(K, N);
+}
+
 // dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
 // (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
 static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                   int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer,
-                                  const AdamEpi* ae = nullptr) {
+                                  const AdamEpi* ae = nullptr, int actx = 1, const float* aux = nullptr, bool* act_done = nullptr) {
+    if (act_done) *act_done = false;
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     defer->adam_done = false;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
@@ -386,6 +405,15 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     if (g_tune[TUNE_SKINNY] > 0 && g_tune[TUNE_SKINNY_GROUPED] && vec && M <= 96 && (K % 4 == 0) && (N % 4 == 0)) {
         pw.klen = round_k(M);
         pw.C = dw; pw.colsum = dbias; pw.slab = 0;
+        // the dX tiles may carry an element-wise stage of the caller's graph: 3 = times (1 - aux^2) (tanh gradient),
+        // 4 = plus aux (gradient accumulation): two 5 us launches of the equaliser step less
+        if (actx != 1 && act_done && aux && g_tune[TUNE_EQ_EPILOGUES]) {
+            px.aux = aux;
+            *act_done = true;
+            if (actx == 3) DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 3>(px, pw, 1, s, tune_smem_min())));
+            else if (actx == 4) DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 4>(px, pw, 1, s, tune_smem_min())));
+            else return DCCN_ERR_INVALID_ARG;
+        } else
         DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2>(px, pw, 1, s, tune_smem_min())));
         defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1;
         return DCCN_OK;
@@ -1872,6 +1900,82 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
                            noise_power);
         DCCN_LAUNCH_CHECK();
     }
+    return DCCN_OK;
+}
+
+// ---- classical pilot-aided receivers (classical.h) -----------------------------------------------------------------
+size_t dccn_classical_workspace_size(void) {
+    size_t o = 0;
+    o = carve_size(o, (size_t)kClassicalPartials * 4 * sizeof(double));
+    o = carve_size(o, (size_t)kClassicalPartials * sizeof(long long));
+    return align_up(o, 256);
+}
+static int classical_blocks(long long items) {
+    long long b = items < 2 * kCUs ? items : 2 * kCUs;
+    if (b > kClassicalPartials) b = kClassicalPartials;
+    return (int)(b < 1 ? 1 : b);
+}
+int dccn_dense_fwd_ld(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K, int N,
+                      dccn_stream_t stream) {
+    if (ldx < K) return DCCN_ERR_INVALID_ARG;
+    return dense_fwd_impl(x, w, bias, y, M, K, N, (hipStream_t)stream, ldx);
+}
+int dccn_classical_pilot_ls(const float* Y, const int* pil, float* gp, int n, int SK, int P, float pv_re, float pv_im,
+                            dccn_stream_t stream) {
+    if (!Y || !pil || !gp || n <= 0 || SK <= 0 || P <= 0 || (pv_re == 0.f && pv_im == 0.f)) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(classical_pilot_ls_kernel, dim3((unsigned)ceil_div_ll((long long)n * P, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float2*)Y, pil, gp, n, SK, P, make_float2(pv_re, pv_im));
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_classical_gain(const float* Y, const float* H, const float* Gls, const int* pil, int n, int SK, int P, float pv_re,
+                        float pv_im, double* sums4, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!Y || !Gls || !pil || n <= 0 || SK <= 0 || P <= 0) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
+    Carver c(workspace, workspace_bytes);
+    double* partial = c.take<double>((size_t)kClassicalPartials * 4);
+    const int nblk = classical_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(classical_gain_kernel, dim3(nblk), dim3(256), 0, s, (const float2*)Y, (const float2*)H, Gls, pil, partial,
+                       n, SK, P, make_float2(pv_re, pv_im));
+    DCCN_LAUNCH_CHECK();
+    if (sums4) {
+        hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)nullptr, 0, (const double*)partial,
+                           nblk, (long long*)nullptr, sums4);
+        DCCN_LAUNCH_CHECK();
+    }
+    return DCCN_OK;
+}
+int dccn_classical_estimate(const float* Gls, const float* H, float* G, int n, int S, int K, int mode, float c_var,
+                            void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!Gls || !G || n <= 0 || S <= 0 || S > 32 || K <= 0 || mode < CE_LS || mode > CE_FRAME_MEAN) return DCCN_ERR_INVALID_ARG;
+    if ((mode == CE_LMMSE || mode == CE_PERFECT) && !H) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
+    Carver c(workspace, workspace_bytes);
+    double* partial = c.take<double>((size_t)kClassicalPartials * 4);
+    hipLaunchKernelGGL(classical_estimate_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, Gls, (const float2*)H,
+                       (const double*)partial, classical_blocks(n), (float2*)G, n, S, K, mode, c_var);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_classical_detect(const float* Y, const float* G, const int* dat, const float* table, const int* labels,
+                          const int32_t* bits, int32_t* det, long long* errors, int n, int SK, int D, int m, int nbits,
+                          int g_row, int g_mod, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!Y || !G || !dat || !table || !labels || !bits || !errors || n <= 0 || SK <= 0 || D <= 0 || m <= 0 || nbits < 1 ||
+        nbits > 8 || g_row <= 0)
+        return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
+    Carver c(workspace, workspace_bytes);
+    c.take<double>((size_t)kClassicalPartials * 4);
+    long long* ep = c.take<long long>((size_t)kClassicalPartials);
+    const int nblk = classical_blocks(ceil_div_ll((long long)n * D, 256));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(classical_detect_kernel, dim3(nblk), dim3(256), 0, s, (const float2*)Y, (const float2*)G, dat,
+                       (const float2*)table, labels, bits, det, ep, n, SK, D, m, nbits, g_row, g_mod);
+    DCCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)ep, nblk, (const double*)nullptr, 0,
+                       errors, (double*)nullptr);
+    DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 

@@ -115,11 +115,14 @@ static size_t eq_ws_bytes(const dccn_eq_shape* sh, int train) {
 }
 
 // dense backward with reduced outputs: dx (nullable: weight gradient only), dw, dbias
+// actx / aux / act_done: optional element-wise stage on the dX store (dense_bwd_grouped_impl)
 static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
-                               int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s) {
+                               int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, int actx = 1,
+                               const float* aux = nullptr, bool* act_done = nullptr) {
+    if (act_done) *act_done = false;
     if (!dx) return dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s);
     DeferredSlabs ds;
-    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds));
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds, nullptr, actx, aux, act_done));
     if (ds.dw_slabs) {
         const long long n = (long long)K * N;
         if (dbias && ds.db_slabs)
@@ -167,9 +170,14 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
     DCCN_TRY(dense_fwd_impl(w.d1, P + d.o[6], P + d.o[7], w.d2, B, d.Pp, SK2, s));
     DCCN_TRY(dense_fwd_impl(w.d2, P + d.o[8], P + d.o[9], w.d3, B, SK2, SK2, s));
-    DCCN_TRY(dense_fwd_impl(w.d3, P + d.o[10], P + d.o[11], w.d4, B, SK2, SK2, s));
-    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.d4, w.d4, nBK);
-    DCCN_LAUNCH_CHECK();
+    {
+        bool fused = false;                 // tanh in the GEMM's store when the plan has the stage (few-row batches)
+        DCCN_TRY(dense_fwd_impl(w.d3, P + d.o[10], P + d.o[11], w.d4, B, SK2, SK2, s, 0, 2, &fused));
+        if (!fused) {
+            hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.d4, w.d4, nBK);
+            DCCN_LAUNCH_CHECK();
+        }
+    }
     // :428 smoothing C-Conv (S x K, same) as a block-Toeplitz dense layer -> channel estimate
     hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s,
                        P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
@@ -227,23 +235,34 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                        (const float2*)h, (const float2*)w.deq, (const float2*)w.dcorr, (float2*)w.dy, (float2*)w.dh,
                        nBK / 2);
     DCCN_LAUNCH_CHECK();
-    DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_split, w.n_split, s));
+    bool tg_fused = false;                  // tanh gradient on the dX store: dd4 = (dh . T^T) (1 - d4^2)
+    DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_split, w.n_split, s, 3, w.d4, &tg_fused));
     hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
                        (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
     DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.dd4, (const float*)w.d4,
-                       w.dd4, nBK);
-    DCCN_LAUNCH_CHECK();
+    if (!tg_fused) {
+        hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.dd4, (const float*)w.d4,
+                           w.dd4, nBK);
+        DCCN_LAUNCH_CHECK();
+    }
     DCCN_TRY(dense_bwd_full_impl(w.d3, w.dd4, P + d.o[10], w.dd3, G + d.o[10], G + d.o[11], B, SK2, SK2, w.ws_split,
                                  w.n_split, s));
     DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_split,
                                  w.n_split, s));
     DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_split,
                                  w.n_split, s));
-    DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
-                                 w.n_split, s));
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
-    DCCN_LAUNCH_CHECK();
+    if (dense_bwd_stage_planned(B, SK2, d.Pp)) {
+        // dy += (gradient through the pilot branch): accumulated by the dX store itself
+        bool add_fused = false;
+        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dy, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
+                                     w.n_split, s, 4, w.dy, &add_fused));
+        if (!add_fused) return DCCN_ERR_STATE;              // plan and launch disagree: never silently drop the sum
+    } else {
+        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
+                                     w.n_split, s));
+        hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
+        DCCN_LAUNCH_CHECK();
+    }
     DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
     DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_split, w.n_split, s));
     DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_split, w.n_split, s, nullptr,

@@ -493,7 +493,16 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
                     float v;
                     if constexpr (KS > 1) v = set == 0 ? tile_val(a, b, rr, lane) : tile_val(a, b, 2 + rr, lane);
                     else v = acc[a][b][rr];
-                    if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + col] = v + bj;
+                    if (row < p.M && col < p.N) {
+                        // EPI_STORE: NB selects an element-wise stage on the way out (compile time: the plain store pays
+                        // nothing): the equaliser's tanh, its gradient, and "add to what is there" (model.py:424, 393-462)
+                        const size_t ci = (size_t)row * p.ldc + col;
+                        float o = v + bj;
+                        if constexpr (NB == 2) o = tanhf(o);
+                        else if constexpr (NB == 3) { const float y = p.aux[ci]; o = o * (1.0f - y * y); }
+                        else if constexpr (NB == 4) o = p.aux[ci] + o;
+                        Cz[ci] = o;
+                    }
                 }
             }
         }
@@ -698,13 +707,13 @@ __global__ __launch_bounds__(256 * KS) void gemm16_kernel(const GemmParams p, co
 }
 
 // dense backward: dX = dY.W^T tiles and the split-K slabs of dW = X^T.dY in ONE grid (independent GEMMs sharing dY)
-template <int WGM, int WGN, int TM, int TN, int BK, int WWGM, int WWGN, int WTM, int WTN>
+template <int WGM, int WGN, int TM, int TN, int BK, int WWGM, int WWGN, int WTM, int WTN, int ACTX = 1>
 __global__ __launch_bounds__(256) void dense_bwd16_kernel(const GemmParams px, const GemmParams pw, const int nx,
                                                           const int tw) {
     const int b = (int)blockIdx.x;
     TailEpiParams none{};
     if (b < nx) {
-        gemm16_block<OP_KCONTIG, OP_KCONTIG, WGM, WGN, TM, TN, BK, 1, 0, EPI_STORE, 1, false>(px, none, b, nx, 0, 0);
+        gemm16_block<OP_KCONTIG, OP_KCONTIG, WGM, WGN, TM, TN, BK, 1, 0, EPI_STORE, ACTX, false>(px, none, b, nx, 0, 0);
     } else {
         const int c = b - nx;
         gemm16_block<OP_ICONTIG, OP_ICONTIG, WWGM, WWGN, WTM, WTN, BK, 1, 1, EPI_STORE, 1, false>(pw, none, c % tw, tw,
@@ -733,10 +742,10 @@ static int set_smem_attr(K kern, size_t smem) {         // once per (device, ker
 }
 
 // plain launch of one configuration; smem_pad lets a caller force fewer resident blocks per CU (experiments)
-template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int TAG, int PD = 1>
+template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int TAG, int PD = 1, int ACT = 1>
 static int launch_gemm16(const GemmParams& p, int splits, hipStream_t s, size_t smem_min = 0) {
     using CF = Cfg16<KA, KB, WGM, WGN, TM, TN, BK, KS>;
-    auto kern = gemm16_kernel<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI_STORE, 1, false, TAG, PD>;
+    auto kern = gemm16_kernel<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI_STORE, ACT, false, TAG, PD>;
     size_t smem = CF::smem_bytes(0);
     if (smem < smem_min) smem = smem_min;
     DCCN_TRY(set_smem_attr(kern, smem));
@@ -764,12 +773,12 @@ static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hip
     return DCCN_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, int WWGM, int WWGN, int WTM, int WTN>
+template <int WGM, int WGN, int TM, int TN, int BK, int WWGM, int WWGN, int WTM, int WTN, int ACTX = 1>
 static int launch_dense_bwd16(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s,
                               size_t smem_min = 0) {
     using CX = Cfg16<OP_KCONTIG, OP_KCONTIG, WGM, WGN, TM, TN, BK, 1>;
     using CW = Cfg16<OP_ICONTIG, OP_ICONTIG, WWGM, WWGN, WTM, WTN, BK, 1>;
-    auto kern = dense_bwd16_kernel<WGM, WGN, TM, TN, BK, WWGM, WWGN, WTM, WTN>;
+    auto kern = dense_bwd16_kernel<WGM, WGN, TM, TN, BK, WWGM, WWGN, WTM, WTN, ACTX>;
     size_t smem = CX::smem_bytes(0) > CW::smem_bytes(0) ? CX::smem_bytes(0) : CW::smem_bytes(0);
     if (smem < smem_min) smem = smem_min;
     DCCN_TRY(set_smem_attr(kern, smem));

@@ -55,6 +55,9 @@ struct GemmParams {
     // optional optimizer epilogue (an UNSPLIT weight gradient of a large layer: the stored tile is the gradient of
     // ad_p[row*ldc + col]): the TF-Adam update of norm_adam.h, same operations in the same order, applied to the tile while
     // it is in registers -- the gradient needs no round trip through HBM and the optimizer launch skips the segment.
+    // gemm16.h store epilogue with an element-wise stage (template parameter NB of EPI_STORE: 2 tanh, 3 v (1 - aux^2),
+    // 4 v + aux): the other operand of stages 3 and 4, same shape and row stride as C
+    const float* aux;
     float* ad_p; float* ad_m; float* ad_v;
     const float* ad_reg; const float* ad_gate;
     const dccn_adam_state* ad_state;

@@ -176,6 +176,35 @@ int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal
                       unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
                       dccn_stream_t stream);
 
+/* ---- classical pilot-aided receivers: dev/m/OFDM_Benchmark_dev.m:339-456 ----------------------
+ * The estimator family the "DCCN vs LS / LMMSE" curves are drawn against, as device operators (the contractions -- DFT
+ * of the FFT window, pilot interpolation, long-term LMMSE smoothing -- are dccn_dense_fwd[_ld] calls on constant
+ * matrices; host mirror dl_ofdm_amd/benchmark_gpu.py, NumPy restatement = oracle: dl_ofdm_amd/benchmark.py).
+ * Y [n, S*K, 2] frequency-domain frames, pil [P] / dat [D] flat cell indices (symbol*K + carrier), H [n, S*K, 2] the
+ * channel's true response (Perfect / ideal LMMSE only).
+ *   dccn_dense_fwd_ld        dccn_dense_fwd with a row stride on x (a column window of wider rows: the FFT window)
+ *   dccn_classical_pilot_ls  gp [2][n][P] = Re / Im planes of Y[pilot] / pilot_value          (:345-352 LS at the pilots)
+ *   dccn_classical_gain      block partials (left in the workspace for _estimate) of the scalar mapping the unit-gain
+ *                            response onto the power-normalised frames and of sum |G_ls|^2; sums4 (nullable, device
+ *                            double[4]) = {Re, Im of sum Y_p conj(H_p pv), sum |H_p pv|^2, sum |G_ls|^2}
+ *   dccn_classical_estimate  mode 0 LS (planes -> interleaved), 1 ideal per-symbol LMMSE (:353-372), 2 ALMMSE (:437-446),
+ *                            3 Perfect, 4 frame mean V [n, K, 2] (input of the PDP variants :399-416); Gls [2][n][S*K]
+ *   dccn_classical_detect    x = Y / G at the data cells, nearest point of table [m, 2], labels [m, nbits]; det (nullable)
+ *                            [n, D, nbits]; errors[0] = bit errors against bits [n, D, nbits]; G rows of g_row cells per
+ *                            frame, cell index taken modulo g_mod when g_mod > 0 (one estimate row per frame)      */
+size_t dccn_classical_workspace_size(void);
+int dccn_dense_fwd_ld(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K, int N,
+                      dccn_stream_t stream);
+int dccn_classical_pilot_ls(const float* Y, const int* pil, float* gp, int n, int SK, int P, float pv_re, float pv_im,
+                            dccn_stream_t stream);
+int dccn_classical_gain(const float* Y, const float* H, const float* Gls, const int* pil, int n, int SK, int P, float pv_re,
+                        float pv_im, double* sums4, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+int dccn_classical_estimate(const float* Gls, const float* H, float* G, int n, int S, int K, int mode, float c_var,
+                            void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+int dccn_classical_detect(const float* Y, const float* G, const int* dat, const float* table, const int* labels,
+                          const int32_t* bits, int32_t* det, long long* errors, int n, int SK, int D, int m, int nbits,
+                          int g_row, int g_mod, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 /* One row of the sweep table {c00,c01,c10,c11,ce_sum,count} (float64, device): row6 += the metrics record of the
  * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);

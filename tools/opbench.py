@@ -34,8 +34,10 @@ def main():
     torch.cuda.synchronize()
     ops = op_launchers(eng)
     ops["step"] = (lambda: eng.train_step(), 0.0, "whole training step (eager launch sequence)")
+    ops["step_pipe"] = (lambda: eng.train_step_pipelined(), 0.0, "pipelined training step (what bench.py times)")
     t = HipTimer()
     for name in args.ops:
+        eng.drop_prefetch()
         fn = ops[name][0]
         for _ in range(5):
             fn()
