@@ -143,10 +143,10 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
 // radio.py:360-366: y = np.convolve(frame, g, 'same') over the frame's T = n_sym*n_sc samples
 // (y[t] = sum_l g[l] x[t + off - l], off = (L-1)//2, zero outside the frame) + per-block partial sums of
 // |y|^2 for the AWGN stage's power normalisation.  grid = (ceil(T/256), frames).
-// Persistent form: the grid is a fixed number of blocks (<= kChanPartials) that walk the (frame, 256-sample chunk) items
-// with a grid stride and leave ONE partial sum of |y|^2 each, in a fixed order -- few enough for the AWGN kernel to add
+// Persistent form: the grid is a fixed number of blocks (<= kChanPartials) that each walk a run of consecutive
+// (frame, 256-sample chunk) items and leave ONE partial sum of |y|^2 each, in a fixed order -- few enough for the AWGN kernel to add
 // them up itself (the separate sum_partials launch of rounds 1-2 is gone).  pbase: this launch's first slot in `partial`.
-constexpr int kChanPartials = 512;
+constexpr int kChanPartials = 1024;
 __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                        float2* __restrict__ y, double* __restrict__ partial, int T,
                                                        int L, const int* __restrict__ frames, int g_stride, int n_frames,
@@ -156,12 +156,18 @@ __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict_
     const int bx = (T + 255) / 256;
     const int off = (L - 1) / 2;
     double pw = 0.0;
-    for (int item = blockIdx.x; item < n_frames * bx; item += gridDim.x) {
+    // a block takes a run of consecutive items: mostly chunks of one frame, whose taps are loaded once
+    const int items = n_frames * bx, ipb = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    int cur = -1;
+    for (int item = blockIdx.x * ipb; item < min(items, ((int)blockIdx.x + 1) * ipb); ++item) {
         const int fi = item / bx, cb = item - fi * bx;
         const int fr = frames ? frames[fi] : fi;
-        __syncthreads();                                  // previous item's taps are no longer read
-        if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
-        __syncthreads();
+        if (fr != cur) {                                      // (block-uniform)
+            __syncthreads();                                  // previous frame's taps are no longer read
+            if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
+            __syncthreads();
+            cur = fr;
+        }
         const int t = cb * 256 + threadIdx.x;
         if (t < T) {
             const float2* xf = x + (size_t)fr * T;
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restri
     const int bx = (T + 255) / 256;
     const int off = (L - 1) / 2;
     double pw = 0.0;
-    for (int item = blockIdx.x; item < n_frames * bx; item += gridDim.x) {      // persistent: see fir_same_kernel
+    const int items = n_frames * bx, ipb = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int item = blockIdx.x * ipb; item < min(items, ((int)blockIdx.x + 1) * ipb); ++item) {      // persistent: see fir_same_kernel
         const int fi = item / bx, cb = item - fi * bx;
         const int fr = frames ? frames[fi] : fi;
         const int t = cb * 256 + threadIdx.x;

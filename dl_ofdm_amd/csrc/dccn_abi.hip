@@ -1741,9 +1741,9 @@ int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t
     return dense_fwd_impl(grid_ws, idft, nullptr, tx, frames * S, 2 * K, 2 * (K + CP), s);
 }
 static int chan_blocks_x(int T) { return ceil_div(T, 256); }
-// persistent FIR grid: all items when they are few, else two blocks per CU; never more than the partial slots
+// persistent FIR grid: all items when they are few, else four blocks per CU; never more than the partial slots
 static int fir_blocks(int items, int cap) {
-    int b = items < 2 * kCUs ? items : 2 * kCUs;
+    int b = items < 4 * kCUs ? items : 4 * kCUs;
     if (b > cap) b = cap;
     return b < 1 ? 1 : b;
 }

@@ -31,8 +31,11 @@ static EqDims eq_dims(const dccn_eq_shape* sh) {
                                  (long long)d.K * K2, K2,     // conv3d_2   (corr)
                                  (long long)d.K * K2, K2,     // conv3d_3   (equalized)
                                  4LL * d.K * N2, N2};         // dense_5
+    // every tensor starts on a 16-byte boundary (padding floats stay zero: zero gradient, zero Adam slots): the
+    // two-float bias of conv3d_1 used to shift conv3d_2 / conv3d_3 / dense_5 off it, and their five GEMMs onto the
+    // element-wise masked loaders -- 45 us of the 374 us step at 73 frames (profiles/r03_eq73_kernel_stats.txt)
     d.o[0] = 0;
-    for (int i = 0; i < 20; ++i) d.o[i + 1] = d.o[i] + sizes[i];
+    for (int i = 0; i < 20; ++i) d.o[i + 1] = (d.o[i] + sizes[i] + 3) / 4 * 4;
     return d;
 }
 

@@ -42,7 +42,7 @@ class _FusedPlan:
                              len(o.pilotCarriers))
         offs = (C.c_longlong * 21)()
         check(tr.lib.dccn_eq_param_offsets(C.byref(self.shape), offs), "dccn_eq_param_offsets")
-        assert offs[20] == tr.n_params and [offs[i] for i in range(20)] == [tr.layout[n][0] for n in tr.names]
+        assert offs[20] == tr.arena_size and [offs[i] for i in range(20)] == [tr.layout[n][0] for n in tr.names]
         f32 = dict(dtype=torch.float32, device=dev)
         B, S, n_sc = self.batch, F.nsymbol, o.K + o.CP
         self.x = torch.zeros(B, S, n_sc, 2, **f32)
@@ -139,9 +139,11 @@ class EqualizerTrainer:
     def _flatten(self):
         f32 = dict(dtype=torch.float32, device=self.device)
         sizes = [self.store.tensor(n).numel() for n in self.names]
-        total = int(sum(sizes))
-        self.n_params = total
-        self.params, self.grads = torch.empty(total, **f32), torch.zeros(total, **f32)
+        self.n_params = int(sum(sizes))
+        # every tensor starts on a 16-byte boundary of the arena (dccn_eq_param_offsets): vector loads for every layer
+        total = int(sum((sz + 3) // 4 * 4 for sz in sizes))
+        self.arena_size = total
+        self.params, self.grads = torch.zeros(total, **f32), torch.zeros(total, **f32)
         self.adam_m, self.adam_v = torch.zeros(total, **f32), torch.zeros(total, **f32)
         self.reg_coef = torch.zeros(total, **f32)
         self.layout, o = {}, 0
@@ -153,7 +155,7 @@ class EqualizerTrainer:
             if "/dense" in n:
                 self.reg_coef[o:o + sz] = EQ_REG_COEFF * 2.0 * REG_L2
             self.layout[n] = (o, tuple(p.shape))
-            o += sz
+            o += (sz + 3) // 4 * 4
 
     def view(self, name: str, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
         o, shp = self.layout[name]
@@ -213,7 +215,7 @@ class EqualizerTrainer:
     def _adam_step(self):
         check(self.lib.dccn_adam_tf_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                          self.adam_v.data_ptr(), self.reg_coef.data_ptr(), None,
-                                         self.adam_state.data_ptr(), self.hp, self.n_params,
+                                         self.adam_state.data_ptr(), self.hp, self.arena_size,
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
               "dccn_adam_tf_step")
 

@@ -13,6 +13,8 @@ import sys
 from collections import defaultdict
 
 OP_OF_KERNEL = [  # kernel-name substring -> bench.py operator key (C2 shapes)
+    ("rx_bwd_fused_kernel", "rx_backward"),
+    ("adam_rx_kernel", "adam_rx"),
     ("dense_bwd_grouped_km_kernel", "dense_bwd_slabs"),
     ("dense_bwd_grouped_kernel", "dense_bwd_slabs"),
     ("gemm16_kernel<1, 0, 1, 4, 3, 1, 64", "dense_tail_fwd_bwd"),
