@@ -74,6 +74,7 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
                  rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
                  timing: Optional[dict] = None):
     """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
+    eq_epochs <= 0: the reference driver's cap of 4000 * nbits epochs (run_local_ofdm.py:96; early stopping ends it sooner).
 
     world > 1: each chain is trained by its owner only (job_owners); the owner then broadcasts the two flat arenas
     (receiver 2.3 MB, equaliser 7 MB) and the other ranks build the same trainer around them.  Training is bitwise
@@ -89,7 +90,7 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         rf = R.Flags(nbits=nbits, nfilter=64, channel="AWGN", SNR=5.0 * nbits,
                      max_epoch_num=max(1, int(1200 * nbits * rx_epoch_scale)), early_stop=200, token="C5_%dmod" % nbits,
                      save_dir=save, device_data=True, seed=nbits)
-        hf = H.Flags(nbits=nbits, nfilter=64, channel="mixRayleigh", max_epoch_num=eq_epochs, early_stop=200,
+        hf = H.Flags(nbits=nbits, nfilter=64, channel="mixRayleigh", max_epoch_num=eq_epochs if eq_epochs > 0 else 4000 * nbits, early_stop=200,
                      token=rf.token, save_dir=save, device_data=True, seed=10 + nbits, test_frames=frames)
         flags[nbits] = (rf, hf)
         if owners[nbits] != rank:

@@ -12,6 +12,7 @@
 #include "gemm_kmajor.h"
 #include "rx_bwd.h"
 #include "equalizer.h"
+#include "eq_opt.h"
 #include "datagen.h"
 #include "im2col.h"
 #include "classical.h"
@@ -58,7 +59,9 @@ enum TuneKey : int {
     TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
     TUNE_NORM_ON_BWD = 18,      // 1: double-buffered pipelining: R0 of the next batch rides on the backward launch
     TUNE_EQ_EPILOGUES = 19,     // 1: equaliser step: tanh / tanh-gradient / gradient add in the epilogues of the few-row GEMMs
-    TUNE_COUNT = 20
+    TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
+                                //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
+    TUNE_COUNT = 21
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -81,7 +84,7 @@ struct TuneTable {
 //   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {1}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {1}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -386,8 +389,10 @@ static bool dense_bwd_stage_planned(int M, int K, int N) {
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
 static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                   int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer,
-                                  const AdamEpi* ae = nullptr, int actx = 1, const float* aux = nullptr, bool* act_done = nullptr) {
+                                  const AdamEpi* ae = nullptr, int actx = 1, const float* aux = nullptr, bool* act_done = nullptr,
+                                  float* split_dst = nullptr, long long split_pairs_gc = 0, bool* split_done = nullptr) {
     if (act_done) *act_done = false;
+    if (split_done) *split_done = false;
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     defer->adam_done = false;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
@@ -472,8 +477,17 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
         return dense_bwd_x_impl(dy, w, dx, M, K, N, s);
     }
     pw.ldc = N;
-    if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && kmajor_ok(pw)) DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
-    else DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
+    if (g_tune[TUNE_DENSE_BWD] == kVariantKmajor && kmajor_ok(pw)) {
+        if (split_done && split_dst && split_pairs_gc != 0 && (K % 4 == 0)) {
+            // dx is the gradient of a concat of two IQ-pair streams: the stores write the two streams' own buffers
+            // instead of dx (split_dst = stream 0, [M, K/2]; stream 1 split_pairs_gc elements further)
+            px.C = split_dst; px.ldc = K / 2; px.gC = split_pairs_gc;
+            *split_done = true;
+            DCCN_TRY((launch_dense_bwd_grouped_km<64, CMAP_SPLIT_PAIRS>(px, pw, sp.splits, s)));
+        } else {
+            DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
+        }
+    } else DCCN_TRY(launch_dense_bwd_grouped<true>(px, pw, sp.splits, s));
     defer->dw_slabs = slabs;
     defer->db_slabs = dbias ? cs : nullptr;
     defer->splits = sp.splits;
@@ -658,6 +672,10 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         DCCN_TRY((launch_kmajor<1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
     else
         DCCN_TRY((launch_gemm<OP_ICONTIG, OP_ICONTIG, 1, TAG_CCONV_BWD_W>(p, sp.splits, s)));
+    if (defer && !fin) {                     // the caller's optimizer launch folds the slabs (eq_opt.h)
+        defer->slabs = slabs; defer->colsum = cs; defer->splits = sp.splits; defer->slab = p.slab;
+        return DCCN_OK;
+    }
     const int nthreads = kin * F + F;
     const int fold_blocks = ceil_div(nthreads, kRedLanes);
     if (fin)
@@ -667,6 +685,83 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
         hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, slabs, sp.splits, p.slab, cs, dw, dbias,
                            kin, F);
     DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// same-shaped C-Conv layers as grouped launches (the equaliser's corr / eq pair, model.py:439-449)
+// ---------------------------------------------------------------------------------------
+// forward of `groups` (1,kin)->F C-Convs: operands of group g at element strides gx / gw / gb from group 0.
+// join_pairs: the two outputs are the IQ-pair streams of ONE [rows, F, 4] tensor (tf.concat on the last axis,
+// model.py:456): out = that tensor, group g writes floats 2g, 2g+1 of every cell.  Returns false when the shapes do
+// not qualify for the grouped kernels (the caller then runs the layers one by one).
+static bool cconv_pair_ok(const float* x, const float* w, const float* o, int rows, int kin, int F, long long gx, long long gw,
+                          long long go) {
+    return (kin % 2 == 0) && (F % 2 == 0) && (kin % 32 == 0) && (F % 32 == 0) && aligned16(x) && aligned16(w) && aligned16(o) &&
+           (gx % 4 == 0) && (gw % 4 == 0) && (go % 2 == 0) && small_enough(rows, 4LL * (kin > F ? kin : F)) &&
+           small_enough(kin, 2LL * F) && (long long)ceil_div(rows, 128) * ceil_div(2 * F, 128) < 2 * kCUs;
+}
+static int cconv_fwd_grouped_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
+                                  int groups, long long gx, long long gw, long long gb, bool join_pairs, hipStream_t s) {
+    if (!x || !w || !out || rows <= 0 || groups < 1 || groups > 2 || (join_pairs && groups != 2)) return DCCN_ERR_INVALID_ARG;
+    GemmParams p = gp_zero();                 // out_g[rows,2F] = x_g[rows,2kin] . Weff_g[2kin,2F]
+    p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
+    p.M = rows; p.N = 2 * F; p.K = 2 * kin;
+    p.lda = 2 * kin; p.ldb = 2 * F; p.ldc = join_pairs ? 4 * F : 2 * F;
+    p.klen = round_k(2 * kin);
+    p.cF = F;
+    p.vecA = 1; p.vecB = 1;
+    GroupStride gs;
+    gs.a = gx; gs.b = gw; gs.bias = gb; gs.colsum = 0;
+    gs.c = join_pairs ? 2 : (long long)rows * 2 * F;
+    if (join_pairs) {
+        if (p.K == 128 && g_whole_k)
+            return launch_gemm_grouped<OP_KCONTIG, OP_CCONV_W, 64, 64, 128, TAG_CCONV_FWD, 1, CMAP_JOIN_PAIRS>(p, gs, groups, s);
+        return launch_gemm_grouped<OP_KCONTIG, OP_CCONV_W, 64, 64, 64, TAG_CCONV_FWD, 2, CMAP_JOIN_PAIRS>(p, gs, groups, s);
+    }
+    return launch_gemm_grouped<OP_KCONTIG, OP_CCONV_W, 64, 64, 64, TAG_CCONV_FWD, 2, CMAP_NONE>(p, gs, groups, s);
+}
+
+// backward of `groups` (1,kin)->F C-Convs in ONE launch: dx_g = dout_g . Weff_g^T and the split-K slabs of
+// dWeff_g = x_g^T . dout_g (+ column sums), left un-folded in ws for the optimizer launch (defer[g]).
+// Strides in elements: gx (x and dx), gd (dout), gw (kernels).
+static size_t cconv_bwd_grouped_ws_bytes(int rows, int kin, int F, int groups) {
+    return (size_t)groups * cconv_bw_ws_bytes(rows, kin, F);
+}
+static int cconv_bwd_grouped_impl(const float* x, const float* dout, const float* w, float* dx, int rows, int kin, int F,
+                                  int groups, long long gx, long long gd, long long gw, void* ws, size_t ws_bytes,
+                                  FoldDefer* defer, hipStream_t s) {
+    if (!x || !dout || !w || !dx || !defer || rows <= 0 || groups < 1 || groups > 2) return DCCN_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < cconv_bwd_grouped_ws_bytes(rows, kin, F, groups)) return DCCN_ERR_WORKSPACE;
+    SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    if (sp.splits > kCconvBwMaxSplits) return DCCN_ERR_STATE;
+    const size_t per = cconv_bw_ws_bytes(rows, kin, F) / sizeof(float);
+    float* slabs = static_cast<float*>(ws);
+    float* cs = slabs + (size_t)sp.splits * 4 * kin * F;
+    GemmParams px = gp_zero();                // dx[rows,2kin] = dout[rows,2F] . Weff^T
+    px.A = dout; px.B = w; px.C = dx;
+    px.M = rows; px.N = 2 * kin; px.K = 2 * F;
+    px.lda = 2 * F; px.ldb = 2 * F; px.ldc = 2 * kin;
+    px.klen = round_k(2 * F);
+    px.cF = F;
+    px.vecA = 1; px.vecB = 1;
+    GroupStride g1;
+    g1.a = gd; g1.b = gw; g1.c = gx; g1.bias = 0; g1.colsum = 0;
+    GemmParams pw = gp_zero();                // dWeff[2kin,2F] = x[rows,2kin]^T . dout[rows,2F]
+    pw.A = x; pw.B = dout; pw.C = slabs; pw.colsum = cs;
+    pw.M = 2 * kin; pw.N = 2 * F; pw.K = rows;
+    pw.lda = 2 * kin; pw.ldb = 2 * F; pw.ldc = 2 * F;
+    pw.klen = sp.klen;
+    pw.slab = (long long)4 * kin * F;
+    pw.vecA = 1; pw.vecB = 1;
+    if (!kmajor_ok(pw)) return DCCN_ERR_STATE;
+    GroupStride g2;
+    g2.a = gx; g2.b = gd; g2.c = (long long)per; g2.bias = 0; g2.colsum = (long long)per;
+    DCCN_TRY(launch_cconv_bwd_grouped_km<64>(px, g1, pw, g2, sp.splits, groups, s));
+    for (int g = 0; g < groups; ++g) {
+        defer[g].slabs = slabs + (size_t)g * per; defer[g].colsum = cs + (size_t)g * per;
+        defer[g].splits = sp.splits; defer[g].slab = pw.slab;
+    }
     return DCCN_OK;
 }
 

@@ -1,0 +1,257 @@
+// The equaliser step's LAST launch: every gradient reduction that used to be its own 5 us kernel (three C-Conv folds,
+// the split-K sums of the dense layers, the fold of the block-Toeplitz smoothing layer, the tail's metric reduction)
+// and the TF-Adam update of all 20 Equalizer/* variables (ofdmreceiver_np_mp.py:330) as ONE grid driven by a job table.
+// A job is a contiguous run of blocks that produces the gradient of one arena segment from where the backward GEMMs
+// left it and applies the update to those elements right away -- each parameter is read and written once, by the
+// thread that reduced its gradient; no job depends on another, so there is nothing to order inside the launch.
+//
+//   EQJ_SUM           g[i] = sum_z src[z*slab + i]  (fixed order), or the gradient arena itself (src == nullptr)
+//   EQJ_CCONV_FOLD    Appendix A.2 fold of the dWeff slabs of a (1,K) C-Conv into [Wa|Wb] and its bias pair
+//   EQJ_CONV2D_FOLD   transpose of the block-Toeplitz expansion of the (S,K) smoothing C-Conv (one wave per tap)
+//   EQJ_TAIL_FINALIZE the demodulation tail's per-block metrics -> dccn_metrics (no parameters: the receiver is frozen)
+#pragma once
+#include "gemm_f32_mfma.h"
+#include "tail.h"
+
+namespace dccn {
+
+enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3 };
+struct EqOptJob {
+    int kind, block0, blocks, splits;
+    long long off, n;        // arena segment of the (first) variable
+    long long off_b;         // folds: arena offset of the bias variable
+    const float* src;        // slabs (SUM: nullptr = the gradient arena holds the finished gradient)
+    const float* src2;       // folds: column-sum slabs
+    long long slab, slab2;   // elements between consecutive slabs of src / src2
+    int kin, F;              // CCONV_FOLD: kin, F; CONV2D_FOLD: L, W
+};
+constexpr int kEqOptJobs = 24;
+struct EqOptArgs {
+    float* param; float* grad; float* m; float* v;
+    const float* reg_coef;
+    const dccn_adam_state* state;
+    int njobs;
+    EqOptJob job[kEqOptJobs];
+    TailFinalizeArgs fin;
+};
+
+struct AdamCoef {
+    float alpha, omb1, omb2, eps;
+};
+__device__ __forceinline__ void eq_adam_one(const EqOptArgs& a, const AdamCoef& k, const long long j, const float g) {
+    float p = a.param[j], mm = a.m[j], vv = a.v[j];
+    const float ge = g + (a.reg_coef ? a.reg_coef[j] : 0.f) * p;
+    mm += (ge - mm) * k.omb1;
+    vv += (ge * ge - vv) * k.omb2;
+    p -= (mm * k.alpha) / (sqrtf(vv) + k.eps);
+    a.param[j] = p; a.m[j] = mm; a.v[j] = vv;
+}
+
+__device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
+    const long long stride = (long long)J.blocks * 256 * 4;
+    for (long long i = ((long long)bx * 256 + threadIdx.x) * 4; i < J.n; i += stride) {
+        const long long j = J.off + i;
+        if (i + 4 <= J.n) {                        // (segments start on 16-byte boundaries: eq_dims)
+            const float4 p4 = *reinterpret_cast<const float4*>(a.param + j);
+            const float4 m4 = *reinterpret_cast<const float4*>(a.m + j);
+            const float4 v4 = *reinterpret_cast<const float4*>(a.v + j);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + j);
+            float4 g4;
+            if (J.src) {
+                // the summation order of splitk_reduce_body (four interleaved runs, then 0+1+2+3): the step's gradients
+                // are bit-identical to those of the launch-per-stage plan
+                float4 run[kRedGroups];
+#pragma unroll
+                for (int r = 0; r < kRedGroups; ++r) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int z = r; z < J.splits; z += kRedGroups) {
+                        const float4 u = *reinterpret_cast<const float4*>(J.src + (size_t)z * J.slab + i);
+                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    }
+                    run[r] = t;
+                }
+                g4 = run[0];
+#pragma unroll
+                for (int r = 1; r < kRedGroups; ++r) { g4.x += run[r].x; g4.y += run[r].y; g4.z += run[r].z; g4.w += run[r].w; }
+                *reinterpret_cast<float4*>(a.grad + j) = g4;
+            } else {
+                g4 = *reinterpret_cast<const float4*>(a.grad + j);
+            }
+            float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = g[e] + cc[e] * p[e];
+                mm[e] += (ge - mm[e]) * k.omb1;
+                vv[e] += (ge * ge - vv[e]) * k.omb2;
+                p[e] -= (mm[e] * k.alpha) / (sqrtf(vv[e]) + k.eps);
+            }
+            *reinterpret_cast<float4*>(a.param + j) = make_float4(p[0], p[1], p[2], p[3]);
+            *reinterpret_cast<float4*>(a.m + j) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(a.v + j) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            for (long long e = i; e < J.n; ++e) {
+                float g;
+                if (J.src) {
+                    float run[kRedGroups];
+                    for (int r = 0; r < kRedGroups; ++r) {
+                        float t = 0.f;
+                        for (int z = r; z < J.splits; z += kRedGroups) t += J.src[(size_t)z * J.slab + e];
+                        run[r] = t;
+                    }
+                    g = run[0];
+                    for (int r = 1; r < kRedGroups; ++r) g += run[r];
+                    a.grad[J.off + e] = g;
+                } else {
+                    g = a.grad[J.off + e];
+                }
+                eq_adam_one(a, k, J.off + e, g);
+            }
+        }
+    }
+}
+
+// element i of a split-K result, summed in splitk_reduce_body's order
+__device__ __forceinline__ float slab_sum(const float* __restrict__ src, const size_t i, const int splits, const long long slab) {
+    float run[kRedGroups];
+#pragma unroll
+    for (int r = 0; r < kRedGroups; ++r) {
+        float t = 0.f;
+        for (int z = r; z < splits; z += kRedGroups) t += src[(size_t)z * slab + i];
+        run[r] = t;
+    }
+    return ((run[0] + run[1]) + run[2]) + run[3];
+}
+
+// dev/py/complex.py:185-188 with a (S,K) kernel, 'same' padding, one filter, expanded to T[(s',k',iq)][(s,k,re/im)]
+// (equalizer.h cconv2d_same_expand_kernel); its transpose: tap (a,b) gathers its diagonal of dT
+__device__ __forceinline__ void eq_opt_conv2d(const EqOptArgs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
+    const int L = J.kin, W = J.F, n = L * W * 2;
+    const int padL = (L - 1) / 2, padW = (W - 1) / 2;
+    const int tap = bx * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tap > L * W) return;
+    if (tap == L * W) {                              // bias pair: d = sum_c (dbe[2c] - dbe[2c+1])
+        float d = 0.f;
+        for (int c = lane; c < L * W; c += 64)
+            d += slab_sum(J.src2, 2 * c, J.splits, J.slab2) - slab_sum(J.src2, 2 * c + 1, J.splits, J.slab2);
+        d = wave_sum(d);
+        if (lane == 0) {
+            a.grad[J.off_b] = d;
+            a.grad[J.off_b + 1] = -d;
+            eq_adam_one(a, k, J.off_b, d);
+            eq_adam_one(a, k, J.off_b + 1, -d);
+        }
+        return;
+    }
+    const int ta = tap / W, tb = tap % W;
+    float ga = 0.f, gb = 0.f;
+    for (int c = lane; c < L * W; c += 64) {
+        const int s = c / W, kk = c % W;
+        const int sp = s + ta - padL, kp = kk + tb - padW;
+        if (sp < 0 || sp >= L || kp < 0 || kp >= W) continue;
+        const size_t r0 = (size_t)((sp * W + kp) * 2) * n + (size_t)c * 2;
+        // d/dWa: (I->re) - (Q->im), d/dWb: (I->im) - (Q->re); each dT element = the split-K sum of its slabs
+        ga += slab_sum(J.src, r0, J.splits, J.slab) - slab_sum(J.src, r0 + n + 1, J.splits, J.slab);
+        gb += slab_sum(J.src, r0 + 1, J.splits, J.slab) - slab_sum(J.src, r0 + n, J.splits, J.slab);
+    }
+    ga = wave_sum(ga);
+    gb = wave_sum(gb);
+    if (lane == 0) {
+        a.grad[J.off + tap * 2] = ga;
+        a.grad[J.off + tap * 2 + 1] = gb;
+        eq_adam_one(a, k, J.off + tap * 2, ga);
+        eq_adam_one(a, k, J.off + tap * 2 + 1, gb);
+    }
+}
+
+__global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dccn_adam_hparams hp) {
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].block0) ++j;      // (block-uniform scan of the table)
+    const EqOptJob& J = a.job[j];
+    const int bx = (int)blockIdx.x - J.block0;
+    if (J.kind == EQJ_TAIL_FINALIZE) {
+        demod_tail_finalize_body(a.fin, bx);
+        return;
+    }
+    AdamCoef k;
+    k.alpha = a.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
+    if (J.kind == EQJ_SUM) {
+        eq_opt_sum(a, J, k, bx);
+    } else if (J.kind == EQJ_CCONV_FOLD) {
+        long long idx[2];
+        float gv[2];
+        cconv_fold_body<kRedLanes>(J.src, J.splits, J.slab, J.src2, a.grad + J.off, a.grad + J.off_b, J.kin, J.F, bx, idx, gv, 0);
+        const long long nw = (long long)J.kin * 2 * J.F;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (idx[e] < 0) continue;
+            eq_adam_one(a, k, idx[e] < nw ? J.off + idx[e] : J.off_b + (idx[e] - nw), gv[e]);
+        }
+    } else {
+        eq_opt_conv2d(a, J, k, bx);
+    }
+}
+
+// host side: the table is built per step from what the backward GEMMs report
+struct EqOptBuilder {
+    EqOptArgs a;
+    int blocks = 0;
+    int status = DCCN_OK;
+    EqOptJob* add(int kind, int nblocks) {
+        if (a.njobs >= kEqOptJobs) { status = DCCN_ERR_STATE; return nullptr; }
+        EqOptJob* J = &a.job[a.njobs++];
+        memset(J, 0, sizeof(*J));
+        J->kind = kind; J->block0 = blocks; J->blocks = nblocks;
+        blocks += nblocks;
+        return J;
+    }
+    static int stream_blocks(long long n) {
+        long long b = ceil_div_ll(ceil_div_ll(n, 4), 256);
+        if (b > 2 * kCUs) b = 2 * kCUs;
+        return (int)(b < 1 ? 1 : b);
+    }
+    // [off, off+n): finished gradient in the arena (adjacent segments merge into one job)
+    void plain(long long off, long long n) {
+        if (a.njobs > 0) {
+            EqOptJob& P = a.job[a.njobs - 1];
+            if (P.kind == EQJ_SUM && P.src == nullptr && P.off + P.n <= off && off - (P.off + P.n) < 4) {
+                blocks -= P.blocks;                     // (the gap is alignment padding: zero gradient, zero state)
+                P.n = off + n - P.off;
+                P.blocks = stream_blocks(P.n);
+                blocks += P.blocks;
+                return;
+            }
+        }
+        EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
+        if (J) { J->off = off; J->n = n; J->splits = 1; }
+    }
+    void slabs(long long off, long long n, const float* src, int splits, long long slab) {
+        EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
+        if (J) { J->off = off; J->n = n; J->src = src; J->splits = splits; J->slab = slab; }
+    }
+    void cconv_fold(long long off, long long off_b, const float* slabs_, const float* colsum, int splits, long long slab,
+                    int kin, int F) {
+        EqOptJob* J = add(EQJ_CCONV_FOLD, ceil_div(kin * F + F, kRedLanes));
+        if (J) { J->off = off; J->off_b = off_b; J->src = slabs_; J->src2 = colsum; J->splits = splits; J->slab = slab; J->kin = kin; J->F = F; }
+    }
+    void conv2d_fold(long long off, long long off_b, const float* dT, const float* dbe, int splits, long long slab,
+                     long long slab2, int L, int W) {
+        EqOptJob* J = add(EQJ_CONV2D_FOLD, ceil_div(L * W + 1, 4));
+        if (J) { J->off = off; J->off_b = off_b; J->src = dT; J->src2 = dbe; J->splits = splits; J->slab = slab; J->slab2 = slab2; J->kin = L; J->F = W; }
+    }
+    void tail_finalize(const TailFinalizeArgs& fin) {
+        EqOptJob* J = add(EQJ_TAIL_FINALIZE, tail_finalize_blocks(fin.P));
+        if (J) a.fin = fin;
+    }
+};
+
+static int launch_eq_opt(EqOptBuilder& b, dccn_adam_hparams hp, hipStream_t s) {
+    if (b.status != DCCN_OK) return b.status;
+    if (b.blocks <= 0) return DCCN_OK;
+    hipLaunchKernelGGL(eq_opt_kernel, dim3((unsigned)b.blocks), dim3(256), 0, s, b.a, hp);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+}  // namespace dccn

@@ -14,6 +14,7 @@ static bool eq_shape_ok(const dccn_eq_shape* sh) {
 struct EqDims {
     int B, S, K, nsc, R, SK2, Pp, F, D, cp, win;     // win: float offset of the post-CP window inside a row
     long long o[21];        // parameter offsets, TF creation order (dense, conv3d, dense_1..4, conv3d_1..3, dense_5)
+    long long sz[20];       // element counts (o[i+1] - o[i] may include up to three floats of alignment padding)
 };
 static EqDims eq_dims(const dccn_eq_shape* sh) {
     EqDims d;
@@ -35,29 +36,30 @@ static EqDims eq_dims(const dccn_eq_shape* sh) {
     // two-float bias of conv3d_1 used to shift conv3d_2 / conv3d_3 / dense_5 off it, and their five GEMMs onto the
     // element-wise masked loaders -- 45 us of the 374 us step at 73 frames (profiles/r03_eq73_kernel_stats.txt)
     d.o[0] = 0;
-    for (int i = 0; i < 20; ++i) d.o[i + 1] = (d.o[i] + sizes[i] + 3) / 4 * 4;
+    for (int i = 0; i < 20; ++i) { d.o[i + 1] = (d.o[i] + sizes[i] + 3) / 4 * 4; d.sz[i] = sizes[i]; }
     return d;
 }
 
+// weight-gradient workspaces, one per trainable layer (their slabs stay live until the optimizer launch reduces them)
+enum EqLayer : int { EQL_DENSE = 0, EQL_CONV, EQL_DENSE1, EQL_DENSE2, EQL_DENSE3, EQL_DENSE4, EQL_SMOOTH, EQL_PAIR, EQL_DENSE5,
+                     EQL_COUNT };
 struct EqWs {
-    void *ws_norm, *ws_tail, *ws_split;
-    size_t n_norm, n_tail, n_split;
+    void *ws_norm, *ws_tail;
+    void* ws_l[EQL_COUNT];
+    size_t n_norm, n_tail, n_l[EQL_COUNT];
     float *x_norm, *ln, *t1, *y, *d1, *d2, *d3, *d4, *T, *be, *eq, *corr, *eqc, *corc, *cat, *fft, *z;
     // training only
     float *dz, *dfft, *dout, *dcat, *deqc, *dcorc, *deq, *dcorr, *dy, *dh, *dT, *dbe, *dd4, *dd3, *dd2, *dd1,
         *dflat, *dt1, *dtail;
 };
-static size_t eq_split_ws(const EqDims& d) {
-    size_t m = 0;
-    auto upd = [&](int Mo, int No, int Kr) { const size_t v = splitk_ws_bytes(Mo, No, Kr); if (v > m) m = v; };
-    upd(d.cp ? 2 * d.nsc : 2 * d.K, 2 * d.K, d.R);   // dense
-    upd(2 * d.K, 2 * d.K, d.R);            // the three (1,K) C-Convs
-    { const size_t v = cconv_bw_ws_bytes(d.R, d.K, d.K); if (v > m) m = v; }
-    upd(d.SK2, d.Pp, d.B);
-    upd(d.Pp, d.SK2, d.B);
-    upd(d.SK2, d.SK2, d.B);                // dense_3, dense_4, Toeplitz
-    upd(4 * d.K, 2 * d.nsc, d.R);          // dense_5
-    return m;
+static void eq_layer_ws(const EqDims& d, size_t (&n)[EQL_COUNT]) {
+    n[EQL_DENSE] = splitk_ws_bytes(d.cp ? 2 * d.nsc : 2 * d.K, 2 * d.K, d.R);
+    n[EQL_CONV] = cconv_bwd_grouped_ws_bytes(d.R, d.K, d.K, 1);
+    n[EQL_DENSE1] = splitk_ws_bytes(d.SK2, d.Pp, d.B);
+    n[EQL_DENSE2] = splitk_ws_bytes(d.Pp, d.SK2, d.B);
+    n[EQL_DENSE3] = n[EQL_DENSE4] = n[EQL_SMOOTH] = splitk_ws_bytes(d.SK2, d.SK2, d.B);
+    n[EQL_PAIR] = cconv_bwd_grouped_ws_bytes(d.R, d.K, d.K, 2);           // corr and eq C-Convs
+    n[EQL_DENSE5] = splitk_ws_bytes(4 * d.K, 2 * d.nsc, d.R);
 }
 static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool train, EqWs& w) {
     const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
@@ -67,10 +69,10 @@ static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool t
         const size_t f = dense_tail_ws_bytes(d.B, 2 * d.D, sh->nbits);
         if (f > w.n_tail) w.n_tail = f;
     }
-    w.n_split = train ? eq_split_ws(d) : 0;
     w.ws_norm = c.take<char>(w.n_norm);
     w.ws_tail = c.take<char>(w.n_tail);
-    w.ws_split = train ? c.take<char>(w.n_split) : nullptr;
+    eq_layer_ws(d, w.n_l);
+    for (int l = 0; l < EQL_COUNT; ++l) w.ws_l[l] = train ? c.take<char>(w.n_l[l]) : nullptr;
     w.x_norm = c.take<float>(R * N2);
     w.ln = c.take<float>(R * N2);
     w.t1 = c.take<float>(R * K2);
@@ -119,13 +121,26 @@ static size_t eq_ws_bytes(const dccn_eq_shape* sh, int train) {
 
 // dense backward with reduced outputs: dx (nullable: weight gradient only), dw, dbias
 // actx / aux / act_done: optional element-wise stage on the dX store (dense_bwd_grouped_impl)
+// keep: leave split-K slabs un-reduced and report them (the optimizer launch sums them, eq_opt.h)
+// split_dst / split_gc / split_done: dx is the gradient of a concat of two IQ-pair streams; when the launch plan has the
+// stage, the streams' own buffers are written instead of dx (dense_bwd_grouped_impl)
 static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, int actx = 1,
-                               const float* aux = nullptr, bool* act_done = nullptr) {
+                               const float* aux = nullptr, bool* act_done = nullptr, DeferredSlabs* keep = nullptr,
+                               float* split_dst = nullptr, long long split_gc = 0, bool* split_done = nullptr) {
     if (act_done) *act_done = false;
-    if (!dx) return dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s);
+    if (split_done) *split_done = false;
     DeferredSlabs ds;
-    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds, nullptr, actx, aux, act_done));
+    if (!dx) {
+        DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, keep));
+        return DCCN_OK;
+    }
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds, nullptr, actx, aux, act_done,
+                                    split_dst, split_gc, split_done));
+    if (keep) {
+        *keep = ds;
+        return DCCN_OK;
+    }
     if (ds.dw_slabs) {
         const long long n = (long long)K * N;
         if (dbias && ds.db_slabs)
@@ -134,6 +149,14 @@ static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, 
             DCCN_TRY(launch_splitk_reduce(ds.dw_slabs, ds.splits, n, dw, n, s));
     }
     return DCCN_OK;
+}
+
+// optimizer jobs of a dense layer (kernel variable i, bias variable i + 1)
+static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const DeferredSlabs& ds, long long N) {
+    if (ds.dw_slabs) ob.slabs(d.o[i], d.sz[i], ds.dw_slabs, ds.splits, d.sz[i]);
+    else ob.plain(d.o[i], d.sz[i]);
+    if (ds.dw_slabs && ds.db_slabs) ob.slabs(d.o[i + 1], d.sz[i + 1], ds.db_slabs, ds.splits, N);
+    else ob.plain(d.o[i + 1], d.sz[i + 1]);
 }
 
 static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool train, dccn_adam_hparams hp,
@@ -158,15 +181,31 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     const float* Q = b->rx_params;
     float* h = b->chest;
 
+    // round-3 plan (TUNE_EQ_REPLAN): merged element-wise launches, the corr / eq C-Conv pair as grouped launches with the
+    // concat / split of model.py:456 in the GEMM stores, ONE job-table launch for every gradient reduction + Adam
+    const bool replan = g_tune[TUNE_EQ_REPLAN] != 0;
+    const bool keep_slabs = g_tune[TUNE_EQ_REPLAN] == 1;     // 2: the plan with every dense split-K sum as its own launch (debugging)
+    const long long g_in = w.corr - w.eq;                                  // eq -> corr stride of the pair's tensors
+    const long long g_w = d.o[14] - d.o[16], g_b = d.o[15] - d.o[17];      // conv3d_3 (eq) -> conv3d_2 (corr)
+    const bool pair = replan && cconv_pair_ok(w.eq, P + d.o[16], w.cat, R, K, K, g_in, g_w, 2) && aligned16(w.corr) &&
+                      (g_b % 2 == 0);
+
     // `input:0` (ofdmreceiver_np.py:128-137) + tx_power partials
     PowerPartials pp;
     // (training: the optimizer's per-step bookkeeping rides on this first launch)
     DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, d.S * N2, 1e-9f, 8.0f,
                        train ? b->adam : nullptr, hp, w.ws_norm, w.n_norm, s));
-    // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"
-    hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
-                       (float*)nullptr, d.S * N2, 1e-12f);
-    DCCN_LAUNCH_CHECK();
+    // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"; the expansion of the :428 smoothing C-Conv (S x K, same)
+    // into the block-Toeplitz matrix of a dense layer depends on the parameters only and shares the launch
+    if (replan) {
+        hipLaunchKernelGGL(eq_prep_kernel, dim3(B + ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s, (const float*)w.x_norm,
+                           w.ln, B, d.S * N2, 1e-12f, P + d.o[12], P + d.o[13], w.T, w.be, d.S, K);
+        DCCN_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
+                           (float*)nullptr, d.S * N2, 1e-12f);
+        DCCN_LAUNCH_CHECK();
+    }
     DCCN_TRY(dense_fwd_impl(w.ln + d.win, P + d.o[0], P + d.o[1], w.t1, R, kin0, K2, s, N2));
     DCCN_TRY(cconv_fwd_impl(w.t1, P + d.o[2], P + d.o[3], w.y, R, K, K, s));
     // :394-426 pilot bottleneck
@@ -181,34 +220,53 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
             DCCN_LAUNCH_CHECK();
         }
     }
-    // :428 smoothing C-Conv (S x K, same) as a block-Toeplitz dense layer -> channel estimate
-    hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s,
-                       P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
-    DCCN_LAUNCH_CHECK();
-    DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s));
-    // :431-438 equalise + autocorrelation
-    hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
-                       (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2);
-    DCCN_LAUNCH_CHECK();
-    if (b->snr_db && b->pilot_carriers && sh->P > 0) {
-        hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
-                           d.S, K, sh->P);
+    // :428 smoothing C-Conv as a dense layer -> channel estimate
+    if (!replan) {
+        hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s,
+                           P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
         DCCN_LAUNCH_CHECK();
     }
+    DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s));
+    // :431-438 equalise + autocorrelation, :465-475 pilot monitor
+    const bool want_snr = b->snr_db && b->pilot_carriers && sh->P > 0;
+    if (replan && want_snr) {
+        const int eb = (int)ew_blocks_n(nBK / 2);
+        hipLaunchKernelGGL(equalize_fwd_snr_kernel, dim3(eb + ceil_div(B, 4)), dim3(256), 0, s, (const float2*)w.y,
+                           (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2, eb, b->pilot_carriers, b->snr_db, B,
+                           d.S, K, sh->P);
+        DCCN_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
+                           (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2);
+        DCCN_LAUNCH_CHECK();
+        if (want_snr) {
+            hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
+                               d.S, K, sh->P);
+            DCCN_LAUNCH_CHECK();
+        }
+    }
     // :439-449 C-Conv "IDFT" of corr and eq, :456-463 concat + dense back to the receiver's input
-    DCCN_TRY(cconv_fwd_impl(w.corr, P + d.o[14], P + d.o[15], w.corc, R, K, K, s));
-    DCCN_TRY(cconv_fwd_impl(w.eq, P + d.o[16], P + d.o[17], w.eqc, R, K, K, s));
-    hipLaunchKernelGGL(concat_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float2*)w.eqc,
-                       (const float2*)w.corc, (float4*)w.cat, (long long)R * K);
-    DCCN_LAUNCH_CHECK();
+    if (pair) {
+        // both C-Convs in one grid; their stores interleave the two IQ-pair streams into cat = [.., K, (eq, corr)]
+        DCCN_TRY(cconv_fwd_grouped_impl(w.eq, P + d.o[16], P + d.o[17], w.cat, R, K, K, 2, g_in, g_w, g_b, true, s));
+    } else {
+        DCCN_TRY(cconv_fwd_impl(w.corr, P + d.o[14], P + d.o[15], w.corc, R, K, K, s));
+        DCCN_TRY(cconv_fwd_impl(w.eq, P + d.o[16], P + d.o[17], w.eqc, R, K, K, s));
+        hipLaunchKernelGGL(concat_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float2*)w.eqc,
+                           (const float2*)w.corc, (float4*)w.cat, (long long)R * K);
+        DCCN_LAUNCH_CHECK();
+    }
     DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
     // frozen basic receiver (model.py:1222-1292) + loss/BER
     DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
+    TailFinalizeArgs fin;
+    bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
     if (dense_tail_planned(sh->nbits, train) &&
         dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
+        fin_deferred = replan && train;
         DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
                                  b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, L.dK, L.dN, sh->nbits,
-                                 &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+                                 &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? &fin : nullptr));
     } else {
         DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
         DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
@@ -224,52 +282,97 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         DCCN_LAUNCH_CHECK();
     }
     DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout + d.win, R, rsh.kin, d.F, s, N2));
-    // ... then the equaliser, last layer first
-    DCCN_TRY(dense_bwd_full_impl(w.cat, w.dout, P + d.o[18], w.dcat, G + d.o[18], G + d.o[19], R, 4 * K, N2, w.ws_split,
-                                 w.n_split, s));
-    hipLaunchKernelGGL(split_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float4*)w.dcat,
-                       (float2*)w.deqc, (float2*)w.dcorc, (long long)R * K);
-    DCCN_LAUNCH_CHECK();
-    DCCN_TRY(cconv_bwd_x_impl(w.deqc, P + d.o[16], w.deq, R, K, K, s));
-    DCCN_TRY(cconv_bwd_w_impl(w.eq, w.deqc, G + d.o[16], G + d.o[17], R, K, K, w.ws_split, w.n_split, s));
-    DCCN_TRY(cconv_bwd_x_impl(w.dcorc, P + d.o[14], w.dcorr, R, K, K, s));
-    DCCN_TRY(cconv_bwd_w_impl(w.corr, w.dcorc, G + d.o[14], G + d.o[15], R, K, K, w.ws_split, w.n_split, s));
+    // ... then the equaliser, last layer first.  replan: every weight gradient stays where its GEMM left it (finished
+    // in the gradient arena, or as split-K slabs in the layer's own workspace) until the optimizer launch
+    DeferredSlabs ds5{}, dsT{}, ds4{}, ds3{}, ds2{}, ds1{}, ds0{};       // (null slabs: the gradient arena holds the result)
+    FoldDefer fpair[2], fconv;
+    fpair[0].slabs = fpair[1].slabs = fconv.slabs = nullptr;
+    bool split_done = false;                // dcat's stores write deqc / dcorc themselves (when the plan has the stage)
+    DCCN_TRY(dense_bwd_full_impl(w.cat, w.dout, P + d.o[18], w.dcat, G + d.o[18], G + d.o[19], R, 4 * K, N2,
+                                 w.ws_l[EQL_DENSE5], w.n_l[EQL_DENSE5], s, 1, nullptr, nullptr, keep_slabs ? &ds5 : nullptr,
+                                 pair ? w.deqc : nullptr, pair ? (long long)(w.dcorc - w.deqc) : 0, pair ? &split_done : nullptr));
+    if (!split_done) {
+        hipLaunchKernelGGL(split_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float4*)w.dcat,
+                           (float2*)w.deqc, (float2*)w.dcorc, (long long)R * K);
+        DCCN_LAUNCH_CHECK();
+    }
+    if (pair) {
+        // dX and dWeff slabs of both C-Convs in one grid (group 0 = eq, 1 = corr)
+        DCCN_TRY(cconv_bwd_grouped_impl(w.eq, w.deqc, P + d.o[16], w.deq, R, K, K, 2, g_in, w.dcorc - w.deqc, g_w,
+                                        w.ws_l[EQL_PAIR], w.n_l[EQL_PAIR], fpair, s));
+        if (w.dcorr - w.deq != g_in) return DCCN_ERR_STATE;
+    } else {
+        DCCN_TRY(cconv_bwd_x_impl(w.deqc, P + d.o[16], w.deq, R, K, K, s));
+        DCCN_TRY(cconv_bwd_w_impl(w.eq, w.deqc, G + d.o[16], G + d.o[17], R, K, K, w.ws_l[EQL_PAIR], w.n_l[EQL_PAIR], s));
+        DCCN_TRY(cconv_bwd_x_impl(w.dcorc, P + d.o[14], w.dcorr, R, K, K, s));
+        DCCN_TRY(cconv_bwd_w_impl(w.corr, w.dcorc, G + d.o[14], G + d.o[15], R, K, K, w.ws_l[EQL_PAIR], w.n_l[EQL_PAIR], s));
+    }
     hipLaunchKernelGGL(equalize_bwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
                        (const float2*)h, (const float2*)w.deq, (const float2*)w.dcorr, (float2*)w.dy, (float2*)w.dh,
                        nBK / 2);
     DCCN_LAUNCH_CHECK();
     bool tg_fused = false;                  // tanh gradient on the dX store: dd4 = (dh . T^T) (1 - d4^2)
-    DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_split, w.n_split, s, 3, w.d4, &tg_fused));
-    hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
-                       (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
-    DCCN_LAUNCH_CHECK();
+    DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_l[EQL_SMOOTH], w.n_l[EQL_SMOOTH], s, 3,
+                                 w.d4, &tg_fused, keep_slabs ? &dsT : nullptr));
+    if (!replan) {
+        hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
+                           (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
+        DCCN_LAUNCH_CHECK();
+    }
     if (!tg_fused) {
         hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.dd4, (const float*)w.d4,
                            w.dd4, nBK);
         DCCN_LAUNCH_CHECK();
     }
-    DCCN_TRY(dense_bwd_full_impl(w.d3, w.dd4, P + d.o[10], w.dd3, G + d.o[10], G + d.o[11], B, SK2, SK2, w.ws_split,
-                                 w.n_split, s));
-    DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_split,
-                                 w.n_split, s));
-    DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_split,
-                                 w.n_split, s));
+    DCCN_TRY(dense_bwd_full_impl(w.d3, w.dd4, P + d.o[10], w.dd3, G + d.o[10], G + d.o[11], B, SK2, SK2, w.ws_l[EQL_DENSE4],
+                                 w.n_l[EQL_DENSE4], s, 1, nullptr, nullptr, keep_slabs ? &ds4 : nullptr));
+    DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_l[EQL_DENSE3],
+                                 w.n_l[EQL_DENSE3], s, 1, nullptr, nullptr, keep_slabs ? &ds3 : nullptr));
+    DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_l[EQL_DENSE2],
+                                 w.n_l[EQL_DENSE2], s, 1, nullptr, nullptr, keep_slabs ? &ds2 : nullptr));
     if (dense_bwd_stage_planned(B, SK2, d.Pp)) {
         // dy += (gradient through the pilot branch): accumulated by the dX store itself
         bool add_fused = false;
-        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dy, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
-                                     w.n_split, s, 4, w.dy, &add_fused));
+        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dy, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
+                                     w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
         if (!add_fused) return DCCN_ERR_STATE;              // plan and launch disagree: never silently drop the sum
     } else {
-        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_split,
-                                     w.n_split, s));
+        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
+                                     w.n_l[EQL_DENSE1], s, 1, nullptr, nullptr, keep_slabs ? &ds1 : nullptr));
         hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
         DCCN_LAUNCH_CHECK();
     }
-    DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
-    DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_split, w.n_split, s));
-    DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_split, w.n_split, s, nullptr,
-                              N2));
+    const bool conv_grouped = replan && cconv_pair_ok(w.t1, P + d.o[2], w.dt1, R, K, K, 0, 0, 0) && aligned16(w.dy);
+    if (conv_grouped) {
+        DCCN_TRY(cconv_bwd_grouped_impl(w.t1, w.dy, P + d.o[2], w.dt1, R, K, K, 1, 0, 0, 0, w.ws_l[EQL_CONV], w.n_l[EQL_CONV],
+                                        &fconv, s));
+    } else {
+        DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
+        DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_l[EQL_CONV], w.n_l[EQL_CONV], s));
+    }
+    DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_l[EQL_DENSE], w.n_l[EQL_DENSE], s,
+                              keep_slabs ? &ds0 : nullptr, N2));
     // optimizer: Equalizer/* only (ofdmreceiver_np_mp.py:330), L2 terms enter through reg_coef
-    return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s, false);
+    if (!replan) return adam_impl(b->eq_params, G, b->adam_m, b->adam_v, b->reg_coef, nullptr, b->adam, hp, d.o[20], s, false);
+    EqOptBuilder ob;
+    memset(&ob.a, 0, sizeof(ob.a));
+    ob.a.param = b->eq_params; ob.a.grad = G; ob.a.m = b->adam_m; ob.a.v = b->adam_v; ob.a.reg_coef = b->reg_coef;
+    ob.a.state = b->adam;
+    eq_opt_dense(ob, d, 0, ds0, K2);
+    if (fconv.slabs) ob.cconv_fold(d.o[2], d.o[3], fconv.slabs, fconv.colsum, fconv.splits, fconv.slab, K, K);
+    else { ob.plain(d.o[2], d.sz[2]); ob.plain(d.o[3], d.sz[3]); }
+    eq_opt_dense(ob, d, 4, ds1, d.Pp);
+    eq_opt_dense(ob, d, 6, ds2, SK2);
+    eq_opt_dense(ob, d, 8, ds3, SK2);
+    eq_opt_dense(ob, d, 10, ds4, SK2);
+    ob.conv2d_fold(d.o[12], d.o[13], dsT.dw_slabs ? dsT.dw_slabs : w.dT, (dsT.dw_slabs && dsT.db_slabs) ? dsT.db_slabs : w.dbe,
+                   dsT.dw_slabs ? dsT.splits : 1, (long long)SK2 * SK2, SK2, d.S, K);
+    for (int g = 1; g >= 0; --g) {          // arena order: conv3d_2 (corr, group 1), then conv3d_3 (eq, group 0)
+        const int i = g == 1 ? 14 : 16;
+        if (fpair[g].slabs) ob.cconv_fold(d.o[i], d.o[i + 1], fpair[g].slabs, fpair[g].colsum, fpair[g].splits, fpair[g].slab, K, K);
+        else { ob.plain(d.o[i], d.sz[i]); ob.plain(d.o[i + 1], d.sz[i + 1]); }
+    }
+    eq_opt_dense(ob, d, 18, ds5, N2);
+    if (fin_deferred) ob.tail_finalize(fin);
+    return launch_eq_opt(ob, hp, s);
 }

@@ -27,12 +27,12 @@ __device__ __forceinline__ T block_sum_256(T v, T* sh) {
 // tf.contrib.layers.layer_norm(center=False, scale=False, begin_norm_axis=1) (model.py:363):
 // one block per sample; two-pass moments (mean, then mean of squared differences), then
 // tf.nn.batch_normalization's  x*inv + (-mean*inv).
-__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             float* __restrict__ mean_out,
-                                                             float* __restrict__ inv_out, int cols, float eps) {
+__device__ __forceinline__ void layer_norm_fwd_body(const float* __restrict__ x, float* __restrict__ y,
+                                                    float* __restrict__ mean_out, float* __restrict__ inv_out,
+                                                    const int cols, const float eps, const int row) {
     __shared__ float sh[4];
-    const float* xr = x + (size_t)blockIdx.x * cols;
-    float* yr = y + (size_t)blockIdx.x * cols;
+    const float* xr = x + (size_t)row * cols;
+    float* yr = y + (size_t)row * cols;
     float s = 0.f;
     for (int c = threadIdx.x; c < cols; c += 256) s += xr[c];
     const float mean = block_sum_256(s, sh) / (float)cols;
@@ -46,9 +46,14 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
     const float shift = -mean * inv;
     for (int c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] * inv + shift;
     if (threadIdx.x == 0) {
-        if (mean_out) mean_out[blockIdx.x] = mean;
-        if (inv_out) inv_out[blockIdx.x] = inv;
+        if (mean_out) mean_out[row] = mean;
+        if (inv_out) inv_out[row] = inv;
     }
+}
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             float* __restrict__ mean_out,
+                                                             float* __restrict__ inv_out, int cols, float eps) {
+    layer_norm_fwd_body(x, y, mean_out, inv_out, cols, eps, (int)blockIdx.x);
 }
 
 // dx = inv * (dy - mean(dy) - y * mean(dy*y))   (y = normalised output)
@@ -85,19 +90,26 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
 }
 
 // model.py:431-438: eq = y * conj(h)/|h|,  corr = eq * conj(eq)   (IQ pairs as float2)
-__global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
-                                                           float2* __restrict__ eq, float2* __restrict__ corr,
-                                                           long long n) {
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float2 yv = y[i], hv = h[i];
-        const float a = sqrtf(hv.x * hv.x + hv.y * hv.y);
-        const float cr = hv.x / a, ci = (-hv.y) / a;
-        const float er = yv.x * cr - yv.y * ci;
-        const float ei = yv.x * ci + yv.y * cr;
+__device__ __forceinline__ float2 equalize_one(const float2 yv, const float2 hv) {
+    const float a = sqrtf(hv.x * hv.x + hv.y * hv.y);
+    const float cr = hv.x / a, ci = (-hv.y) / a;
+    return make_float2(yv.x * cr - yv.y * ci, yv.x * ci + yv.y * cr);
+}
+__device__ __forceinline__ void equalize_fwd_body(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                  float2* __restrict__ eq, float2* __restrict__ corr, const long long n,
+                                                  const int bx, const int nbx) {
+    const long long stride = (long long)nbx * 256;
+    for (long long i = (long long)bx * 256 + threadIdx.x; i < n; i += stride) {
+        const float2 e = equalize_one(y[i], h[i]);
+        const float er = e.x, ei = e.y;
         eq[i] = make_float2(er, ei);
         if (corr) corr[i] = make_float2(er * er - ei * (-ei), er * (-ei) + ei * er);
     }
+}
+__global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                           float2* __restrict__ eq, float2* __restrict__ corr,
+                                                           long long n) {
+    equalize_fwd_body(y, h, eq, corr, n, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // real-valued backward of the pair above; d_corr may be null.  corr = (er^2+ei^2, 0), so only its
@@ -131,26 +143,51 @@ __global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* __restr
 }
 
 // model.py:465-475 pilot "SNR" monitor: log10(clip(mean/var of |pilot|^2 over the frame's pilot
-// cells)).  One wave per frame.
-__global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict__ eq, const int* __restrict__ carriers,
-                                                       float* __restrict__ snr_db, int S, int K, int P) {
-    const float2* f = eq + (size_t)blockIdx.x * S * K;
+// cells)).  One wave per frame.  FROM_YH: the equalised cell is recomputed from (y, h) -- the monitor then rides on the
+// launch that writes eq instead of waiting for it in a launch of its own.
+template <bool FROM_YH>
+__device__ __forceinline__ void pilot_snr_body(const float2* __restrict__ eq, const float2* __restrict__ y,
+                                               const float2* __restrict__ h, const int* __restrict__ carriers,
+                                               float* __restrict__ snr_db, const int S, const int K, const int P,
+                                               const int frame, const int lane) {
+    const size_t base = (size_t)frame * S * K;
     const int n = S * P;
+    auto cell = [&](int i) -> float2 {
+        const size_t j = base + (size_t)(i / P) * K + carriers[i % P];
+        if constexpr (FROM_YH) return equalize_one(y[j], h[j]);
+        else return eq[j];
+    };
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        const float2 v = f[(i / P) * K + carriers[i % P]];
+    for (int i = lane; i < n; i += 64) {
+        const float2 v = cell(i);
         s += v.x * v.x + v.y * v.y;
     }
     const float mean = wave_sum(s) / (float)n;
     float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        const float2 v = f[(i / P) * K + carriers[i % P]];
+    for (int i = lane; i < n; i += 64) {
+        const float2 v = cell(i);
         const float d = (v.x * v.x + v.y * v.y) - mean;
         q += d * d;
     }
     const float var = wave_sum(q) / (float)n;
     const float ratio = fminf(fmaxf(mean / var, 0.001f), 10000.0f);
-    if (threadIdx.x == 0) snr_db[blockIdx.x] = logf(ratio) / logf(10.0f);
+    if (lane == 0) snr_db[frame] = logf(ratio) / logf(10.0f);
+}
+__global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict__ eq, const int* __restrict__ carriers,
+                                                       float* __restrict__ snr_db, int S, int K, int P) {
+    pilot_snr_body<false>(eq, nullptr, nullptr, carriers, snr_db, S, K, P, (int)blockIdx.x, (int)threadIdx.x);
+}
+// equalise + the pilot monitor in one launch: blocks [0, eq_blocks) equalise, each later block serves four frames
+__global__ __launch_bounds__(256) void equalize_fwd_snr_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                               float2* __restrict__ eq, float2* __restrict__ corr,
+                                                               long long n, int eq_blocks, const int* __restrict__ carriers,
+                                                               float* __restrict__ snr_db, int frames, int S, int K, int P) {
+    if ((int)blockIdx.x < eq_blocks) {
+        equalize_fwd_body(y, h, eq, corr, n, (int)blockIdx.x, eq_blocks);
+        return;
+    }
+    const int frame = ((int)blockIdx.x - eq_blocks) * 4 + (int)(threadIdx.x >> 6);
+    if (frame < frames) pilot_snr_body<true>(nullptr, y, h, carriers, snr_db, S, K, P, frame, (int)(threadIdx.x & 63));
 }
 
 // ---- one-channel, one-filter complex "same" convolution as a dense layer ---------------------
@@ -161,15 +198,15 @@ __global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict_
 // column = output cell/re-im) and the layer runs on the MFMA dense GEMM.  Entry for input (s',k')
 // and output (s,k): tap (a,b) = (s'-s+padL, k'-k+padW) if inside the kernel, else 0, with the
 // C-Conv sign pattern  [I->re]=Wa [I->im]=Wb [Q->re]=-Wb [Q->im]=-Wa  (complex.py:185-188).
-__global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* __restrict__ w,
-                                                                  const float* __restrict__ bias,
-                                                                  float* __restrict__ T, float* __restrict__ bias_eff,
-                                                                  int L, int W, int kL, int kW) {
+__device__ __forceinline__ void cconv2d_same_expand_body(const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ T, float* __restrict__ bias_eff,
+                                                         const int L, const int W, const int kL, const int kW,
+                                                         const int bx, const int nbx) {
     const int n = L * W * 2;
     const int padL = (kL - 1) / 2, padW = (kW - 1) / 2;
     const long long total = (long long)n * n;
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const long long stride = (long long)nbx * 256;
+    for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += stride) {
         const int row = (int)(i / n), col = (int)(i % n);
         const int iq = row & 1, kp = (row >> 1) % W, sp = (row >> 1) / W;
         const int ri = col & 1, k = (col >> 1) % W, s = (col >> 1) / W;
@@ -185,6 +222,20 @@ __global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* _
             bias_eff[i] = (i & 1) ? -d : d;
         }
     }
+}
+__global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* __restrict__ w,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ T, float* __restrict__ bias_eff,
+                                                                  int L, int W, int kL, int kW) {
+    cconv2d_same_expand_body(w, bias, T, bias_eff, L, W, kL, kW, (int)blockIdx.x, (int)gridDim.x);
+}
+// the equaliser step's second launch: layer_norm of the normalised frames (one block per frame) and, in the blocks behind
+// them, the expansion of the smoothing kernel -- two independent 5 us launches as one
+__global__ __launch_bounds__(256) void eq_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int cols,
+                                                      float eps, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ T, float* __restrict__ bias_eff, int L, int W) {
+    if ((int)blockIdx.x < frames) layer_norm_fwd_body(x, y, nullptr, nullptr, cols, eps, (int)blockIdx.x);
+    else cconv2d_same_expand_body(w, bias, T, bias_eff, L, W, L, W, (int)blockIdx.x - frames, (int)gridDim.x - frames);
 }
 
 // transpose of the expansion: one wave per tap gathers its diagonal of dT; wave kL*kW reduces the

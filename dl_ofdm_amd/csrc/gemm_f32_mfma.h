@@ -58,6 +58,7 @@ struct GemmParams {
     // gemm16.h store epilogue with an element-wise stage (template parameter NB of EPI_STORE: 2 tanh, 3 v (1 - aux^2),
     // 4 v + aux): the other operand of stages 3 and 4, same shape and row stride as C
     const float* aux;
+    long long gC;        // CMAP_SPLIT_PAIRS stores (gemm_store): elements between the two destination buffers
     float* ad_p; float* ad_m; float* ad_v;
     const float* ad_reg; const float* ad_gate;
     const dccn_adam_state* ad_state;
@@ -419,8 +420,23 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
     cs_out = cs;
 }
 
+// Column maps of the store epilogue (compile-time: the equaliser's concat / split of two IQ-pair streams, model.py:456,
+// happens in the stores of the GEMMs on either side of it instead of in two element-wise launches):
+//   CMAP_JOIN_PAIRS   this GEMM produces ONE of the two streams of cat[rows, K, (eq re, eq im, corr re, corr im)]:
+//                     logical column 2k+j goes to column 4k+j of a row of 2*N floats (C already points at the
+//                     stream's first float: +0 / +2)
+//   CMAP_SPLIT_PAIRS  this GEMM produces the gradient of such a cat row: logical column 4k+2g+j goes to column 2k+j of
+//                     stream g's own [rows, N/2] buffer at C + g*gC
+enum ColumnMap : int { CMAP_NONE = 0, CMAP_JOIN_PAIRS = 1, CMAP_SPLIT_PAIRS = 2 };
+template <int CMAP>
+__device__ __forceinline__ size_t cmap_col(const GemmParams& p, const int col) {
+    if constexpr (CMAP == CMAP_JOIN_PAIRS) return (size_t)(2 * col - (col & 1));
+    else if constexpr (CMAP == CMAP_SPLIT_PAIRS) return (size_t)((col >> 1) & 1) * (size_t)p.gC + (size_t)(2 * (col >> 2) + (col & 1));
+    else return (size_t)col;
+}
+
 // store epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int BM, int BN, int COLSUM>
+template <int BM, int BN, int COLSUM, int CMAP = CMAP_NONE>
 __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, const f32x16 (&acc)[BM / 64][BN / 64],
                                            const int m0, const int n0, const float cs) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -463,14 +479,14 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, con
                     }
                 }
             } else if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
-                float* Cc = Cz + (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + col;
+                float* Cc = Cz + (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + cmap_col<CMAP>(p, col);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Cc[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[a][b][r] + bj;
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + col] = acc[a][b][r] + bj;
+                    if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + cmap_col<CMAP>(p, col)] = acc[a][b][r] + bj;
                 }
             }
         }
@@ -482,13 +498,44 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, con
 }
 
 // One output tile of C = A.B: k-loop + store
-template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC, int NBUF = 2>
+template <int KA, int KB, int BM, int BN, int BK, int COLSUM, bool VEC, int NBUF = 2, int CMAP = CMAP_NONE>
 __device__ __forceinline__ void gemm_block(const GemmParams& p, const int L, const int T, const int z) {
     f32x16 acc[BM / 64][BN / 64];
     int m0, n0;
     float cs;
     gemm_mainloop<KA, KB, BM, BN, BK, COLSUM, VEC, NBUF>(p, L, T, z, acc, m0, n0, cs);
-    gemm_store<BM, BN, COLSUM>(p, z, acc, m0, n0, cs);
+    gemm_store<BM, BN, COLSUM, CMAP>(p, z, acc, m0, n0, cs);
+}
+
+// Several independent GEMMs of ONE shape in one grid (blockIdx.y = the group): the operands of group g lie at a fixed
+// element stride from those of group 0.  The equaliser's corr / eq C-Conv pair (model.py:439-449): two 5-12 us launches
+// that never overlapped become one grid of twice the blocks.
+struct GroupStride {
+    long long a, b, c, bias, colsum;
+};
+__device__ __forceinline__ GemmParams group_params(const GemmParams& p, const GroupStride& gs, const int g) {
+    GemmParams q = p;
+    q.A = p.A + g * gs.a;
+    q.B = p.B + g * gs.b;
+    q.C = p.C + g * gs.c;
+    if (p.bias) q.bias = p.bias + g * gs.bias;
+    if (p.colsum) q.colsum = p.colsum + g * gs.colsum;
+    return q;
+}
+template <int KA, int KB, int BM, int BN, int BK, int TAG, bool VEC, int NBUF, int CMAP>
+__global__ __launch_bounds__(kGemmThreads) void gemm_grouped_kernel(const GemmParams p, const GroupStride gs) {
+    const GemmParams q = group_params(p, gs, (int)blockIdx.y);
+    gemm_block<KA, KB, BM, BN, BK, 0, VEC, NBUF, CMAP>(q, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+template <int KA, int KB, int BM, int BN, int BK, int TAG, int NBUF, int CMAP>
+static int launch_gemm_grouped(const GemmParams& p, const GroupStride& gs, int groups, hipStream_t s) {
+    auto kern = gemm_grouped_kernel<KA, KB, BM, BN, BK, TAG, true, NBUF, CMAP>;
+    constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK, NBUF>();
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
+    dim3 grid(ceil_div(p.N, BN) * ceil_div(p.M, BM), groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, gs);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
 }
 
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator

@@ -29,7 +29,13 @@ constexpr size_t kmajor_smem_bytes() { return (size_t)(2 * 2 * BK * 64) * sizeof
 
 // COLSUM: also the column sums of the B rows of this k range (bias gradient), written by the m0 == 0 tiles
 template <int COLSUM, int BK = 64>
-__device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, const int T, const int z) {
+__device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, const int T, const int z,
+                                             const long long goA = 0, const long long goB = 0, const long long goC = 0,
+                                             const long long goS = 0) {
+    // go*: element offsets of this block's group from the operands in `p` (grouped launches; a shifted COPY of p would
+    // turn the dynamically indexed koff[] into scratch memory)
+    const float* __restrict__ pA = p.A + goA;
+    const float* __restrict__ pB = p.B + goB;
     constexpr int BT = 64, NV = BK / 16;                // 64x64 output tile, BK-deep k-tiles, NV float4 per thread/operand
     constexpr int NKS = BK / 4;                         // k-steps per k-tile
     static_assert(BK == 32 || BK == 64, "k-tile depth");
@@ -75,17 +81,17 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int v = q % NV;
         if constexpr (!MASKED) {
-            const char* base = reinterpret_cast<const char*>(q < NV ? p.A + (size_t)k0 * p.lda : p.B + (size_t)k0 * p.ldb);
+            const char* base = reinterpret_cast<const char*>(q < NV ? pA + (size_t)k0 * p.lda : pB + (size_t)k0 * p.ldb);
             if (q < NV) ra[v] = *reinterpret_cast<const float4*>(base + offA[v]);
             else rb[v] = *reinterpret_cast<const float4*>(base + offB[v]);
         } else {
             const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
             const int k = k0 + row, kc = min(k, p.K - 1);
             if (q < NV) {
-                ra[v] = *reinterpret_cast<const float4*>(p.A + (size_t)kc * p.lda + min(m0 + 4 * c4, p.M - 4));
+                ra[v] = *reinterpret_cast<const float4*>(pA + (size_t)kc * p.lda + min(m0 + 4 * c4, p.M - 4));
                 okm = (okm & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
             } else {
-                rb[v] = *reinterpret_cast<const float4*>(p.B + (size_t)kc * p.ldb + min(n0 + 4 * c4, p.N - 4));
+                rb[v] = *reinterpret_cast<const float4*>(pB + (size_t)kc * p.ldb + min(n0 + 4 * c4, p.N - 4));
             }
         }
     };
@@ -178,7 +184,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
     while (t + 1 < ntiles) ktile(std::integral_constant<int, PF_MASKED>{});
     if (ntiles > 0) ktile(std::integral_constant<int, PF_NONE>{});
 
-    float* Cz = p.C + (size_t)z * p.slab;
+    float* Cz = p.C + goC + (size_t)z * p.slab;
     const int col = n0 + 32 * hB + 2 * c;
     const int rowb = m0 + 32 * hA + 8 * kq;
     if (m0 + BT <= p.M && n0 + BT <= p.N) {                // interior tile (block-uniform): stores without exec masks
@@ -208,7 +214,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             bsum.w += __shfl_xor(bsum.w, m, 64);
         }
         const int cc = n0 + 4 * c;
-        if (lane < 16 && cc < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)z * p.N + cc) = bsum;
+        if (lane < 16 && cc < p.N) *reinterpret_cast<float4*>(p.colsum + goS + (size_t)z * p.N + cc) = bsum;
     }
 }
 
@@ -234,8 +240,8 @@ static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
 }
 
 // dense backward in one grid: blocks [0, nx) = the dX tiles (gemm_f32_mfma.h, k-contiguous operands), the rest = the
-// dW (tile, split) items in the k-major form
-template <int BK>
+// dW (tile, split) items in the k-major form.  CMAP: column map of the dX stores (gemm_store)
+template <int BK, int CMAP = CMAP_NONE>
 __global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_km_kernel(const GemmParams px, const GemmParams pw,
                                                                             const int nx, const int tw) {
     const int b = (int)blockIdx.x;
@@ -243,21 +249,57 @@ __global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_km_kernel(cons
     if ((GROUPED_ABL == 1) == (b < nx)) return;
 #endif
     if (b < nx) {
-        gemm_block<OP_KCONTIG, OP_KCONTIG, 64, 64, BK, 0, true>(px, b, nx, 0);
+        gemm_block<OP_KCONTIG, OP_KCONTIG, 64, 64, BK, 0, true, 2, CMAP>(px, b, nx, 0);
     } else {
         const int c = b - nx;
         kmajor_block<1, BK>(pw, c % tw, tw, c / tw);
     }
 }
 
-template <int BK>
+template <int BK, int CMAP = CMAP_NONE>
 static int launch_dense_bwd_grouped_km(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s) {
     constexpr size_t sx = gemm_smem_bytes<OP_KCONTIG, OP_KCONTIG, 64, 64, BK>();
     constexpr size_t smem = sx > kmajor_smem_bytes<BK>() ? sx : kmajor_smem_bytes<BK>();
-    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(dense_bwd_grouped_km_kernel<BK>), smem));
+    auto kern = dense_bwd_grouped_km_kernel<BK, CMAP>;
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
     const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
-    hipLaunchKernelGGL(dense_bwd_grouped_km_kernel<BK>, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
+    hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// C-Conv backward of `groups` same-shaped layers in one grid (the equaliser's corr / eq pair, or one layer):
+// blocks [0, groups*nx) = the dX tiles  dx_g = dout_g . Weff_g^T  (group-major), the rest = the (group, tile, split)
+// items of  dWeff_g = x_g^T . dout_g  in the k-major form, slabs left for the optimizer launch to fold.
+// Four launches of the pair (two dX, two dW) + two folds become one grid.
+template <int BK>
+__global__ __launch_bounds__(kGemmThreads) void cconv_bwd_grouped_km_kernel(const GemmParams px, const GroupStride gx,
+                                                                            const GemmParams pw, const GroupStride gw,
+                                                                            const int nx, const int tw, const int splits,
+                                                                            const int groups) {
+    const int b = (int)blockIdx.x;
+    if (b < nx * groups) {
+        const GemmParams q = group_params(px, gx, b / nx);
+        gemm_block<OP_KCONTIG, OP_CCONV_WT, 64, 64, BK, 0, true>(q, b % nx, nx, 0);
+    } else {
+        const int c = b - nx * groups, per = tw * splits;
+        const int g = c / per, i = c % per;
+        kmajor_block<1, BK>(pw, i % tw, tw, i / tw, g * gw.a, g * gw.b, g * gw.c, g * gw.colsum);
+    }
+}
+
+template <int BK>
+static int launch_cconv_bwd_grouped_km(const GemmParams& px, const GroupStride& gx, const GemmParams& pw,
+                                       const GroupStride& gw, int splits_w, int groups, hipStream_t s) {
+    constexpr size_t sx = gemm_smem_bytes<OP_KCONTIG, OP_CCONV_WT, 64, 64, BK>();
+    constexpr size_t smem = sx > kmajor_smem_bytes<BK>() ? sx : kmajor_smem_bytes<BK>();
+    auto kern = cconv_bwd_grouped_km_kernel<BK>;
+    DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
+    const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
+    const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
+    hipLaunchKernelGGL(kern, dim3((nx + tw * splits_w) * groups), dim3(kGemmThreads), smem, s, px, gx, pw, gw, nx, tw,
+                       splits_w, groups);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

@@ -217,8 +217,12 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
  * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1), 12 wave priority of those tiles,
  * 13 fused dense+tail launch for 8-QAM / 16-QAM steps (bit 0 lane-per-cell forms, bit 1 quad-lane training form),
  * 14 graded k ranges of the dense weight-gradient items in the fused backward launch (preset number, 0 = uniform),
- * 15 C-Conv forward of the next batch on the optimizer launch of double-buffered pipelined steps (default 1),
- * 16 large layers: optimizer update of the dense kernel in the epilogue of its unsplit weight-gradient tiles (default 1).
+ * 15 C-Conv forward of the next batch on the optimizer launch of double-buffered pipelined steps (default 0: measured
+ * slower), 16 large layers: optimizer update of the dense kernel in the epilogue of its unsplit weight-gradient tiles
+ * (default 0: measured slower), 17 few-row dense backward as one grid (default 1), 18 R0 of the next batch on the
+ * backward launch of double-buffered pipelined steps (default 0), 19 equaliser step: element-wise stages in GEMM
+ * epilogues (default 1), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
+ * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);

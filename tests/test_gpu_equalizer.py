@@ -381,6 +381,49 @@ def test_fused_step_equals_composed_step(cp):
     close(pl.chest, torch.view_as_real(out_b[4]).cpu().numpy(), 1e-5, "chest")
 
 
+@pytest.mark.parametrize("B,cp", [(12, True), (73, True), (73, False), (200, True), (200, False)])
+def test_round3_launch_plan_equals_round2_plan(B, cp):
+    """dccn_set_tuning(20, .): the re-planned step (grouped corr/eq C-Convs, concat / split in GEMM stores, merged
+    element-wise launches, one job-table optimizer launch) computes what the launch-per-stage plan computes -- at the
+    few-row batch (direct weight gradients), the reference's 73 frames and a batch whose dense gradients are split-K slabs"""
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=41, cp=cp)
+    _, _, _, _, _, _, tr_b = _trainer(seed=41, cp=cp)
+    rng = np.random.RandomState(19)
+    try:
+        for step in range(3):
+            x = (rng.standard_normal((B, 7, 80, 2)) * 2).astype(np.float32)
+            bits = rng.randint(0, 2, (B, tx.frame_size, 2)).astype(np.int32)
+            lib.dccn_set_tuning(20, 1)
+            ma = tr_a.train_step(x, bits, fused=True, graph=(step == 1))
+            lib.dccn_set_tuning(20, 0)
+            mb = tr_b.train_step(x, bits, fused=True, graph=False)
+            assert ma["conf"] == mb["conf"] and abs(ma["ce_mean"] - mb["ce_mean"]) <= 1e-6 * abs(mb["ce_mean"])
+            assert abs(ma["tx_power"] - mb["tx_power"]) <= 1e-6 * abs(mb["tx_power"])
+            ga, gb = tr_a.get_grads(), tr_b.get_grads()
+            if step == 0:                    # same parameters: same GEMM plans, same summation orders -> same bits
+                diff = {n: float(np.abs(ga[n] - gb[n]).max() / max(np.abs(gb[n]).max(), 1e-30)) for n in tr_a.names
+                        if not np.array_equal(ga[n], gb[n])}
+                assert not diff, " ".join("%s=%.1e" % (k.split("/", 1)[1], v) for k, v in diff.items())
+            for n in tr_a.names:
+                assert np.abs(ga[n] - gb[n]).max() <= 5e-5 * max(np.abs(gb[n]).max(), 1e-30), (step, n)
+            pa, pb = tr_a.get_params(), tr_b.get_params()
+            for n in tr_a.names:
+                d = np.abs(pa[n] - pb[n]).ravel()
+                assert np.quantile(d, 0.999) <= 2e-6, (step, n, d.max())
+        pl_a, pl_b = tr_a._plan(B), tr_b._plan(B)
+        for name in ("out_eq", "snr_db", "chest"):
+            close(getattr(pl_a, name), getattr(pl_b, name).cpu().numpy(), 2e-6, name)
+        lib.dccn_set_tuning(20, 1)
+        ea = tr_a.eval_step(x, bits, fused=True)
+        lib.dccn_set_tuning(20, 0)
+        eb = tr_b.eval_step(x, bits, fused=True)
+        assert ea["conf"] == eb["conf"]
+    finally:
+        lib.dccn_set_tuning(20, 1)
+
+
 def test_chan_rms_monitor_is_keras_layer_normalization_over_the_symbol_axis():
     """ofdmreceiver_np_mp.py:245, 325-333: LayerNormalization(axis=1, center=False, scale=False), epsilon 1e-3"""
     F, tx, ecfg, rcfg, pe, pr, tr = _trainer(seed=3, cp=True)

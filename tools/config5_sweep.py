@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="config5_out")
     ap.add_argument("--frames", type=int, default=20000)
-    ap.add_argument("--eq_epochs", type=int, default=600)
+    ap.add_argument("--eq_epochs", type=int, default=600, help="<= 0: the reference's 4000 * nbits cap")
     ap.add_argument("--rx_epoch_scale", type=float, default=1.0)
     ap.add_argument("--classical_frames", type=int, default=1500)
     ap.add_argument("--backend", default=None, help="nccl (default; RCCL over xGMI) or gloo; also DCCN_DIST_BACKEND")
