@@ -58,7 +58,8 @@ enum TuneKey : int {
     TUNE_ADAM_IN_DW = 16,       // 1: large layers (unsplit dW tiles): the dense kernel's Adam update runs in the dW epilogue
     TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
     TUNE_NORM_ON_BWD = 18,      // 1: double-buffered pipelining: R0 of the next batch rides on the backward launch
-    TUNE_EQ_EPILOGUES = 19,     // 1: equaliser step: tanh / tanh-gradient / gradient add in the epilogues of the few-row GEMMs
+    TUNE_EQ_EPILOGUES = 19,     // equaliser step: tanh / tanh-gradient / gradient add in GEMM stores: 1 = the few-row GEMMs,
+                                //    2 = also the 48x64 / 64x64 tiles of larger batches
     TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
                                 //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
     TUNE_COUNT = 21
@@ -82,9 +83,12 @@ struct TuneTable {
 //   16 = 0  Adam in the dW epilogue of large layers: built, bitwise-tested, +4.7 % on the C4 step (5.21 vs 4.98 ms): the
 //           epilogue's per-row 128-byte accesses to p/m/v cost more than the 0.94 GB gradient round trip they save.
 //   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
+//   19 = 2  element-wise stages in GEMM stores: 73 frames 0.2688 -> 0.2663 ms (few-row tiles); 1170 frames 0.5276 -> 0.5247 ms
+//           (the stage costs the GEMM 8-10 us where the stand-alone launch cost 5: a small net gain);
+//   20 = 1  equaliser re-plan: 73 frames 0.319 -> 0.263 ms, 1170 frames 0.570 -> 0.509 ms (tools/eqbench.py --ab 20=0,1,2);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {1}, {1}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -217,8 +221,13 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     // small layers (64x64 tiles would leave CUs without a block: 1170x640 = 190 tiles): the 48x64 tiles of the fused
     // kernel, loads two k-tiles ahead
     if (g_tune[TUNE_DENSE_FWD_PLAIN] && p.vecA && p.vecB && (K % 4 == 0) && (N % 4 == 0) && K >= 128 &&
-        (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs)
+        (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs) {
+        if (act == 2 && act_done && g_tune[TUNE_EQ_EPILOGUES] >= 2) {
+            *act_done = true;                       // tanh in the store of the same tiles
+            return launch_gemm16<OP_KCONTIG, OP_ICONTIG, 1, 4, 3, 1, 64, 1, 0, TAG_DENSE_FWD, 2, 2>(p, 1, s);
+        }
         return launch_gemm16<OP_KCONTIG, OP_ICONTIG, 1, 4, 3, 1, 64, 1, 0, TAG_DENSE_FWD, 2>(p, 1, s);
+    }
     return launch_gemm<OP_KCONTIG, OP_ICONTIG, 0, TAG_DENSE_FWD>(p, 1, s);
 }
 
@@ -377,13 +386,6 @@ static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
     if (variant == 6) wn = 128;
 }
 
-// will dense_bwd_grouped_impl take the few-row grid that can carry an element-wise stage on its dX store (16-byte
-// aligned operands assumed: the callers' workspaces are)
-static bool dense_bwd_stage_planned(int M, int K, int N) {
-    return g_tune[TUNE_SKINNY] > 0 && g_tune[TUNE_SKINNY_GROUPED] && g_tune[TUNE_EQ_EPILOGUES] && M <= 96 && (K % 4 == 0) &&
-           (N % 4 == 0) && small_enough(M, K) && small_enough(M, N) && small_enough(K, N);
-}
-
 // dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
 // (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
@@ -484,6 +486,13 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
             px.C = split_dst; px.ldc = K / 2; px.gC = split_pairs_gc;
             *split_done = true;
             DCCN_TRY((launch_dense_bwd_grouped_km<64, CMAP_SPLIT_PAIRS>(px, pw, sp.splits, s)));
+        } else if (actx != 1 && act_done && aux && g_tune[TUNE_EQ_EPILOGUES] >= 2) {
+            // element-wise stage of the caller's graph on the dX stores (as in the few-row grid above)
+            px.aux = aux;
+            *act_done = true;
+            if (actx == 3) DCCN_TRY((launch_dense_bwd_grouped_km<64, CMAP_TANHGRAD>(px, pw, sp.splits, s)));
+            else if (actx == 4) DCCN_TRY((launch_dense_bwd_grouped_km<64, CMAP_ADD>(px, pw, sp.splits, s)));
+            else return DCCN_ERR_INVALID_ARG;
         } else {
             DCCN_TRY(launch_dense_bwd_grouped_km<64>(px, pw, sp.splits, s));
         }

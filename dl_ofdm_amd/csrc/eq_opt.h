@@ -62,14 +62,38 @@ __device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J
                 // the summation order of splitk_reduce_body (four interleaved runs, then 0+1+2+3): the step's gradients
                 // are bit-identical to those of the launch-per-stage plan
                 float4 run[kRedGroups];
+                if (J.splits <= 2 * kRedGroups) {
+                    // (uniform count) every slab's load is issued before the first add
+                    float4 u[2 * kRedGroups];
 #pragma unroll
-                for (int r = 0; r < kRedGroups; ++r) {
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int z = r; z < J.splits; z += kRedGroups) {
-                        const float4 u = *reinterpret_cast<const float4*>(J.src + (size_t)z * J.slab + i);
-                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    for (int q = 0; q < 2 * kRedGroups; ++q) {
+                        u[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (q < J.splits) u[q] = *reinterpret_cast<const float4*>(J.src + (size_t)q * J.slab + i);
                     }
-                    run[r] = t;
+#pragma unroll
+                    for (int r = 0; r < kRedGroups; ++r) {
+                        run[r] = u[r];
+                        if (r + kRedGroups < J.splits) {
+                            run[r].x += u[r + kRedGroups].x; run[r].y += u[r + kRedGroups].y;
+                            run[r].z += u[r + kRedGroups].z; run[r].w += u[r + kRedGroups].w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < kRedGroups; ++r) {
+                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int zb = r; zb < J.splits; zb += 8 * kRedGroups) {       // batches of 8 loads, then 8 adds
+                            float4 u[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (zb + q * kRedGroups < J.splits)
+                                    u[q] = *reinterpret_cast<const float4*>(J.src + (size_t)(zb + q * kRedGroups) * J.slab + i);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (zb + q * kRedGroups < J.splits) { t.x += u[q].x; t.y += u[q].y; t.z += u[q].z; t.w += u[q].w; }
+                        }
+                        run[r] = t;
+                    }
                 }
                 g4 = run[0];
 #pragma unroll
@@ -114,12 +138,27 @@ __device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J
 
 // element i of a split-K result, summed in splitk_reduce_body's order
 __device__ __forceinline__ float slab_sum(const float* __restrict__ src, const size_t i, const int splits, const long long slab) {
+    if (splits == 1) return src[i];
     float run[kRedGroups];
+    if (splits <= 2 * kRedGroups) {
+        float u[2 * kRedGroups];
 #pragma unroll
-    for (int r = 0; r < kRedGroups; ++r) {
-        float t = 0.f;
-        for (int z = r; z < splits; z += kRedGroups) t += src[(size_t)z * slab + i];
-        run[r] = t;
+        for (int q = 0; q < 2 * kRedGroups; ++q) {
+            u[q] = 0.f;
+            if (q < splits) u[q] = src[(size_t)q * slab + i];
+        }
+#pragma unroll
+        for (int r = 0; r < kRedGroups; ++r) {
+            run[r] = u[r];
+            if (r + kRedGroups < splits) run[r] += u[r + kRedGroups];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRedGroups; ++r) {
+            float t = 0.f;
+            for (int z = r; z < splits; z += kRedGroups) t += src[(size_t)z * slab + i];
+            run[r] = t;
+        }
     }
     return ((run[0] + run[1]) + run[2]) + run[3];
 }

@@ -314,6 +314,13 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     bool tg_fused = false;                  // tanh gradient on the dX store: dd4 = (dh . T^T) (1 - d4^2)
     DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_l[EQL_SMOOTH], w.n_l[EQL_SMOOTH], s, 3,
                                  w.d4, &tg_fused, keep_slabs ? &dsT : nullptr));
+    if (dsT.dw_slabs) {
+        // the fold of this layer gathers diagonals of dT (one cache line per element): over several slabs that gather
+        // thrashes the L2 (measured 53 us for the optimizer launch at 1170 frames), so the slabs are summed first
+        const long long n = (long long)SK2 * SK2;
+        DCCN_TRY(launch_splitk_reduce2(dsT.dw_slabs, dsT.splits, n, w.dT, n, dsT.db_slabs, (long long)SK2, w.dbe, (long long)SK2, s));
+        dsT.dw_slabs = dsT.db_slabs = nullptr;
+    }
     if (!replan) {
         hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
                            (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
@@ -330,25 +337,23 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                                  w.n_l[EQL_DENSE3], s, 1, nullptr, nullptr, keep_slabs ? &ds3 : nullptr));
     DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_l[EQL_DENSE2],
                                  w.n_l[EQL_DENSE2], s, 1, nullptr, nullptr, keep_slabs ? &ds2 : nullptr));
-    if (dense_bwd_stage_planned(B, SK2, d.Pp)) {
-        // dy += (gradient through the pilot branch): accumulated by the dX store itself
-        bool add_fused = false;
-        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dy, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
-                                     w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
-        if (!add_fused) return DCCN_ERR_STATE;              // plan and launch disagree: never silently drop the sum
-    } else {
-        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
-                                     w.n_l[EQL_DENSE1], s, 1, nullptr, nullptr, keep_slabs ? &ds1 : nullptr));
+    // dy += (gradient through the pilot branch): by the dX stores themselves when the launch plan has the stage (the sum
+    // then lands in dflat), else by a launch of its own
+    bool add_fused = false;
+    DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
+                                 w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
+    if (!add_fused) {
         hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
         DCCN_LAUNCH_CHECK();
     }
-    const bool conv_grouped = replan && cconv_pair_ok(w.t1, P + d.o[2], w.dt1, R, K, K, 0, 0, 0) && aligned16(w.dy);
+    const float* dy_sum = add_fused ? w.dflat : w.dy;
+    const bool conv_grouped = replan && cconv_pair_ok(w.t1, P + d.o[2], w.dt1, R, K, K, 0, 0, 0) && aligned16(dy_sum);
     if (conv_grouped) {
-        DCCN_TRY(cconv_bwd_grouped_impl(w.t1, w.dy, P + d.o[2], w.dt1, R, K, K, 1, 0, 0, 0, w.ws_l[EQL_CONV], w.n_l[EQL_CONV],
+        DCCN_TRY(cconv_bwd_grouped_impl(w.t1, dy_sum, P + d.o[2], w.dt1, R, K, K, 1, 0, 0, 0, w.ws_l[EQL_CONV], w.n_l[EQL_CONV],
                                         &fconv, s));
     } else {
-        DCCN_TRY(cconv_bwd_x_impl(w.dy, P + d.o[2], w.dt1, R, K, K, s));
-        DCCN_TRY(cconv_bwd_w_impl(w.t1, w.dy, G + d.o[2], G + d.o[3], R, K, K, w.ws_l[EQL_CONV], w.n_l[EQL_CONV], s));
+        DCCN_TRY(cconv_bwd_x_impl(dy_sum, P + d.o[2], w.dt1, R, K, K, s));
+        DCCN_TRY(cconv_bwd_w_impl(w.t1, dy_sum, G + d.o[2], G + d.o[3], R, K, K, w.ws_l[EQL_CONV], w.n_l[EQL_CONV], s));
     }
     DCCN_TRY(dense_bwd_w_impl(w.ln + d.win, w.dt1, G + d.o[0], G + d.o[1], R, kin0, K2, w.ws_l[EQL_DENSE], w.n_l[EQL_DENSE], s,
                               keep_slabs ? &ds0 : nullptr, N2));

@@ -427,7 +427,15 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
 //                     stream's first float: +0 / +2)
 //   CMAP_SPLIT_PAIRS  this GEMM produces the gradient of such a cat row: logical column 4k+2g+j goes to column 2k+j of
 //                     stream g's own [rows, N/2] buffer at C + g*gC
-enum ColumnMap : int { CMAP_NONE = 0, CMAP_JOIN_PAIRS = 1, CMAP_SPLIT_PAIRS = 2 };
+//   CMAP_TANHGRAD / CMAP_ADD  no column map, an element-wise stage instead: v (1 - aux^2) (the gradient through
+//                     tanh, aux = its output) / aux + v (gradient accumulation); aux has C's shape and row stride
+enum ColumnMap : int { CMAP_NONE = 0, CMAP_JOIN_PAIRS = 1, CMAP_SPLIT_PAIRS = 2, CMAP_TANHGRAD = 3, CMAP_ADD = 4 };
+template <int CMAP>
+__device__ __forceinline__ float cmap_stage(const GemmParams& p, const size_t i, const float v) {
+    if constexpr (CMAP == CMAP_TANHGRAD) { const float y = p.aux[i]; return v * (1.0f - y * y); }
+    else if constexpr (CMAP == CMAP_ADD) return p.aux[i] + v;
+    else return v;
+}
 template <int CMAP>
 __device__ __forceinline__ size_t cmap_col(const GemmParams& p, const int col) {
     if constexpr (CMAP == CMAP_JOIN_PAIRS) return (size_t)(2 * col - (col & 1));
@@ -479,14 +487,20 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, con
                     }
                 }
             } else if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
-                float* Cc = Cz + (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + cmap_col<CMAP>(p, col);
+                const size_t c0 = (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + cmap_col<CMAP>(p, col);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Cc[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[a][b][r] + bj;
+                for (int r = 0; r < 16; ++r) {
+                    const size_t i = c0 + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc;
+                    Cz[i] = cmap_stage<CMAP>(p, i, acc[a][b][r] + bj);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < p.M && col < p.N) Cz[(size_t)row * p.ldc + cmap_col<CMAP>(p, col)] = acc[a][b][r] + bj;
+                    if (row < p.M && col < p.N) {
+                        const size_t i = (size_t)row * p.ldc + cmap_col<CMAP>(p, col);
+                        Cz[i] = cmap_stage<CMAP>(p, i, acc[a][b][r] + bj);
+                    }
                 }
             }
         }

@@ -221,7 +221,7 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
  * slower), 16 large layers: optimizer update of the dense kernel in the epilogue of its unsplit weight-gradient tiles
  * (default 0: measured slower), 17 few-row dense backward as one grid (default 1), 18 R0 of the next batch on the
  * backward launch of double-buffered pipelined steps (default 0), 19 equaliser step: element-wise stages in GEMM
- * epilogues (default 1), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
+ * stores (1 few-row tiles, 2 = default: also larger batches), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
  * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--paths", nargs="+", default=["fused-graph", "fused-eager", "composed-autograd"])
+    ap.add_argument("--ab", default="", help="KEY=V1,V2,..: time the eager fused step under each value of a dccn_set_tuning "
+                                             "key, alternating inside this process (boxes differ; only this decides)")
+    ap.add_argument("--rounds", type=int, default=5)
     a = ap.parse_args()
     F = H.Flags(nbits=2, nfilter=64, channel="EPA")
     tx = ofdm.ofdm_tx(F)
@@ -54,6 +57,30 @@ def main():
             ce.backward()
             tr._adam_step()
 
+        if a.ab:
+            from dl_ofdm_amd import _lib
+            lib = _lib.load()
+            key, vals = a.ab.split("=")
+            key, vals = int(key), [int(v) for v in vals.split(",")]
+            default = lib.dccn_get_tuning(key)
+            times = {v: [] for v in vals}
+            st = torch.cuda.current_stream().cuda_stream
+            for r in range(a.rounds):
+                for v in vals:
+                    lib.dccn_set_tuning(key, v)
+                    for _ in range(a.warmup):
+                        pl.run(True, False)
+                    torch.cuda.synchronize()
+                    t = HipTimer()
+                    t.start(st)
+                    for _ in range(a.steps):
+                        pl.run(True, False)
+                    t.stop(st)
+                    times[v].append(t.elapsed_ms() / a.steps)
+            lib.dccn_set_tuning(key, default)
+            print(json.dumps(dict(frames=B, key=key, median_ms={v: round(sorted(t)[len(t) // 2], 4) for v, t in times.items()},
+                                  all_ms={v: [round(x, 4) for x in t] for v, t in times.items()})))
+            continue
         for name, fn in (("fused-graph", lambda: pl.run(True, True)), ("fused-eager", lambda: pl.run(True, False)),
                          ("composed-autograd", composed)):
             if name not in a.paths:
