@@ -108,6 +108,8 @@ SIGNATURES = {
     "dccn_dense_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_dense_tail_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_cconv_im2col": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
+    "dccn_cconv_patch_supported": (_i, [_i] * 9),
+    "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
     "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),

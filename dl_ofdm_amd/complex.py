@@ -127,6 +127,11 @@ def _live_taps(in_size: int, k: int, stride: int, out: int, pad_before: int) -> 
     return [a for a in range(k) if any(0 <= o * stride + a - pad_before < in_size for o in range(out))]
 
 
+# general-k convolutions run as an implicit GEMM when the shapes qualify (ops.cconv_patch_supported); False forces the
+# im2col + GEMM route (the fallback, and the reference point of tools/convbench.py)
+IMPLICIT_GEMM = True
+
+
 def _split_complex(inputs: torch.Tensor):
     return torch.stack([inputs.real, inputs.imag], dim=-1).to(torch.float32)
 
@@ -179,6 +184,10 @@ def _cconv_lower(x5: torch.Tensor, filters: int, ksize, strides, padding: str, s
         return ops.cconv2d_same(x5[:, :, :, 0, :], kern.view(kL, kW, 2), bias).view(B, L, Wd, 1, 2)
     if len(tl) == 1 and len(tw) == 1 and (sL, sW) == (1, 1) and Lo == L and Wo == Wd and tl[0] == pl0 and tw[0] == pw0:
         rows = x5.reshape(B * L * Wd, C, 2)                               # one live tap over the input itself: no gather
+    elif IMPLICIT_GEMM and ops.cconv_patch_supported(x5, Lo, Wo, len(tl), len(tw), filters):
+        # implicit GEMM: the operand loader gathers the taps, the k-inflated patch tensor never exists in the forward
+        out = ops.cconv_patch(x5, kern.reshape(-1, 2 * filters), bias, Lo, Wo, tl, tw, (sL, sW), (pl0, pw0))
+        return out.view(B, Lo, Wo, filters, 2)
     else:
         rows = ops.cconv_im2col(x5, Lo, Wo, tl, tw, (sL, sW), (pl0, pw0))  # HIP patch gather [B*Lo*Wo, tl*tw*C, 2]
     out = ops.cconv_gemm(rows, kern.reshape(-1, 2 * filters), bias)

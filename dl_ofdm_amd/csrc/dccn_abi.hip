@@ -2098,6 +2098,34 @@ int dccn_cconv_im2col(const float* x, float* rows, int B, int L, int Wd, int C, 
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
+// the same convolution without the patch tensor: the GEMM's A-loader gathers the taps (gemm_f32_mfma.h OP_KPATCH)
+int dccn_cconv_patch_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int F) {
+    // float4 pieces must not straddle cells: 2C multiple of 4; 32-bit element offsets into x; weights on the vector loaders
+    if (B <= 0 || L <= 0 || Wd <= 0 || C <= 0 || Lo <= 0 || Wo <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
+    if ((C % 2) != 0 || (F % 2) != 0) return 0;
+    if ((long long)B * L * Wd * C * 2 >= (1LL << 31) || (long long)B * Lo * Wo >= (1LL << 31)) return 0;
+    if ((long long)ntl * ntw * C * 2 * 2 * F * 4 >= (1LL << 31)) return 0;
+    return 1;
+}
+int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, float* out, int B, int L, int Wd, int C, int Lo,
+                         int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
+                         dccn_stream_t stream) {
+    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
+    if (!x || !w || !out || !im2col_geom_ok(g) || !dccn_cconv_patch_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, F) ||
+        !aligned16(x) || !aligned16(w))
+        return DCCN_ERR_INVALID_ARG;
+    const int kin = ntl * ntw * C;
+    GemmParams p = gp_zero();                 // out[rows,2F] = patches[rows,2kin] . Weff[2kin,2F]
+    p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
+    p.M = B * Lo * Wo; p.N = 2 * F; p.K = 2 * kin;
+    p.lda = 0; p.ldb = 2 * F; p.ldc = 2 * F;
+    p.klen = round_k(2 * kin);
+    p.cF = F;
+    p.vecA = 1; p.vecB = 1;
+    p.pg.L = L; p.pg.Wd = Wd; p.pg.c2 = 2 * C; p.pg.Lo = Lo; p.pg.Wo = Wo; p.pg.ntl = ntl; p.pg.ntw = ntw;
+    p.pg.sL = sL; p.pg.sW = sW; p.pg.l0 = tl0 - pl0; p.pg.w0 = tw0 - pw0;
+    return launch_gemm<OP_KPATCH, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, (hipStream_t)stream);
+}
 int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
                       int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
     const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};

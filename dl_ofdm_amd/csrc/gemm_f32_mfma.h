@@ -21,6 +21,12 @@
 //                so that x[rows,(n,iq)] . Weff = out[rows,(f,re/im)] : the four real
 //                sub-convolutions of the C-Conv are ONE GEMM with interleaved IQ in/out.
 //   OP_CCONV_WT  Weff transposed (for dX = dOut . Weff^T)
+//   OP_KPATCH    the im2col patch matrix of a general-k complex convolution (dev/py/complex.py:51-92, 140-196), never
+//                materialised: row i = output position (b, lo, wo), column k = (tap ti, tap tj, channel, iq) is
+//                x[b, lo*sL + l0 + ti, wo*sW + w0 + tj, c, iq] or 0 where TensorFlow's padding lies (PatchGeom).  For a
+//                fixed (row, ti) the (tj, c, iq) run is contiguous in x, so the loader still fetches float4s; what it
+//                adds is address arithmetic and a validity mask per piece.  The k-inflated patch tensor of the im2col
+//                route (k = 5: five times the input, written once and read once) never touches HBM.
 //
 // Block = 256 threads = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) made of 32x32 MFMA tiles.
 #pragma once
@@ -31,9 +37,15 @@ namespace dccn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum OperandKind : int { OP_ICONTIG = 0, OP_KCONTIG = 1, OP_CCONV_W = 2, OP_CCONV_WT = 3 };
+enum OperandKind : int { OP_ICONTIG = 0, OP_KCONTIG = 1, OP_CCONV_W = 2, OP_CCONV_WT = 3, OP_KPATCH = 4 };
 enum GemmTag : int { TAG_DENSE_FWD = 0, TAG_DENSE_BWD_X = 1, TAG_DENSE_BWD_W = 2, TAG_CCONV_FWD = 3, TAG_CCONV_BWD_X = 4,
                      TAG_CCONV_BWD_W = 5 };
+
+// geometry of an OP_KPATCH operand: x [B, L, Wd, C, 2]; live taps ntl x ntw; l = lo*sL + l0 + ti, w = wo*sW + w0 + tj
+// (l0 = first live tap - padding before, may be negative); c2 = 2C floats per cell
+struct PatchGeom {
+    int L, Wd, c2, Lo, Wo, ntl, ntw, sL, sW, l0, w0;
+};
 
 struct GemmParams {
     const float* A;
@@ -59,6 +71,7 @@ struct GemmParams {
     // 4 v + aux): the other operand of stages 3 and 4, same shape and row stride as C
     const float* aux;
     long long gC;        // CMAP_SPLIT_PAIRS stores (gemm_store): elements between the two destination buffers
+    PatchGeom pg;        // OP_KPATCH operand A
     float* ad_p; float* ad_m; float* ad_v;
     const float* ad_reg; const float* ad_gate;
     const dccn_adam_state* ad_state;
@@ -91,7 +104,8 @@ struct Tile {
     static constexpr int LD = BK + 4;
     static constexpr bool IC = (KIND == OP_ICONTIG);
     static constexpr bool CC = (KIND == OP_CCONV_W || KIND == OP_CCONV_WT);
-    static constexpr int NOFF = CC ? 2 * NV : NV;
+    static constexpr bool PATCH = (KIND == OP_KPATCH);
+    static constexpr int NOFF = CC ? 2 * NV : (PATCH ? 3 * NV : NV);
     static_assert(NV >= 1 && (!IC || NV % 4 == 0) && (KIND != OP_CCONV_W || NV % 2 == 0), "tile too small for the thread block");
     float4 r[NV];
     unsigned okmask;        // masked path: bit v = piece v lies inside the k range (applied at LDS-write time)
@@ -169,6 +183,44 @@ struct Tile {
             const float sgn = ((negmask >> v) & 1u) ? -1.f : 1.f;
             r[v] = make_float4(sgn * a.x, sgn * b.x, sgn * a.y, sgn * b.y);
         }
+    }
+
+    // ---- OP_KPATCH ------------------------------------------------------------------------------------
+    // Every piece of a thread sits in the same float4 column of the k-tile (idx % (BK/4) = tid % (BK/4)), so the tap
+    // decomposition of that column -- two integer divisions -- is done once per thread and k-tile (piece 0) and shared;
+    // a piece adds its row's (l, w) origin, tests the padding and forms one address.
+    // voff[3v] = element offset of x[b, 0, 0, 0, 0]; voff[3v+1] / [3v+2] = the row's l / w at tap (0,0) (may be < 0)
+    int p_ti, p_tj, p_cc;
+    bool p_kok;
+    __device__ __forceinline__ void init_patch(const PatchGeom& g, int i0, int I, int tid) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * kGemmThreads;
+            const int i = min(i0 + idx / (BK / 4), I - 1);
+            const int per = g.Lo * g.Wo;
+            const int b = i / per, rem = i - b * per, lo = rem / g.Wo, wo = rem - lo * g.Wo;
+            voff[3 * v] = (unsigned)(b * g.L * g.Wd * g.c2);
+            voff[3 * v + 1] = (unsigned)(lo * g.sL + g.l0);
+            voff[3 * v + 2] = (unsigned)(wo * g.sW + g.w0);
+        }
+    }
+    __device__ __forceinline__ void load_patch(int v, const float* __restrict__ p, const PatchGeom& g, int k0, int kend,
+                                               int K, int tid) {
+        if (v == 0) {
+            const int k = k0 + (tid % (BK / 4)) * 4;
+            const int kc = min(k, K - 4);
+            const int seg = g.ntw * g.c2;
+            p_ti = kc / seg;
+            const int r2 = kc - p_ti * seg;
+            p_tj = r2 / g.c2;
+            p_cc = r2 - p_tj * g.c2;
+            p_kok = k < kend;
+        }
+        const int l = (int)voff[3 * v + 1] + p_ti, w = (int)voff[3 * v + 2] + p_tj;
+        const bool ok = p_kok && (unsigned)l < (unsigned)g.L && (unsigned)w < (unsigned)g.Wd;
+        const unsigned off = ok ? (unsigned)((l * g.Wd + w) * g.c2 + p_cc) : 0u;       // (padding: any legal address)
+        r[v] = *reinterpret_cast<const float4*>(p + (size_t)voff[3 * v] + off);
+        okmask = (okmask & ~(1u << v)) | ((ok ? 1u : 0u) << v);
     }
 
     // ---- masked path ------------------------------------------------------------------------
@@ -310,8 +362,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
     TB tb;
     ta.okmask = 0u;
     tb.okmask = 0u;
+    // (a patch operand has one loader for every k-tile: address + padding mask per piece; its LDS writes apply the mask)
+    constexpr bool APATCH = KA == OP_KPATCH;
+    if constexpr (APATCH) ta.init_patch(p.pg, m0, p.M, tid);
     if constexpr (VEC) {
-        ta.init_fast(p.lda, m0, p.M, p.cF, tid);
+        if constexpr (!APATCH) ta.init_fast(p.lda, m0, p.M, p.cF, tid);
         tb.init_fast(p.ldb, n0, p.N, p.cF, tid);
     }
     constexpr int PA = TA::NV, PB = TB::NV;
@@ -321,7 +376,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
 
     auto load_a = [&](auto mode_tag, int v, int k0) {
         constexpr int MODE = decltype(mode_tag)::value;
-        if constexpr (MODE == PF_FAST) ta.load_fast(v, TA::tile_base(p.A, p.lda, k0, p.cF), p.cF);
+        if constexpr (KA == OP_KPATCH) ta.load_patch(v, p.A, p.pg, k0, kend, p.K, tid);
+        else if constexpr (MODE == PF_FAST) ta.load_fast(v, TA::tile_base(p.A, p.lda, k0, p.cF), p.cF);
         else ta.template load_masked<VEC>(v, p.A, p.lda, k0, kend, p.K, m0, p.M, p.cF, tid);
     };
     auto load_b = [&](auto mode_tag, int v, int k0) {
@@ -336,7 +392,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
 #pragma unroll
         for (int v = 0; v < PB; ++v) load_b(mode_tag, v, kbeg);
 #pragma unroll
-        for (int v = 0; v < PA; ++v) ta.template store_piece<MODE == PF_MASKED>(v, sA, tid);
+        for (int v = 0; v < PA; ++v) ta.template store_piece<MODE == PF_MASKED || APATCH>(v, sA, tid);
 #pragma unroll
         for (int v = 0; v < PB; ++v) tb.template store_piece<MODE == PF_MASKED>(v, sB, tid);
     };
@@ -395,7 +451,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int L, 
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (MODE != PF_NONE) {
                     constexpr int S0 = NSTEP - PA - PB;
-                    if (step >= S0 && step < S0 + PA) ta.template store_piece<MODE == PF_MASKED>(step - S0, An, tid);
+                    if (step >= S0 && step < S0 + PA) ta.template store_piece<MODE == PF_MASKED || APATCH>(step - S0, An, tid);
                     else if (step >= S0 + PA) tb.template store_piece<MODE == PF_MASKED>(step - S0 - PA, Bn, tid);
                 }
             }
@@ -626,7 +682,8 @@ static inline bool grouped_big_ok(const GemmParams& px, const GemmParams& pw, in
 template <int KA, int KB, int COLSUM, int TAG>
 static int launch_gemm(const GemmParams& p, int splits, hipStream_t s) {
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * splits;
-    if (big >= 2 * kCUs) return launch_gemm_cfg<KA, KB, 128, 128, 32, COLSUM, TAG>(p, splits, s);
+    // (an output of <= 64 columns or rows would leave half of every 128-wide tile empty)
+    if (big >= 2 * kCUs && p.N > 64 && p.M > 64) return launch_gemm_cfg<KA, KB, 128, 128, 32, COLSUM, TAG>(p, splits, s);
     // the N=64 C-Conv forward (K = 2*(N+CP) = 160, or 128 without the cyclic prefix): the whole k range as ONE tile --
     // all of a block's loads are issued together (one exposed memory latency instead of five) and no k-tile barrier
     if constexpr (KA == OP_KCONTIG && KB == OP_CCONV_W) {

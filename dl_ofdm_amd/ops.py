@@ -191,6 +191,70 @@ def cconv_im2col(x: torch.Tensor, Lo: int, Wo: int, taps_l, taps_w, strides, pad
     return _Im2col.apply(x.contiguous(), geom)
 
 
+class _CConvPatch(torch.autograd.Function):
+    """dccn_cconv_patch_fwd: the general-k complex convolution as an implicit GEMM (the operand loader gathers the taps;
+    no patch tensor in the forward).  The backward materialises the patches once (dccn_cconv_im2col) for the weight
+    gradient and scatters the input gradient back with dccn_cconv_col2im -- the same operators the im2col route uses."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, geom):
+        _need_cuda(x, w, bias); _f32(x, w, bias)
+        B, L, Wd, C, _ = x.shape
+        Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0 = geom
+        F = w.shape[1] // 2
+        out = torch.empty(B * Lo * Wo, F, 2, dtype=torch.float32, device=x.device)
+        check(_lib.load().dccn_cconv_patch_fwd(_p(x), _p(w), _p(bias), _p(out), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW,
+                                               pl0, pw0, F, _stream()), "dccn_cconv_patch_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.geom, ctx.has_bias = geom, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        lib = _lib.load()
+        B, L, Wd, C, _ = x.shape
+        Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0 = ctx.geom
+        dout = dout.contiguous()
+        rows, kin, F = B * Lo * Wo, ntl * ntw * C, w.shape[1] // 2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            drows = torch.empty(rows, kin, 2, dtype=torch.float32, device=x.device)
+            check(lib.dccn_cconv_gemm_bwd_x(_p(dout), _p(w), _p(drows), rows, kin, F, _stream()), "dccn_cconv_gemm_bwd_x")
+            dx = torch.empty_like(x)
+            check(lib.dccn_cconv_col2im(_p(drows), _p(dx), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0, _stream()),
+                  "dccn_cconv_col2im")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            patches = torch.empty(rows, kin, 2, dtype=torch.float32, device=x.device)
+            check(lib.dccn_cconv_im2col(_p(x), _p(patches), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0, _stream()),
+                  "dccn_cconv_im2col")
+            dw = torch.empty_like(w)
+            db = torch.empty(2 * F, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_cconv_gemm_bwd_w_workspace_size(rows, kin, F)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_cconv_gemm_bwd_w(_p(patches), _p(dout), _p(dw), _p(db), rows, kin, F, _p(ws), nws, _stream()),
+                  "dccn_cconv_gemm_bwd_w")
+        return dx, dw, db, None
+
+
+def cconv_patch_supported(x: torch.Tensor, Lo: int, Wo: int, ntl: int, ntw: int, F: int) -> bool:
+    B, L, Wd, C, _ = x.shape
+    return bool(_lib.load().dccn_cconv_patch_supported(B, L, Wd, C, int(Lo), int(Wo), int(ntl), int(ntw), int(F)))
+
+
+def cconv_patch(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Lo: int, Wo: int, taps_l, taps_w, strides,
+                pads) -> torch.Tensor:
+    """General-k complex convolution, x [B, L, Wd, C, 2], w [ntl*ntw*C, 2F] over the live taps -> [B*Lo*Wo, F, 2]: what
+    ``cconv_gemm(cconv_im2col(x, ...), w, bias)`` computes, with the patches gathered inside the GEMM (same geometry
+    arguments and the same contiguous-live-taps restriction as :func:`cconv_im2col`)."""
+    tl, tw = list(taps_l), list(taps_w)
+    if tl != list(range(tl[0], tl[0] + len(tl))) or tw != list(range(tw[0], tw[0] + len(tw))):
+        raise ValueError("live taps must form a contiguous range (undilated kernels only)")
+    geom = (int(Lo), int(Wo), len(tl), len(tw), int(tl[0]), int(tw[0]), int(strides[0]), int(strides[1]), int(pads[0]),
+            int(pads[1]))
+    return _CConvPatch.apply(x.contiguous(), w.contiguous(), None if bias is None else bias.contiguous(), geom)
+
+
 def cconv_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """Complex convolution in GEMM form (complex.py:140-196 after im2col).
 

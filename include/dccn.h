@@ -163,6 +163,14 @@ int dccn_cconv_im2col(const float* x, float* rows, int B, int L, int Wd, int C, 
                       int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream);
 int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
                       int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream);
+/* The forward of the same convolutions WITHOUT the patch tensor (dev/py/complex.py:51-92, :140-196 as an implicit GEMM):
+ * out [B*Lo*Wo, F, 2] = patches(x) . Weff(w) + bias, the GEMM's operand loader gathering the taps from x [B, L, Wd, C, 2]
+ * itself; w [ntl*ntw*C, 2F] = [Wa|Wb] over the live taps, bias [2F] nullable.  dccn_cconv_patch_supported: 1 when the
+ * shapes qualify (even C and F, 32-bit element offsets); otherwise use dccn_cconv_im2col + dccn_cconv_gemm_fwd. */
+int dccn_cconv_patch_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int F);
+int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, float* out, int B, int L, int Wd, int C, int Lo,
+                         int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
+                         dccn_stream_t stream);
 
 /* The in-graph AWGN monitor branch of the receiver graph (dev/py/radio.py:62-88 AWGN_channel, called at
  * dev/py/ofdmreceiver_np.py:136; tensors `tx_signal:0`, `iq_tx:0`, `iq_rx:0`, `noise_power:0`, :151-152,172-183):

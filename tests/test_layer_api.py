@@ -141,6 +141,70 @@ def test_conv1d_layers_vs_literal():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,F,k,stride,padding", [
+    ((4, 37, 6, 2), 8, 5, 1, "same"),          # k = 5: two taps of padding at either end
+    ((3, 64, 4, 2), 6, 5, 2, "same"),          # strided
+    ((2, 33, 8, 2), 4, 7, 1, "valid"),
+    ((5, 9, 2, 2), 2, 3, 3, "same"),           # stride = kernel size
+    ((2, 130, 64, 2), 64, 5, 1, "same"),       # several 64-deep k-tiles (K = 640), more than one row tile
+])
+def test_conv1d_implicit_gemm_vs_literal_and_im2col(shape, F, k, stride, padding):
+    """general-k layers_conv1d_complex (complex.py:51-92) as an implicit GEMM (dccn_cconv_patch_fwd): against the literal
+    fp64 restatement, and against the im2col + GEMM route it replaces (forward to 1e-5; the backward runs the same
+    operators on the same cotangent, so the gradients agree to the last bit)."""
+    from dl_ofdm_amd import complex as CX
+    rng = np.random.RandomState(2)
+    x = rng.randn(*shape).astype(np.float32)
+    C = shape[2]
+    res = {}
+    for implicit in (True, False):
+        CX.IMPLICIT_GEMM = implicit
+        try:
+            st = CX.VariableStore(seed=9)
+            xt = torch.as_tensor(x).cuda().requires_grad_()
+            CX.layers_conv1d_complex(xt, F, k, strides=stride, padding=padding, scope=st)      # creates the variables
+            st.set("conv2d/bias", np.random.RandomState(4).randn(2 * F))
+            st.begin()
+            y = CX.layers_conv1d_complex(xt, F, k, strides=stride, padding=padding, scope=st)
+            g = torch.as_tensor(np.random.RandomState(5).randn(*y.shape).astype(np.float32)).cuda()
+            y.backward(g)
+            res[implicit] = (y.detach().cpu().numpy(), xt.grad.cpu().numpy(), st.tensor("conv2d/kernel").grad.cpu().numpy(),
+                             st.tensor("conv2d/bias").grad.cpu().numpy())
+            if implicit:
+                assert st.meta["conv2d/kernel"]["live_taps"][0] == tuple(range(k))
+                kern = st.tensor("conv2d/kernel").detach().cpu().numpy().astype(np.float64).reshape(k, 1, C, 2 * F)
+                bias = st.tensor("conv2d/bias").detach().cpu().numpy().astype(np.float64)
+                ref = O.layers_conv1d_complex_literal(x.astype(np.float64), kern, bias, stride, padding)
+                assert relerr(res[True][0], ref) <= 1e-5
+        finally:
+            CX.IMPLICIT_GEMM = True
+    assert relerr(res[True][0], res[False][0]) <= 1e-5
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_conv2d_implicit_gemm_two_tap_axes():
+    """taps over both axes, strides (2, 1), VALID and SAME: the loader's (ti, tj) arithmetic"""
+    from dl_ofdm_amd import complex as CX, ops
+    rng = np.random.RandomState(6)
+    for shape, F, kern, strides, padding in (((2, 9, 10, 4, 2), 6, (3, 2), (2, 1), "valid"),
+                                             ((3, 8, 12, 2, 2), 4, (3, 5), (1, 2), "same")):
+        x = rng.randn(*shape).astype(np.float32)
+        st = CX.VariableStore(seed=3)
+        xt = torch.as_tensor(x).cuda()
+        assert ops.cconv_patch_supported(xt, 1, 1, kern[0], kern[1], F)
+        CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
+        st.set("conv3d/bias", rng.randn(2 * F))
+        st.begin()
+        y = CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
+        full = _full_kernel(st, "conv3d", rng)
+        ref = O.layers_conv2d_complex_literal(x.astype(np.float64), full,
+                                              st.tensor("conv3d/bias").detach().cpu().numpy().astype(np.float64), strides, padding)
+        assert relerr(y.detach().cpu().numpy(), ref) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_composable_model_equals_fused_engine():
     from dl_ofdm_amd import ofdm
     from dl_ofdm_amd.engine import RxEngine

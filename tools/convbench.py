@@ -1,0 +1,62 @@
+"""General-k complex convolution (dev/py/complex.py:51-92 layers_conv1d_complex): implicit GEMM (dccn_cconv_patch_fwd, the
+operand loader gathers the taps) against the im2col + GEMM route (dccn_cconv_im2col writes the k-inflated patch tensor,
+dccn_cconv_gemm_fwd reads it back), forward only, same process, alternating rounds.
+
+    python tools/convbench.py [--k 5] [--iters 100] [--rounds 5]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dl_ofdm_amd import complex as CX          # noqa: E402
+from dl_ofdm_amd.engine import HipTimer        # noqa: E402
+
+SHAPES = [  # (B, L, C, F)
+    (1170, 560, 2, 64),       # one frame of time-domain samples per row, 64 filters
+    (256, 1120, 16, 32),
+    (64, 4096, 64, 64),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--rounds", type=int, default=5)
+    a = ap.parse_args()
+    st_ = torch.cuda.current_stream().cuda_stream
+    for B, L, C, F in SHAPES:
+        x = torch.randn(B, L, C, 2, device="cuda")
+        store = CX.VariableStore(seed=1)
+        with torch.no_grad():
+            CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+        times = {True: [], False: []}
+        for _ in range(a.rounds):
+            for implicit in (True, False):
+                CX.IMPLICIT_GEMM = implicit
+                with torch.no_grad():
+                    for _ in range(5):
+                        store.begin()
+                        CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+                    torch.cuda.synchronize()
+                    t = HipTimer()
+                    t.start(st_)
+                    for _ in range(a.iters):
+                        store.begin()
+                        CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+                    t.stop(st_)
+                times[implicit].append(t.elapsed_ms() / a.iters)
+        CX.IMPLICIT_GEMM = True
+        med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
+        flop = 2.0 * B * L * (2 * a.k * C) * (2 * F)
+        print(json.dumps(dict(shape=dict(B=B, L=L, C=C, F=F, k=a.k), implicit_ms=round(med[True], 4), im2col_ms=round(med[False], 4),
+                              speedup=round(med[False] / med[True], 2), implicit_tflops=round(flop / med[True] / 1e9, 2),
+                              patch_tensor_mb=round(B * L * a.k * C * 2 * 4 / 1e6, 1))))
+
+
+if __name__ == "__main__":
+    main()
