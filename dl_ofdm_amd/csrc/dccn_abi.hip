@@ -955,9 +955,11 @@ static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, i
 }
 // which steps take the fused launch for 8-QAM / 16-QAM (knob 13: bit 0 = the lane-per-cell forms -- nbits 3, and nbits 4
 // evaluation; bit 1 = the quad-lane form of 16-QAM training).  The operator dccn_dense_tail_* itself accepts every nbits.
-static bool dense_tail_planned(int nbits, bool train) {
-    if (nbits <= 2) return true;
+// bit 2: BPSK / QPSK steps of LARGE layers (>= two rounds of 128x128 tiles) run the dense forward on the 128x128x32 tile
+// family and the tail as its own launch.
+static bool dense_tail_planned(int nbits, bool train, int M = 0, int N = 0) {
     const int k = g_tune[TUNE_TAIL_FUSE_HI];
+    if (nbits <= 2) return !((k & 4) && (long long)ceil_div(M, 128) * ceil_div(N, 128) >= 2 * kCUs);
     return (nbits == 4 && train) ? (k & 2) != 0 : (k & 1) != 0;
 }
 
@@ -1147,7 +1149,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     if (!(pre && b->x_prenormalised == 2))
         DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     TailFinalizeArgs fin;
-    if (dense_tail_planned(sh->nbits, train) &&
+    if (dense_tail_planned(sh->nbits, train, sh->batch, L.dN) &&
         dense_tail_ok(b->fft_out, P + L.o_dense_w, sh->batch, L.dK, L.dN, sh->nbits)) {
         // R2 with R3-R6 (+ tail backward) in its epilogue; z is materialised only when the caller gave a buffer
         DCCN_TRY(dense_tail_impl(train, b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, b->bits, P + L.o_tail, b->prob,
@@ -1509,7 +1511,7 @@ int dccn_debug_set_trace(unsigned long long* buf) {
 int dccn_dense_tail_supported(int M, int K, int N, int nbits) { return dense_tail_shape_ok(M, K, N, nbits) ? 1 : 0; }
 int dccn_rx_dense_tail_fused(const dccn_rx_shape* sh, int train) {
     if (!shape_ok(sh)) return 0;
-    return dense_tail_planned(sh->nbits, train != 0) &&
+    return dense_tail_planned(sh->nbits, train != 0, sh->batch, 2 * sh->D) &&
            dense_tail_shape_ok(sh->batch, sh->S * 2 * sh->F, 2 * sh->D, sh->nbits) ? 1 : 0;
 }
 int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {

@@ -261,7 +261,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
     TailFinalizeArgs fin;
     bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
-    if (dense_tail_planned(sh->nbits, train) &&
+    if (dense_tail_planned(sh->nbits, train, B, L.dN) &&
         dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
         fin_deferred = replan && train;
         DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
