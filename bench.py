@@ -47,6 +47,17 @@ CONFIGS = {
 }
 
 
+def pipeline_plan(eng):
+    """what a pipelined step launches under the library's current plan (dccn_rx_norm_rides_backward: 0 / 1 / 2)"""
+    ride = int(getattr(eng, "_ride", 0))
+    if ride == 2:
+        return ("3 launches per step: dense fwd + tail | fused backward + R0 of the next batch | "
+                "optimizer + C-Conv fwd of the next batch")
+    if ride == 1:
+        return "4 launches per step: C-Conv fwd | dense fwd + tail | fused backward + R0 of the next batch | optimizer"
+    return "4 launches per step: C-Conv fwd | dense fwd + tail | fused backward | optimizer + R0 of the next batch"
+
+
 def step_flops(c):
     """Algorithmic FLOPs of one training step (SURVEY.md section 8d / BASELINE.md section 2)."""
     S, kin, F, D, b = 7, c["nfft"] + c["cp"], c["F"], c["D"], c["nbits"]
@@ -364,7 +375,7 @@ def main():
         "config": {"workload": c["workload"], "frames_per_step": c["frames"], "symbols_per_step": sym_per_step,
                    "nfft": c["nfft"], "cp": c["cp"], "nfilter": c["F"], "nbits": c["nbits"],
                    "launch": (("hipGraph replay" + (" (forked dW branch)" if fork else " (grouped dense dX+dW launch)")) if use_graph
-                              else "stream launches") + (", software-pipelined across steps (3 launches per step: dense fwd + tail | fused backward + R0 of the next batch | optimizer + C-Conv fwd of the next batch)"
+                              else "stream launches") + (", software-pipelined across steps (" + pipeline_plan(eng) + ")"
                                                           if pipeline else ", 6 launches per step"),
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }

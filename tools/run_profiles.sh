@@ -25,6 +25,10 @@ done
 python tools/eqbench.py --steps 100 > $O/eqbench.jsonl 2>&1
 rocprofv3 --kernel-trace --stats -d $O/eq73_kt -o kt -- python tools/eqbench.py --frames 73 --steps 100 --paths fused-eager > $O/eq73_kt.log 2>&1
 python tools/profile_summary.py $(find $O/eq73_kt -name "*.db" | head -1) > $O/eq73_kernel_stats.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/eq_kt -o kt -- python tools/eqbench.py --frames 1170 --steps 50 --paths fused-eager > $O/eq_kt.log 2>&1
+python tools/profile_summary.py $(find $O/eq_kt -name "*.db" | head -1) > $O/eq_kernel_stats.txt 2>&1
+python tools/eqbench.py --steps 100 --ab 20=0,1 2>&1 | grep -v amdgpu.ids > $O/eqbench_replan_ab.jsonl
+python tools/convbench.py 2>&1 | grep -v amdgpu.ids > $O/convbench.jsonl
 rocprofv3 --kernel-trace --stats -d $O/e2e_kt -o kt -- python tools/e2ebench.py --host-steps 0 > $O/e2e_kt.log 2>&1
 python tools/profile_summary.py $(find $O/e2e_kt -name "*.db" | head -1) > $O/e2e_kernel_stats.txt 2>&1
 DCCN_LIB_PATH=abl/libdccn_trace.so python tools/blocktrace.py --reps 3 --out $O/blocktrace.txt > /dev/null 2>&1
