@@ -199,8 +199,11 @@ static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < 
 
 // ldx > 0: x is a column window of a wider row-major matrix (row stride ldx)
 // act = 2: y = tanh(x.w + bias) when the launch plan has the stage (few-row 16x64 tiles); *act_done tells
+// act = 5 (+ aux = the received cells, out2 / out3): the output is a channel estimate; eq and corr of model.py:431-438
+// leave the same launch
 static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                          hipStream_t s, int ldx = 0, int act = 1, bool* act_done = nullptr) {
+                          hipStream_t s, int ldx = 0, int act = 1, bool* act_done = nullptr, const float* aux = nullptr,
+                          float* out2 = nullptr, float* out3 = nullptr) {
     if (act_done) *act_done = false;
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     const int lda = ldx > 0 ? ldx : K;
@@ -211,7 +214,14 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.klen = round_k(K);
     p.vecA = (K % 4 == 0) && (lda % 4 == 0) && aligned16(x) && small_enough(M, lda);     // KCONTIG: k extent K
     p.vecB = (N % 4 == 0) && aligned16(w) && small_enough(K, N);     // ICONTIG: ld = N, i extent N
+    const bool eq_stage = act == 5 && act_done && aux && out2 && out3 && g_tune[TUNE_EQ_EPILOGUES] && (N % 2 == 0) &&
+                          aligned16(aux) && aligned16(out2) && aligned16(out3);
+    if (eq_stage) { p.aux = aux; p.out2 = out2; p.out3 = out3; }
     if (skinny_ok(p)) {
+        if (eq_stage) {
+            *act_done = true;
+            return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD, 5>(1, p, s);
+        }
         if (act == 2 && act_done && g_tune[TUNE_EQ_EPILOGUES]) {
             *act_done = true;
             return skinny_launch<OP_KCONTIG, OP_ICONTIG, TAG_DENSE_FWD, 2>(1, p, s);
@@ -222,6 +232,10 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     // kernel, loads two k-tiles ahead
     if (g_tune[TUNE_DENSE_FWD_PLAIN] && p.vecA && p.vecB && (K % 4 == 0) && (N % 4 == 0) && K >= 128 &&
         (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs) {
+        if (eq_stage && g_tune[TUNE_EQ_EPILOGUES] >= 2) {
+            *act_done = true;
+            return launch_gemm16<OP_KCONTIG, OP_ICONTIG, 1, 4, 3, 1, 64, 1, 0, TAG_DENSE_FWD, 2, 5>(p, 1, s);
+        }
         if (act == 2 && act_done && g_tune[TUNE_EQ_EPILOGUES] >= 2) {
             *act_done = true;                       // tanh in the store of the same tiles
             return launch_gemm16<OP_KCONTIG, OP_ICONTIG, 1, 4, 3, 1, 64, 1, 0, TAG_DENSE_FWD, 2, 2>(p, 1, s);

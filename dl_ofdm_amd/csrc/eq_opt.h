@@ -9,13 +9,15 @@
 //   EQJ_CCONV_FOLD    Appendix A.2 fold of the dWeff slabs of a (1,K) C-Conv into [Wa|Wb] and its bias pair
 //   EQJ_CONV2D_FOLD   transpose of the block-Toeplitz expansion of the (S,K) smoothing C-Conv (one wave per tap)
 //   EQJ_TAIL_FINALIZE the demodulation tail's per-block metrics -> dccn_metrics (no parameters: the receiver is frozen)
+//   EQJ_PILOT_SNR     the pilot monitor of model.py:465-475 (no parameters either: it only has to run once eq exists)
 #pragma once
 #include "gemm_f32_mfma.h"
 #include "tail.h"
+#include "equalizer.h"
 
 namespace dccn {
 
-enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3 };
+enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3, EQJ_PILOT_SNR = 4 };
 struct EqOptJob {
     int kind, block0, blocks, splits;
     long long off, n;        // arena segment of the (first) variable
@@ -33,6 +35,9 @@ struct EqOptArgs {
     int njobs;
     EqOptJob job[kEqOptJobs];
     TailFinalizeArgs fin;
+    // EQJ_PILOT_SNR
+    const float2* ps_eq; const int* ps_carriers; float* ps_out;
+    int ps_frames, ps_S, ps_K, ps_P;
 };
 
 struct AdamCoef {
@@ -213,6 +218,13 @@ __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dc
         demod_tail_finalize_body(a.fin, bx);
         return;
     }
+    if (J.kind == EQJ_PILOT_SNR) {
+        const int frame = bx * 4 + (int)(threadIdx.x >> 6);
+        if (frame < a.ps_frames)
+            pilot_snr_body<false>(a.ps_eq, nullptr, nullptr, a.ps_carriers, a.ps_out, a.ps_S, a.ps_K, a.ps_P, frame,
+                                  (int)(threadIdx.x & 63));
+        return;
+    }
     AdamCoef k;
     k.alpha = a.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
     if (J.kind == EQJ_SUM) {
@@ -278,6 +290,13 @@ struct EqOptBuilder {
                      long long slab2, int L, int W) {
         EqOptJob* J = add(EQJ_CONV2D_FOLD, ceil_div(L * W + 1, 4));
         if (J) { J->off = off; J->off_b = off_b; J->src = dT; J->src2 = dbe; J->splits = splits; J->slab = slab; J->slab2 = slab2; J->kin = L; J->F = W; }
+    }
+    void pilot_snr(const float* eq, const int* carriers, float* out, int frames, int S, int K, int P) {
+        EqOptJob* J = add(EQJ_PILOT_SNR, ceil_div(frames, 4));
+        if (J) {
+            a.ps_eq = reinterpret_cast<const float2*>(eq); a.ps_carriers = carriers; a.ps_out = out;
+            a.ps_frames = frames; a.ps_S = S; a.ps_K = K; a.ps_P = P;
+        }
     }
     void tail_finalize(const TailFinalizeArgs& fin) {
         EqOptJob* J = add(EQJ_TAIL_FINALIZE, tail_finalize_blocks(fin.P));

@@ -226,10 +226,21 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                            P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
         DCCN_LAUNCH_CHECK();
     }
-    DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s));
-    // :431-438 equalise + autocorrelation, :465-475 pilot monitor
+    // :431-438 equalise + autocorrelation ride on the store of this GEMM when the plan has the stage; the :465-475 pilot
+    // monitor then runs on the optimizer launch (training) or as its own small launch (evaluation)
     const bool want_snr = b->snr_db && b->pilot_carriers && sh->P > 0;
-    if (replan && want_snr) {
+    bool eq_fused = false, snr_pending = false;
+    if (replan) DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s, 0, 5, &eq_fused, w.y, w.eq, w.corr));
+    else DCCN_TRY(dense_fwd_impl(w.d4, w.T, w.be, h, B, SK2, SK2, s));
+    if (eq_fused) {
+        if (want_snr && train) {
+            snr_pending = true;
+        } else if (want_snr) {
+            hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
+                               d.S, K, sh->P);
+            DCCN_LAUNCH_CHECK();
+        }
+    } else if (replan && want_snr) {
         const int eb = (int)ew_blocks_n(nBK / 2);
         hipLaunchKernelGGL(equalize_fwd_snr_kernel, dim3(eb + ceil_div(B, 4)), dim3(256), 0, s, (const float2*)w.y,
                            (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2, eb, b->pilot_carriers, b->snr_db, B,
@@ -379,5 +390,6 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     }
     eq_opt_dense(ob, d, 18, ds5, N2);
     if (fin_deferred) ob.tail_finalize(fin);
+    if (snr_pending) ob.pilot_snr(w.eq, b->pilot_carriers, b->snr_db, B, d.S, K, sh->P);
     return launch_eq_opt(ob, hp, s);
 }

@@ -493,6 +493,26 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
                     float v;
                     if constexpr (KS > 1) v = set == 0 ? tile_val(a, b, rr, lane) : tile_val(a, b, 2 + rr, lane);
                     else v = acc[a][b][rr];
+                    if constexpr (NB == 5) {
+                        // the channel estimate h leaves the GEMM together with what model.py:431-438 computes from it:
+                        // eq = y conj(h)/|h| and corr = eq conj(eq).  Adjacent lanes hold re and im of one cell: they
+                        // swap halves, the even lane stores the cell of eq, the odd lane that of corr (aux = y, out2 = eq,
+                        // out3 = corr, all [M, N] like C).  Same expressions as equalizer.h equalize_one: same bits.
+                        static_assert(KS == 1, "equalise stage: one wave set");
+                        const float o = v + bj;
+                        const float partner = __shfl_xor(o, 1, 64);
+                        if (row < p.M && col < p.N) {
+                            const size_t ci = (size_t)row * p.ldc + col, c0 = ci - (size_t)(col & 1);
+                            Cz[ci] = o;
+                            const float hr = (col & 1) ? partner : o, hi = (col & 1) ? o : partner;
+                            const float2 yv = *reinterpret_cast<const float2*>(p.aux + c0);
+                            const float aa = sqrtf(hr * hr + hi * hi);
+                            const float cr = hr / aa, cim = (-hi) / aa;
+                            const float er = yv.x * cr - yv.y * cim, ei = yv.x * cim + yv.y * cr;
+                            if ((col & 1) == 0) *reinterpret_cast<float2*>(p.out2 + c0) = make_float2(er, ei);
+                            else *reinterpret_cast<float2*>(p.out3 + c0) = make_float2(er * er - ei * (-ei), er * (-ei) + ei * er);
+                        }
+                    } else
                     if (row < p.M && col < p.N) {
                         // EPI_STORE: NB selects an element-wise stage on the way out (compile time: the plain store pays
                         // nothing): the equaliser's tanh, its gradient, and "add to what is there" (model.py:424, 393-462)

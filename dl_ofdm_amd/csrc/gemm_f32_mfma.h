@@ -70,6 +70,7 @@ struct GemmParams {
     // gemm16.h store epilogue with an element-wise stage (template parameter NB of EPI_STORE: 2 tanh, 3 v (1 - aux^2),
     // 4 v + aux): the other operand of stages 3 and 4, same shape and row stride as C
     const float* aux;
+    float* out2; float* out3;   // gemm16.h EPI_STORE<5> (equalise stage): eq and corr next to C = h, aux = y
     long long gC;        // CMAP_SPLIT_PAIRS stores (gemm_store): elements between the two destination buffers
     PatchGeom pg;        // OP_KPATCH operand A
     float* ad_p; float* ad_m; float* ad_v;
