@@ -243,7 +243,7 @@ def measure_e2e(dev, c, steps=200, warmup=30, channel="EPA", snr_db=10.0):
     return {"workload": "%s + device-side generator: Rayleigh %s at %.0f dB, a fresh %d-frame batch per step" %
                         (c["workload"], channel, snr_db, frames),
             "steps": steps, "ms_per_step": dt * 1e3, "symbols_per_s": frames * 7 / dt,
-            "launches_per_step": "5 generator (grid, IFFT+CP GEMM, taps, FIR, AWGN) + 4 training step",
+            "launches_per_step": "4 generator (grid, IFFT+CP GEMM, FIR drawing its own taps, AWGN) + 4 training step",
             "ce_mean_last": m["ce_mean"], "ber_last": m["berlin"]}
 
 

@@ -146,25 +146,57 @@ __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restric
 // Persistent form: the grid is a fixed number of blocks (<= kChanPartials) that each walk a run of consecutive
 // (frame, 256-sample chunk) items and leave ONE partial sum of |y|^2 each, in a fixed order -- few enough for the AWGN kernel to add
 // them up itself (the separate sum_partials launch of rounds 1-2 is gone).  pbase: this launch's first slot in `partial`.
-constexpr int kChanPartials = 1024;
+constexpr int kChanPartials = 2048;
+// TapGen (enabled): the block draws the static taps of a frame itself when it moves to that frame -- the same Philox
+// draws, coefficients and summation order as channel_taps_kernel, so the impulse response has the same bits; the taps
+// launch disappears when nobody asked for H (the generate-and-train loop of the basic receiver).
+struct TapGen {
+    const float* coeff; const float* alpha;
+    int enabled, n_taps, identity, tap_stride;
+    unsigned offset; unsigned long long seed;
+};
 __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                        float2* __restrict__ y, double* __restrict__ partial, int T,
                                                        int L, const int* __restrict__ frames, int g_stride, int n_frames,
-                                                       int pbase) {
+                                                       int pbase, const TapGen tg, const int ipb) {
     __shared__ double sh[4];
     __shared__ float2 gs[64];
+    __shared__ float2 tap[16];
     const int bx = (T + 255) / 256;
     const int off = (L - 1) / 2;
     double pw = 0.0;
     // a block takes a run of consecutive items: mostly chunks of one frame, whose taps are loaded once
-    const int items = n_frames * bx, ipb = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    // (ipb = items per block, a whole number of frames when the grid allows: a frame's taps are then set up once)
+    const int items = n_frames * bx;
     int cur = -1;
     for (int item = blockIdx.x * ipb; item < min(items, ((int)blockIdx.x + 1) * ipb); ++item) {
         const int fi = item / bx, cb = item - fi * bx;
         const int fr = frames ? frames[fi] : fi;
         if (fr != cur) {                                      // (block-uniform)
             __syncthreads();                                  // previous frame's taps are no longer read
-            if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
+            if (!tg.enabled) {
+                if (threadIdx.x < L) gs[threadIdx.x] = g[(size_t)fr * g_stride + threadIdx.x];
+            } else if (tg.identity) {
+                if (threadIdx.x < L) gs[threadIdx.x] = make_float2(threadIdx.x == 0 ? 1.f : 0.f, 0.f);
+            } else {
+                const int t = threadIdx.x;
+                if (t < tg.n_taps) {
+                    const Philox4 p = philox4x32_10((unsigned long long)fr * tg.tap_stride + t, kStreamTaps, tg.offset, tg.seed);
+                    const float2 z = box_muller(p.v[0], p.v[1]);
+                    const float c = tg.coeff[t] * 0.70710678118654752440f;
+                    tap[t] = make_float2(z.x * c, z.y * c);
+                }
+                __syncthreads();
+                if (t < L) {
+                    float2 a = make_float2(0.f, 0.f);
+                    for (int k = 0; k < tg.n_taps; ++k) {
+                        const float w = tg.alpha[k * L + t];
+                        a.x += tap[k].x * w;
+                        a.y += tap[k].y * w;
+                    }
+                    gs[t] = a;
+                }
+            }
             __syncthreads();
             cur = fr;
         }

@@ -1861,11 +1861,22 @@ int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t
     return dense_fwd_impl(grid_ws, idft, nullptr, tx, frames * S, 2 * K, 2 * (K + CP), s);
 }
 static int chan_blocks_x(int T) { return ceil_div(T, 256); }
-// persistent FIR grid: all items when they are few, else four blocks per CU; never more than the partial slots
+// persistent FIR grid: all items when they are few, else eight blocks per CU; never more than the partial slots
 static int fir_blocks(int items, int cap) {
-    int b = items < 4 * kCUs ? items : 4 * kCUs;
+    int b = items < 8 * kCUs ? items : 8 * kCUs;
     if (b > cap) b = cap;
     return b < 1 ? 1 : b;
+}
+// static-channel FIR: whole frames per block (bx items each) so that a frame's taps are set up once in the launch
+struct FirPlan {
+    int blocks, ipb;
+};
+static FirPlan fir_plan(int items, int bx, int cap) {
+    const int b0 = fir_blocks(items, cap);
+    FirPlan p;
+    p.ipb = ceil_div(ceil_div(items, b0), bx) * bx;
+    p.blocks = ceil_div(items, p.ipb);
+    return p;
 }
 size_t dccn_channel_awgn_workspace_size(int frames, int T, int L) {
     if (frames <= 0 || T <= 0 || L <= 0) return 0;
@@ -1892,12 +1903,21 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
     const int bx = chan_blocks_x(T);
     double* partial = c.take<double>((size_t)kChanPartials);
     double* npartial = c.take<double>((size_t)frames * bx);
-    hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
-                       n_taps, L, nfft, identity, offset, seed, (const int*)nullptr, n_taps, L, 1);
-    DCCN_LAUNCH_CHECK();
-    const int nfb = fir_blocks(frames * bx, kChanPartials);
+    // nobody wants the frequency response and the taps are drawn here: the FIR blocks draw them themselves
+    TapGen tg;
+    memset(&tg, 0, sizeof(tg));
+    tg.enabled = (H == nullptr && taps_in == nullptr) ? 1 : 0;
+    tg.coeff = coeff; tg.alpha = alpha; tg.n_taps = n_taps; tg.identity = identity; tg.tap_stride = n_taps;
+    tg.offset = offset; tg.seed = seed;
+    if (!tg.enabled) {
+        hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
+                           n_taps, L, nfft, identity, offset, seed, (const int*)nullptr, n_taps, L, 1);
+        DCCN_LAUNCH_CHECK();
+    }
+    const FirPlan fp = fir_plan(frames * bx, bx, kChanPartials);
+    const int nfb = fp.blocks;
     hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, (const int*)nullptr, L, frames, 0);
+                       (float2*)y, partial, T, L, (const int*)nullptr, L, frames, 0, tg, fp.ipb);
     DCCN_LAUNCH_CHECK();
     const double total = (double)frames * (double)T;
     hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, nfb, total,
@@ -1992,12 +2012,20 @@ int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, 
         if (q.n_frames == 0) continue;
         if (q.identity || q.Fd <= 0.f) {
             const int L = q.identity ? 1 : q.L;
-            hipLaunchKernelGGL(channel_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, taps_in, q.coeff, q.alpha, (float2*)g,
-                               (float2*)H, q.n_taps, L, nfft, q.identity, offset, seed, q.frames, 16, gstride, S);
-            DCCN_LAUNCH_CHECK();
-            const int nfb = fir_blocks(q.n_frames * bx, pcap);
+            TapGen tg;                          // (see dccn_channel_awgn)
+            memset(&tg, 0, sizeof(tg));
+            tg.enabled = (H == nullptr && taps_in == nullptr) ? 1 : 0;
+            tg.coeff = q.coeff; tg.alpha = q.alpha; tg.n_taps = q.n_taps; tg.identity = q.identity; tg.tap_stride = 16;
+            tg.offset = offset; tg.seed = seed;
+            if (!tg.enabled) {
+                hipLaunchKernelGGL(channel_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, taps_in, q.coeff, q.alpha, (float2*)g,
+                                   (float2*)H, q.n_taps, L, nfft, q.identity, offset, seed, q.frames, 16, gstride, S);
+                DCCN_LAUNCH_CHECK();
+            }
+            const FirPlan fp = fir_plan(q.n_frames * bx, bx, pcap);
+            const int nfb = fp.blocks;
             hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                               (float2*)y, partial, T, L, q.frames, gstride, q.n_frames, pbase);
+                               (float2*)y, partial, T, L, q.frames, gstride, q.n_frames, pbase, tg, fp.ipb);
             DCCN_LAUNCH_CHECK();
             pbase += nfb;
         } else {

@@ -90,6 +90,27 @@ def test_channel_and_awgn_match_host_given_the_same_draws(chan):
     assert np.abs(H.cpu().numpy() - Hh).max() <= 2e-5 * max(np.abs(Hh).max(), 1.0)
 
 
+@pytest.mark.parametrize("chan,mix", [("EPA", False), ("ETU", False), ("AWGN", False), ("mixRayleigh", False)])
+def test_taps_drawn_inside_the_fir_launch_are_the_same_taps(chan, mix):
+    """want_H=False: no taps launch, the FIR blocks draw the static taps of their frames themselves (datagen.h TapGen) --
+    same Philox draws, same coefficients, same order of the sums: the received batch has the same bits as with the taps
+    kernel in front (want_H=True), for the plain static channels and the frame-interleaved mix channels"""
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.datagen import DeviceDataGen
+    F = flags(channel=chan)
+    o = ofdm.ofdm_tx(F)
+    n = 301
+    snr = np.linspace(0, 20, n)
+    outs = []
+    for want_H in (True, False):
+        gen = DeviceDataGen(F, o, seed=13, mix=mix)
+        tx, _ = gen.transmit(n)
+        res = gen.channel(tx, snr, want_H=want_H, offset=5)
+        outs.append((res[0].clone(), float(res[1])))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+
+
 def test_random_streams_statistics():
     from dl_ofdm_amd import ofdm
     from dl_ofdm_amd.datagen import DeviceDataGen
