@@ -108,6 +108,10 @@ SIGNATURES = {
     "dccn_dense_tail_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_dense_tail_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dccn_cconv_im2col": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
+    "dccn_eq_bottleneck_supported": (_i, [_i] * 3),
+    "dccn_eq_bottleneck_workspace_size": (C.c_size_t, [_i] * 3),
+    "dccn_eq_bottleneck_fwd": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
+    "dccn_eq_bottleneck_bwd": (_i, [_vp] * 11 + [_i] * 3 + [_vp, C.c_size_t, _vp]),
     "dccn_cconv_patch_supported": (_i, [_i] * 9),
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),

@@ -13,6 +13,7 @@
 #include "rx_bwd.h"
 #include "equalizer.h"
 #include "eq_opt.h"
+#include "eq_bottleneck.h"
 #include "datagen.h"
 #include "im2col.h"
 #include "classical.h"
@@ -2124,6 +2125,47 @@ int dccn_classical_detect(const float* Y, const float* G, const int* dat, const 
     hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)ep, nblk, (const double*)nullptr, 0,
                        errors, (double*)nullptr);
     DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---- the equaliser's pilot bottleneck as one launch per direction (eq_bottleneck.h) ---------------------------
+int dccn_eq_bottleneck_supported(int B, int SK2, int P) {
+    return ((P == 16 || P == 32) && B > 0 && SK2 >= 64 && (SK2 % 64) == 0) ? 1 : 0;
+}
+size_t dccn_eq_bottleneck_workspace_size(int B, int SK2, int P) {
+    if (!dccn_eq_bottleneck_supported(B, SK2, P)) return 0;
+    return align_up(eq_bottleneck_part_floats(B, SK2, P) * sizeof(float), 256);
+}
+int dccn_eq_bottleneck_fwd(const float* y, const float* W1, const float* b1, const float* W2, const float* b2, float* d1,
+                           float* d2, int B, int SK2, int P, dccn_stream_t stream) {
+    if (!y || !W1 || !W2 || !d1 || !d2 || !eq_bottleneck_ok(B, SK2, P, y, W1, W2) || !aligned16(d1)) return DCCN_ERR_INVALID_ARG;
+    const int q = eq_bottleneck_q(B, SK2);
+    auto kern = P == 32 ? eq_bottleneck_fwd_kernel<2> : eq_bottleneck_fwd_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, (hipStream_t)stream, y, W1, b1, W2, b2,
+                       d1, d2, B, SK2, q);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, const float* W1, const float* W2,
+                           const float* dy_in, float* dy_out, float* dW1, float* db1, float* dW2, float* db2, int B, int SK2,
+                           int P, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!dd2 || !d1 || !y || !W1 || !W2 || !dy_in || !dy_out || !dW1 || !db1 || !dW2 || !db2 ||
+        !eq_bottleneck_ok(B, SK2, P, y, W1, W2) || !aligned16(dd2) || !aligned16(d1))
+        return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_eq_bottleneck_workspace_size(B, SK2, P)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = ceil_div(B, 16), q = eq_bottleneck_q(B, SK2);
+    float* pw2 = static_cast<float*>(workspace);
+    float* pb2 = pw2 + (size_t)tiles * P * SK2;
+    float* pw1 = pb2 + (size_t)tiles * SK2;
+    float* pb1 = pw1 + (size_t)tiles * SK2 * P;
+    auto kern = P == 32 ? eq_bottleneck_bwd_kernel<2> : eq_bottleneck_bwd_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
+                       pw1, pb1, B, SK2, q);
+    DCCN_LAUNCH_CHECK();
+    // (the fused equaliser step leaves these sums to its optimizer launch)
+    DCCN_TRY(launch_splitk_reduce2(pw2, tiles, (long long)P * SK2, dW2, (long long)P * SK2, pb2, (long long)SK2, db2, (long long)SK2, s));
+    DCCN_TRY(launch_splitk_reduce2(pw1, tiles, (long long)SK2 * P, dW1, (long long)SK2 * P, pb1, (long long)P, db1, (long long)P, s));
     return DCCN_OK;
 }
 

@@ -51,6 +51,7 @@ struct EqWs {
     // training only
     float *dz, *dfft, *dout, *dcat, *deqc, *dcorc, *deq, *dcorr, *dy, *dh, *dT, *dbe, *dd4, *dd3, *dd2, *dd1,
         *dflat, *dt1, *dtail;
+    float* bn_part;          // per-block weight-gradient partials of the fused bottleneck backward (eq_bottleneck.h)
 };
 static void eq_layer_ws(const EqDims& d, size_t (&n)[EQL_COUNT]) {
     n[EQL_DENSE] = splitk_ws_bytes(d.cp ? 2 * d.nsc : 2 * d.K, 2 * d.K, d.R);
@@ -110,6 +111,7 @@ static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool t
     w.dflat = c.take<float>(B * SK2);
     w.dt1 = c.take<float>(R * K2);
     w.dtail = c.take<float>(tail_param_count(sh->nbits));
+    w.bn_part = c.take<float>((d.Pp == 16 || d.Pp == 32) ? eq_bottleneck_part_floats(d.B, d.SK2, d.Pp) : 0);
 }
 static size_t eq_ws_bytes(const dccn_eq_shape* sh, int train) {
     const EqDims d = eq_dims(sh);
@@ -183,8 +185,12 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
 
     // round-3 plan (TUNE_EQ_REPLAN): merged element-wise launches, the corr / eq C-Conv pair as grouped launches with the
     // concat / split of model.py:456 in the GEMM stores, ONE job-table launch for every gradient reduction + Adam
-    const bool replan = g_tune[TUNE_EQ_REPLAN] != 0;
-    const bool keep_slabs = g_tune[TUNE_EQ_REPLAN] == 1;     // 2: the plan with every dense split-K sum as its own launch (debugging)
+    // TUNE_EQ_REPLAN: 0 launch-per-stage plan, 1 re-plan, 2 re-plan with every dense split-K sum as its own launch
+    // (debugging), 3 re-plan without the fused pilot bottleneck (bit-identical gradients to plan 0)
+    const int plan = g_tune[TUNE_EQ_REPLAN];
+    const bool replan = plan != 0;
+    const bool keep_slabs = plan == 1 || plan == 3;
+    const bool bn = plan == 1 && eq_bottleneck_ok(B, SK2, d.Pp, w.y, P + d.o[4], P + d.o[6]) && aligned16(w.d1);
     const long long g_in = w.corr - w.eq;                                  // eq -> corr stride of the pair's tensors
     const long long g_w = d.o[14] - d.o[16], g_b = d.o[15] - d.o[17];      // conv3d_3 (eq) -> conv3d_2 (corr)
     const bool pair = replan && cconv_pair_ok(w.eq, P + d.o[16], w.cat, R, K, K, g_in, g_w, 2) && aligned16(w.corr) &&
@@ -209,8 +215,16 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_fwd_impl(w.ln + d.win, P + d.o[0], P + d.o[1], w.t1, R, kin0, K2, s, N2));
     DCCN_TRY(cconv_fwd_impl(w.t1, P + d.o[2], P + d.o[3], w.y, R, K, K, s));
     // :394-426 pilot bottleneck
-    DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
-    DCCN_TRY(dense_fwd_impl(w.d1, P + d.o[6], P + d.o[7], w.d2, B, d.Pp, SK2, s));
+    if (bn) {                               // both layers of the bottleneck in one launch (eq_bottleneck.h)
+        auto kern = d.Pp == 32 ? eq_bottleneck_fwd_kernel<2> : eq_bottleneck_fwd_kernel<1>;
+        const int q = eq_bottleneck_q(B, SK2);
+        hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, s, (const float*)w.y, P + d.o[4],
+                           P + d.o[5], P + d.o[6], P + d.o[7], w.d1, w.d2, B, SK2, q);
+        DCCN_LAUNCH_CHECK();
+    } else {
+        DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
+        DCCN_TRY(dense_fwd_impl(w.d1, P + d.o[6], P + d.o[7], w.d2, B, d.Pp, SK2, s));
+    }
     DCCN_TRY(dense_fwd_impl(w.d2, P + d.o[8], P + d.o[9], w.d3, B, SK2, SK2, s));
     {
         bool fused = false;                 // tanh in the GEMM's store when the plan has the stage (few-row batches)
@@ -346,18 +360,36 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                                  w.n_l[EQL_DENSE4], s, 1, nullptr, nullptr, keep_slabs ? &ds4 : nullptr));
     DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_l[EQL_DENSE3],
                                  w.n_l[EQL_DENSE3], s, 1, nullptr, nullptr, keep_slabs ? &ds3 : nullptr));
-    DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_l[EQL_DENSE2],
-                                 w.n_l[EQL_DENSE2], s, 1, nullptr, nullptr, keep_slabs ? &ds2 : nullptr));
-    // dy += (gradient through the pilot branch): by the dX stores themselves when the launch plan has the stage (the sum
-    // then lands in dflat), else by a launch of its own
-    bool add_fused = false;
-    DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
-                                 w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
-    if (!add_fused) {
-        hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
+    const float* dy_sum;
+    const int bn_tiles = ceil_div(B, 16);
+    float* bn_w2 = w.bn_part;                                   // [tiles][P][SK2]
+    float* bn_b2 = bn_w2 + (size_t)bn_tiles * d.Pp * SK2;       // [tiles][SK2]
+    float* bn_w1 = bn_b2 + (size_t)bn_tiles * SK2;              // [tiles][SK2][P]
+    float* bn_b1 = bn_w1 + (size_t)bn_tiles * SK2 * d.Pp;       // [tiles][P]
+    if (bn) {
+        // both layers' backward in one launch: dd1, the branch's input gradient added to dy, per-block partials of the
+        // four weight / bias gradients (summed by the optimizer launch)
+        auto kern = d.Pp == 32 ? eq_bottleneck_bwd_kernel<2> : eq_bottleneck_bwd_kernel<1>;
+        const int q = eq_bottleneck_q(B, SK2);
+        hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), bn_tiles), dim3(256), 0, s, (const float*)w.dd2, (const float*)w.d1,
+                           (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2, bn_w1, bn_b1, B,
+                           SK2, q);
         DCCN_LAUNCH_CHECK();
+        dy_sum = w.dflat;
+    } else {
+        DCCN_TRY(dense_bwd_full_impl(w.d1, w.dd2, P + d.o[6], w.dd1, G + d.o[6], G + d.o[7], B, d.Pp, SK2, w.ws_l[EQL_DENSE2],
+                                     w.n_l[EQL_DENSE2], s, 1, nullptr, nullptr, keep_slabs ? &ds2 : nullptr));
+        // dy += (gradient through the pilot branch): by the dX stores themselves when the launch plan has the stage (the sum
+        // then lands in dflat), else by a launch of its own
+        bool add_fused = false;
+        DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
+                                     w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
+        if (!add_fused) {
+            hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
+            DCCN_LAUNCH_CHECK();
+        }
+        dy_sum = add_fused ? w.dflat : w.dy;
     }
-    const float* dy_sum = add_fused ? w.dflat : w.dy;
     const bool conv_grouped = replan && cconv_pair_ok(w.t1, P + d.o[2], w.dt1, R, K, K, 0, 0, 0) && aligned16(dy_sum);
     if (conv_grouped) {
         DCCN_TRY(cconv_bwd_grouped_impl(w.t1, dy_sum, P + d.o[2], w.dt1, R, K, K, 1, 0, 0, 0, w.ws_l[EQL_CONV], w.n_l[EQL_CONV],
@@ -377,8 +409,15 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     eq_opt_dense(ob, d, 0, ds0, K2);
     if (fconv.slabs) ob.cconv_fold(d.o[2], d.o[3], fconv.slabs, fconv.colsum, fconv.splits, fconv.slab, K, K);
     else { ob.plain(d.o[2], d.sz[2]); ob.plain(d.o[3], d.sz[3]); }
-    eq_opt_dense(ob, d, 4, ds1, d.Pp);
-    eq_opt_dense(ob, d, 6, ds2, SK2);
+    if (bn) {
+        ob.slabs(d.o[4], d.sz[4], bn_w1, bn_tiles, (long long)SK2 * d.Pp);
+        ob.slabs(d.o[5], d.sz[5], bn_b1, bn_tiles, d.Pp);
+        ob.slabs(d.o[6], d.sz[6], bn_w2, bn_tiles, (long long)d.Pp * SK2);
+        ob.slabs(d.o[7], d.sz[7], bn_b2, bn_tiles, SK2);
+    } else {
+        eq_opt_dense(ob, d, 4, ds1, d.Pp);
+        eq_opt_dense(ob, d, 6, ds2, SK2);
+    }
     eq_opt_dense(ob, d, 8, ds3, SK2);
     eq_opt_dense(ob, d, 10, ds4, SK2);
     ob.conv2d_fold(d.o[12], d.o[13], dsT.dw_slabs ? dsT.dw_slabs : w.dT, (dsT.dw_slabs && dsT.db_slabs) ? dsT.db_slabs : w.dbe,

@@ -155,6 +155,20 @@ int dccn_dense_tail_fwd_bwd(const float* x, const float* w, const float* bias, f
                             int M, int K, int N, int nbits, void* workspace, size_t workspace_bytes,
                             dccn_stream_t stream);
 
+/* The equaliser's pilot bottleneck (dev/py/model.py:394-412: dense SK2 -> P, dense P -> SK2, no activation in between) as
+ * ONE launch per direction, a block per 16 frames x a chunk of columns (csrc/eq_bottleneck.h).  P = 2 * pilot_size must be
+ * 16 or 32, SK2 a multiple of 64 (dccn_eq_bottleneck_supported); otherwise use dccn_dense_fwd / dccn_dense_bwd twice.
+ *   fwd: d1 [B,P] = y [B,SK2] . W1 [SK2,P] + b1;  d2 [B,SK2] = d1 . W2 [P,SK2] + b2
+ *   bwd: given dd2 = dLoss/dd2: dy_out = dy_in + (dd2 . W2^T) . W1^T  (the branch's input gradient ADDED to dy_in),
+ *        dW2 = d1^T . dd2, db2, dW1 = y^T . (dd2 . W2^T), db1   (per-block partials summed in a fixed order) */
+int dccn_eq_bottleneck_supported(int B, int SK2, int P);
+size_t dccn_eq_bottleneck_workspace_size(int B, int SK2, int P);
+int dccn_eq_bottleneck_fwd(const float* y, const float* W1, const float* b1, const float* W2, const float* b2, float* d1,
+                           float* d2, int B, int SK2, int P, dccn_stream_t stream);
+int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, const float* W1, const float* W2,
+                           const float* dy_in, float* dy_out, float* dW1, float* db1, float* dW2, float* db2, int B, int SK2,
+                           int P, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 /* Patch gather in front of dccn_cconv_gemm_* for the general-k cases of dev/py/complex.py:51-92 / :140-196 (k taps over
  * one or two axes, strides, TF SAME / VALID geometry): x [B, L, Wd, C, 2] -> rows [B*Lo*Wo, ntl*ntw*C, 2], zeros where
  * SAME padding lies; only the live taps tl0..tl0+ntl-1 / tw0..tw0+ntw-1 (those that ever meet data) are gathered.
@@ -230,7 +244,7 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
  * (default 0: measured slower), 17 few-row dense backward as one grid (default 1), 18 R0 of the next batch on the
  * backward launch of double-buffered pipelined steps (default 0), 19 equaliser step: element-wise stages in GEMM
  * stores (1 few-row tiles, 2 = default: also larger batches), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
- * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2).
+ * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2, 3 = the re-plan without the fused pilot bottleneck).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);

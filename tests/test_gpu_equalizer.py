@@ -356,8 +356,13 @@ def test_equalizer_learns_a_flat_fading_channel():
 
 @pytest.mark.parametrize("cp", [True, False])
 def test_fused_step_equals_composed_step(cp):
-    """the planned launch sequence and the autograd-composed one run the same kernels on the same arenas
-    (cp=False: both read the post-CP window, model.py:364-366 / 1236-1240)"""
+    """the planned launch sequence and the autograd-composed one compute the same step on the same arenas
+    (cp=False: both read the post-CP window, model.py:364-366 / 1236-1240).  Since round 3 the planned step runs the pilot
+    bottleneck as one launch per direction (eq_bottleneck.h, its own summation order) where the composed path runs GEMMs:
+    the channel-estimator branch's gradients are ill-conditioned in fp32 -- either path is 5e-5..1e-4 of scale away from the
+    fp64 autograd reference -- so the two are compared at IDENTICAL parameters every step, to 3e-4 of the gradient's scale
+    (with the fused bottleneck switched off, tuning key 20 = 3, they agree to the last bit:
+    test_round3_launch_plan_equals_round2_plan)"""
     F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=31, cp=cp)
     _, _, _, _, _, _, tr_b = _trainer(seed=31, cp=cp)
     rng = np.random.RandomState(9)
@@ -365,13 +370,19 @@ def test_fused_step_equals_composed_step(cp):
         x = (rng.standard_normal((12, 7, 80, 2)) * 2).astype(np.float32)
         bits = rng.randint(0, 2, (12, tx.frame_size, 2)).astype(np.int32)
         chan = (rng.standard_normal((12, 7, 64)) + 1j * rng.standard_normal((12, 7, 64))).astype(np.complex64)
+        with torch.no_grad():                    # same parameters and optimizer state on both sides before the step
+            for name in ("params", "adam_m", "adam_v", "adam_state"):
+                getattr(tr_b, name).copy_(getattr(tr_a, name))
         ma = tr_a.train_step(x, bits, chan, fused=True, graph=(step % 2 == 0))
         mb = tr_b.train_step(x, bits, chan, fused=False)
         assert ma["conf"] == mb["conf"] and abs(ma["ce_mean"] - mb["ce_mean"]) <= 1e-6
         assert abs(ma["chan_rms"] - mb["chan_rms"]) <= 1e-5 * abs(mb["chan_rms"])
         assert abs(ma["tx_power"] - mb["tx_power"]) <= 1e-6 * abs(mb["tx_power"])
         ga, gb = tr_a.grads.cpu().numpy(), tr_b.grads.cpu().numpy()
-        assert np.abs(ga - gb).max() <= 1e-5 * np.abs(gb).max()
+        assert np.abs(ga - gb).max() <= 3e-4 * np.abs(gb).max()
+    with torch.no_grad():
+        for name in ("params", "adam_m", "adam_v", "adam_state"):
+            getattr(tr_b, name).copy_(getattr(tr_a, name))
     ea, eb = tr_a.eval_step(x, bits, fused=True), tr_b.eval_step(x, bits, fused=False)
     assert ea["conf"] == eb["conf"] and abs(ea["ce_mean"] - eb["ce_mean"]) <= 1e-6
     pl = tr_a._plan(12)
@@ -381,11 +392,14 @@ def test_fused_step_equals_composed_step(cp):
     close(pl.chest, torch.view_as_real(out_b[4]).cpu().numpy(), 1e-5, "chest")
 
 
+@pytest.mark.parametrize("plan", [1, 3])
 @pytest.mark.parametrize("B,cp", [(12, True), (73, True), (73, False), (200, True), (200, False)])
-def test_round3_launch_plan_equals_round2_plan(B, cp):
+def test_round3_launch_plan_equals_round2_plan(B, cp, plan):
     """dccn_set_tuning(20, .): the re-planned step (grouped corr/eq C-Convs, concat / split in GEMM stores, merged
     element-wise launches, one job-table optimizer launch) computes what the launch-per-stage plan computes -- at the
-    few-row batch (direct weight gradients), the reference's 73 frames and a batch whose dense gradients are split-K slabs"""
+    few-row batch (direct weight gradients), the reference's 73 frames and a batch whose dense gradients are split-K slabs.
+    plan 3 = the re-plan without the fused pilot bottleneck: same GEMM plans and summation orders, gradients of the first
+    step bit-identical; plan 1 (default) also runs the bottleneck as one launch per direction (its own summation order)"""
     from dl_ofdm_amd import _lib
     lib = _lib.load()
     F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=41, cp=cp)
@@ -395,33 +409,76 @@ def test_round3_launch_plan_equals_round2_plan(B, cp):
         for step in range(3):
             x = (rng.standard_normal((B, 7, 80, 2)) * 2).astype(np.float32)
             bits = rng.randint(0, 2, (B, tx.frame_size, 2)).astype(np.int32)
-            lib.dccn_set_tuning(20, 1)
+            with torch.no_grad():                # same parameters and optimizer state on both sides before the step
+                for name in ("params", "adam_m", "adam_v", "adam_state"):
+                    getattr(tr_b, name).copy_(getattr(tr_a, name))
+            lib.dccn_set_tuning(20, plan)
             ma = tr_a.train_step(x, bits, fused=True, graph=(step == 1))
             lib.dccn_set_tuning(20, 0)
             mb = tr_b.train_step(x, bits, fused=True, graph=False)
             assert ma["conf"] == mb["conf"] and abs(ma["ce_mean"] - mb["ce_mean"]) <= 1e-6 * abs(mb["ce_mean"])
             assert abs(ma["tx_power"] - mb["tx_power"]) <= 1e-6 * abs(mb["tx_power"])
             ga, gb = tr_a.get_grads(), tr_b.get_grads()
-            if step == 0:                    # same parameters: same GEMM plans, same summation orders -> same bits
+            if plan == 3:                        # same GEMM plans, same summation orders -> same bits, every step
                 diff = {n: float(np.abs(ga[n] - gb[n]).max() / max(np.abs(gb[n]).max(), 1e-30)) for n in tr_a.names
                         if not np.array_equal(ga[n], gb[n])}
                 assert not diff, " ".join("%s=%.1e" % (k.split("/", 1)[1], v) for k, v in diff.items())
-            for n in tr_a.names:
-                assert np.abs(ga[n] - gb[n]).max() <= 5e-5 * max(np.abs(gb[n]).max(), 1e-30), (step, n)
+            # plan 1: the fused bottleneck sums in its own order; the channel-estimator branch is ill-conditioned in fp32
+            # (either plan is 5e-5..1e-4 of scale away from the fp64 reference)
+            gmax = max(float(np.abs(v).max()) for v in gb.values())
+            for n in tr_a.names:             # (variables whose whole gradient is noise-sized are held to the global scale)
+                err = float(np.abs(ga[n] - gb[n]).max())
+                assert err <= 4e-4 * float(np.abs(gb[n]).max()) or err <= 1e-3 * gmax, (step, n, err, gmax)
             pa, pb = tr_a.get_params(), tr_b.get_params()
             for n in tr_a.names:
                 d = np.abs(pa[n] - pb[n]).ravel()
-                assert np.quantile(d, 0.999) <= 2e-6, (step, n, d.max())
+                assert np.quantile(d, 0.99) <= (2e-6 if plan == 3 else 1e-5), (step, n, d.max())       # (lr = 1e-3)
         pl_a, pl_b = tr_a._plan(B), tr_b._plan(B)
         for name in ("out_eq", "snr_db", "chest"):
-            close(getattr(pl_a, name), getattr(pl_b, name).cpu().numpy(), 2e-6, name)
-        lib.dccn_set_tuning(20, 1)
+            close(getattr(pl_a, name), getattr(pl_b, name).cpu().numpy(), 2e-6 if plan == 3 else 1e-4, name)
+        with torch.no_grad():
+            tr_b.params.copy_(tr_a.params)
+        lib.dccn_set_tuning(20, plan)
         ea = tr_a.eval_step(x, bits, fused=True)
         lib.dccn_set_tuning(20, 0)
         eb = tr_b.eval_step(x, bits, fused=True)
         assert ea["conf"] == eb["conf"]
     finally:
         lib.dccn_set_tuning(20, 1)
+
+
+@pytest.mark.parametrize("B,SK2,P", [(73, 896, 32), (12, 896, 32), (200, 896, 16), (33, 128, 32), (16, 64, 16)])
+def test_pilot_bottleneck_one_launch_per_direction(B, SK2, P):
+    """dccn_eq_bottleneck_fwd / _bwd (model.py:394-412: dense SK2 -> P -> SK2 without an activation) against fp64 NumPy on
+    well-conditioned data: 1e-5 of scale, forward and all six backward outputs (ragged last row tile, one or two MFMA tiles
+    across P, a single row tile)"""
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    assert lib.dccn_eq_bottleneck_supported(B, SK2, P) == 1 and lib.dccn_eq_bottleneck_supported(B, SK2, 24) == 0
+    rng = np.random.RandomState(B + P)
+    y = rng.standard_normal((B, SK2)); W1 = rng.standard_normal((SK2, P)) / np.sqrt(SK2); b1 = rng.standard_normal(P) * 0.1
+    W2 = rng.standard_normal((P, SK2)) / np.sqrt(P); b2 = rng.standard_normal(SK2) * 0.1
+    dd2 = rng.standard_normal((B, SK2)); dy = rng.standard_normal((B, SK2))
+    t = {k: dev(v) for k, v in dict(y=y, W1=W1, b1=b1, W2=W2, b2=b2, dd2=dd2, dy=dy).items()}
+    d1 = torch.empty(B, P, device="cuda"); d2 = torch.empty(B, SK2, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda a: a.data_ptr()
+    _lib.check(lib.dccn_eq_bottleneck_fwd(p(t["y"]), p(t["W1"]), p(t["b1"]), p(t["W2"]), p(t["b2"]), p(d1), p(d2), B, SK2, P, st))
+    d1r = y @ W1 + b1
+    close(d1, d1r, 1e-5, "d1")
+    close(d2, d1r @ W2 + b2, 1e-5, "d2")
+    nws = lib.dccn_eq_bottleneck_workspace_size(B, SK2, P)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    out = {k: torch.empty(*shp, device="cuda") for k, shp in dict(dy=(B, SK2), dW1=(SK2, P), db1=(P,), dW2=(P, SK2), db2=(SK2,)).items()}
+    _lib.check(lib.dccn_eq_bottleneck_bwd(p(t["dd2"]), p(d1), p(t["y"]), p(t["W1"]), p(t["W2"]), p(t["dy"]), p(out["dy"]),
+                                          p(out["dW1"]), p(out["db1"]), p(out["dW2"]), p(out["db2"]), B, SK2, P, p(ws), nws, st))
+    d1f = d1.cpu().numpy().astype(np.float64)
+    dd1 = dd2 @ W2.T
+    close(out["dy"], dy + dd1 @ W1.T, 1e-5, "dy")
+    close(out["dW2"], d1f.T @ dd2, 1e-5, "dW2")
+    close(out["db2"], dd2.sum(0), 1e-5, "db2")
+    close(out["dW1"], y.T @ dd1, 1e-5, "dW1")
+    close(out["db1"], dd1.sum(0), 1e-5, "db1")
 
 
 def test_chan_rms_monitor_is_keras_layer_normalization_over_the_symbol_axis():
