@@ -83,6 +83,96 @@ def effective_cpus():
     return n
 
 
+def hip_device_pci(dev):
+    """PCI address 'dddd:bb:dd.f' of a torch device (the box's sysfs lists every GPU of the host, not just ours)."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+
+
+def _cards(pci=None):
+    import glob
+    devs = [d for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+    if pci:
+        mine = [d for d in devs if os.path.basename(os.path.realpath(d)).lower() == pci.lower()]
+        if mine:
+            return mine
+    return devs
+
+
+def gpu_clock_state(pci=None):
+    """sclk / mclk / fclk / socclk DPM state, performance level, power cap and draw of every amdgpu card the box exposes
+    (sysfs, read-only; the container sees the host's /sys/class/drm).  `step.boundaries[*].sclk_mhz` is the clock the CUs
+    really ran at (s_memtime / s_memrealtime inside the kernels); this is what the driver says it set."""
+    import glob
+    out = []
+    for dev in _cards(pci):
+        rec = {"card": os.path.basename(os.path.dirname(dev)), "pci": os.path.basename(os.path.realpath(dev))}
+        for key in ("sclk", "mclk", "fclk", "socclk"):
+            try:
+                lines = [ln.strip() for ln in open(os.path.join(dev, "pp_dpm_" + key)).read().splitlines() if ln.strip()]
+                act = [ln for ln in lines if ln.endswith("*")]
+                rec[key] = (act[0].split(":")[1].strip(" *") if act else None)
+                rec[key + "_levels"] = len(lines)
+            except Exception:
+                pass
+        try:
+            rec["perf_level"] = open(os.path.join(dev, "power_dpm_force_performance_level")).read().strip()
+        except Exception:
+            pass
+        for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+            for key, fn, scale in (("power_cap_w", "power1_cap", 1e-6), ("power_w", "power1_average", 1e-6),
+                                   ("power_in_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                try:
+                    rec[key] = round(int(open(os.path.join(hw, fn)).read().strip()) * scale, 1)
+                except Exception:
+                    pass
+        out.append(rec)
+    return out
+
+
+def box_fingerprint(pci=None):
+    """What distinguishes one box of the pool from another below the (identical) container image: kernel and amdgpu driver,
+    firmware versions, VBIOS, partition modes, visible-VRAM (large BAR) size, PCIe link, and the runtime knobs in the
+    environment.  Read-only sysfs; missing entries are simply absent."""
+    import glob
+    import platform
+    rec = {"kernel": platform.release()}
+    try:
+        rec["amdgpu_version"] = open("/sys/module/amdgpu/version").read().strip()
+    except Exception:
+        pass
+    rec["env"] = {k: v for k, v in os.environ.items() if k.split("_")[0] in ("HSA", "HIP", "GPU", "AMD", "ROCR", "ROCM", "DCCN", "NCCL", "RCCL")}
+    cards = []
+    all_cards = _cards(None)
+    rec["gpus_on_host"] = len(all_cards)
+    for dev in _cards(pci):
+        c = {"card": os.path.basename(os.path.dirname(dev)), "pci": os.path.basename(os.path.realpath(dev))}
+        for key, fn in (("vbios", "vbios_version"), ("compute_partition", "current_compute_partition"),
+                        ("memory_partition", "current_memory_partition"), ("vram_total", "mem_info_vram_total"),
+                        ("vis_vram_total", "mem_info_vis_vram_total"), ("link_speed", "current_link_speed"),
+                        ("link_width", "current_link_width"), ("numa_node", "numa_node"), ("pci_id", "device"),
+                        ("revision", "revision")):
+            try:
+                c[key] = open(os.path.join(dev, fn)).read().strip()
+            except Exception:
+                pass
+        fw = {}
+        for f in sorted(glob.glob(os.path.join(dev, "fw_version", "*_fw_version"))):
+            try:
+                fw[os.path.basename(f)[:-len("_fw_version")]] = open(f).read().strip()
+            except Exception:
+                pass
+        if fw:
+            c["fw"] = {k: fw[k] for k in fw if k in ("mec", "mec2", "smc", "sdma", "rlc", "pfp", "me", "imu", "mes", "mes_kiq", "vcn", "sos", "asd")}
+        cards.append(c)
+    rec["cards"] = cards
+    return rec
+
+
 def cpu_baseline(c, budget_s=20.0):
     """Time the literal torch-CPU restatement of the reference graph (oracle; checker only) on the host."""
     import numpy as np
@@ -261,6 +351,10 @@ def main():
                     help="every step normalises its own batch first (6 launches) instead of normalising the next batch "
                          "behind its Adam update (5 launches; same results, DESIGN.md section 3.5)")
     ap.add_argument("--fork", action="store_true", help="two-stream graph (dense dW on a forked stream) instead of the grouped dX+dW launch")
+    ap.add_argument("--regions", type=int, default=7,
+                    help="how many times the timed K-step region is run back to back (each bracketed by barrier + synchronize); "
+                         "`value` is the MEDIAN region, all of them are listed in step.regions_ms")
+    ap.add_argument("--no-boundaries", action="store_true", help="skip the in-situ step timeline (step.boundaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short C3 / C4 measurements of the `configs` object")
@@ -343,26 +437,37 @@ def main():
     for _ in range(args.warmup):
         step()
     reduce_table()          # warm-up pass: first use loads torch's element-wise code objects (tens of ms, once)
-    barrier()
+    pci = hip_device_pci(dev)
+    clocks_before = gpu_clock_state(pci) if rank == 0 else None
     timer = HipTimer()
-    timer.start(eng._stream())
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enqueue = time.perf_counter() - t0                        # host cost of issuing the K steps (no sync yet)
-    reduce_table()
-    timer.stop(eng._stream())
-    # a rank's time = common start (barrier above) -> its own K steps and the table reduction have completed; the job's
-    # time = MAX over ranks.  (The closing barrier is taken after the clock is read: with the driver's K = 20 a step
-    # sequence lasts 1.5 ms, and a second RCCL barrier inside it would be timed instead of the path.)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    ev_ms = timer.elapsed_ms()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    regions, ev_regions, enq_regions = [], [], []
+    # The timed region = EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  It is run `--regions` times
+    # back to back and `value` is the median region: with the driver's K = 20 one region lasts 1.6 ms, and a single sample
+    # of that length cannot tell a slow box from a slow moment (0.101 vs 0.079 ms on another box of the pool).
+    for _ in range(max(1, args.regions)):
+        barrier()
+        timer.start(eng._stream())
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        enq_regions.append(time.perf_counter() - t0)            # host cost of issuing the K steps (no sync yet)
+        reduce_table()
+        timer.stop(eng._stream())
+        # a rank's time = common start (barrier above) -> its own K steps and the table reduction have completed; the job's
+        # time = MAX over ranks.  (The closing barrier is taken after the clock is read: with the driver's K = 20 a step
+        # sequence lasts 1.5 ms, and a second RCCL barrier inside it would be timed instead of the path.)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        barrier()
+        ev_regions.append(timer.elapsed_ms())
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        regions.append(float(tmax.item()))
+    clocks_after = gpu_clock_state(pci) if rank == 0 else None
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[len(order) // 2]                                  # the median region (odd count: an actual sample)
+    elapsed, ev_ms, t_enqueue = regions[mid], ev_regions[mid], enq_regions[mid]
 
     sym_per_step = c["frames"] * S
     value = world * args.steps * sym_per_step / elapsed
@@ -385,7 +490,21 @@ def main():
                           "mfma_frac": fl / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                           "hip_event_ms_per_step": ev_ms / args.steps,
                           "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
+                          "regions_ms": [round(r / args.steps * 1e3, 5) for r in regions],
+                          "regions_hip_event_ms": [round(r / args.steps, 5) for r in ev_regions],
                           "ber_table": [float(v) for v in table.cpu()]}
+        if not args.no_boundaries and not use_graph:
+            # in-situ timeline of the same step (dl_ofdm_amd/steptrace.py): per launch its duration inside the step, the idle
+            # gap in front of it and the shader clock its workgroups saw -- the decomposition of ms_per_step
+            from dl_ofdm_amd.steptrace import trace_steps
+            t1 = HipTimer()
+            bd = trace_steps(step, dev, ring=16, bursts=14)
+            t1.start(eng._stream())
+            for _ in range(200):
+                step()
+            t1.stop(eng._stream())
+            bd["untraced_ms_per_step_200"] = round(t1.elapsed_ms() / 200, 5)
+            result["step"]["boundaries"] = bd
         if not args.no_kernel_times:
             kt = time_ops(eng, iters=200, warmup=20)
             result["kernels"] = {k: {"us": round(v["ms"] * 1e3, 3), "tflops": round(v["tflops"], 2), "kernel": v["kernel"]}
@@ -433,7 +552,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()
-        result["device"] = {"arch": arch, "cus": cu}
+        result["device"] = {"arch": arch, "cus": cu, "clocks_before_timed_regions": clocks_before,
+                            "clocks_after_timed_regions": clocks_after, "box": box_fingerprint(pci)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

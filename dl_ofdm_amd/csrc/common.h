@@ -74,6 +74,44 @@ static inline int set_max_dynamic_smem(const void* kern, size_t bytes) {
 }
 #define kCUs (dccn::device_cus())
 
+// ---- step timeline stamps (dccn_step_trace_*: in-situ start/end of every instrumented launch, bench.py `step.boundaries`) ---
+// A launch whose parameter block carries a non-null `stamp` pointer leaves, per workgroup (blockIdx.x < kStampBlocks, y = z = 0),
+// four 64-bit words: {s_memrealtime at entry, s_memtime at entry, s_memrealtime at exit, s_memtime at exit} written by thread 0.
+// s_memrealtime ticks at a constant 100 MHz, s_memtime once per shader cycle: the ratio is the clock the CU really ran at.
+// Null pointer (every normal launch): one scalar compare and a branch per mark.
+constexpr int kStampBlocks = 4096, kStampWords = 4, kStampLaunches = 8;
+__device__ __forceinline__ void stamp_mark(unsigned long long* st, const int which) {
+    if (st != nullptr && threadIdx.x == 0 && blockIdx.x < (unsigned)kStampBlocks && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* p = st + (size_t)blockIdx.x * kStampWords + 2 * which;
+        p[0] = wall_clock64();
+        p[1] = clock64();
+    }
+}
+// host side: the trace buffer is a ring of steps x kStampLaunches launches x kStampBlocks blocks x kStampWords words; a step
+// implementation opens a StepTraceScope and names the launch that follows (`launch(i)`); every parameter block initialised
+// while that is in force (gp_zero() / the optimizer's argument block) picks the pointer up.
+struct StepTraceState {
+    std::atomic<unsigned long long*> buf{nullptr};
+    std::atomic<int> ring{0};
+    std::atomic<long long> step{0};
+};
+extern StepTraceState g_step_trace;
+extern thread_local unsigned long long* tl_stamp;
+struct StepTraceScope {
+    unsigned long long* base;
+    StepTraceScope() : base(nullptr) {
+        unsigned long long* b = g_step_trace.buf.load(std::memory_order_relaxed);
+        const int ring = g_step_trace.ring.load(std::memory_order_relaxed);
+        if (b != nullptr && ring > 0) {
+            const long long st = g_step_trace.step.fetch_add(1, std::memory_order_relaxed);
+            base = b + (size_t)(st % ring) * kStampLaunches * kStampBlocks * kStampWords;
+        }
+    }
+    ~StepTraceScope() { tl_stamp = nullptr; }
+    void launch(int i) const { tl_stamp = (base && i >= 0 && i < kStampLaunches) ? base + (size_t)i * kStampBlocks * kStampWords : nullptr; }
+    void none() const { tl_stamp = nullptr; }
+};
+
 // ---- wave reductions (wave64) on the DPP crossbar: no LDS round trips ------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror sums each 16-lane row
 // (fixed order => deterministic), then the four row sums are combined through v_readlane.

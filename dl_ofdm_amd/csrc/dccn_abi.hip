@@ -20,6 +20,8 @@
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
+StepTraceState g_step_trace;
+thread_local unsigned long long* tl_stamp = nullptr;
 
 // bump allocator over a caller-provided workspace
 struct Carver {
@@ -192,6 +194,7 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
 static GemmParams gp_zero() {
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    p.stamp = tl_stamp;         // non-null only while a StepTraceScope names the launch being built (common.h)
     return p;
 }
 static int round_k(int K) { return ceil_div(K, 64) * 64; }
@@ -916,10 +919,10 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
             if (bwd) {                                   // four lanes per cell (tail.h): 50 accumulators per lane, not 200
                 if (prob)
                     hipLaunchKernelGGL(demod_tail_quad4_kernel<true>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp,
-                                       prob, dz, cells, bm, bg);
+                                       prob, dz, cells, bm, bg, tl_stamp);
                 else
                     hipLaunchKernelGGL(demod_tail_quad4_kernel<false>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits,
-                                       tailp, prob, dz, cells, bm, bg);
+                                       tailp, prob, dz, cells, bm, bg, tl_stamp);
                 DCCN_LAUNCH_CHECK();
                 st = DCCN_OK;
             } else {
@@ -1148,6 +1151,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     unsigned* ws_sync = train ? reinterpret_cast<unsigned*>(c.take<char>(L.ws_sync)) : nullptr;
     float* P = b->params;
     float* G = b->grads;
+    // step timeline (dccn_step_trace_enable): launch slots 1 C-Conv forward, 2 dense forward (+ tail), 3 tail (own launch),
+    // 4 backward (fused, or grouped dX+dW), 5 C-Conv weight gradient (own launch), 6 optimizer
+    const StepTraceScope trace;
 
     // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
@@ -1161,9 +1167,11 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                            nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
     // R1 -- unless the previous call's optimizer launch already ran it on this batch (x_prenormalised == 2)
+    trace.launch(1);
     if (!(pre && b->x_prenormalised == 2))
         DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     TailFinalizeArgs fin;
+    trace.launch(2);
     if (dense_tail_planned(sh->nbits, train, sh->batch, L.dN) &&
         dense_tail_ok(b->fft_out, P + L.o_dense_w, sh->batch, L.dK, L.dN, sh->nbits)) {
         // R2 with R3-R6 (+ tail backward) in its epilogue; z is materialised only when the caller gave a buffer
@@ -1175,10 +1183,12 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         // R2
         DCCN_TRY(dense_fwd_impl(b->fft_out, P + L.o_dense_w, P + L.o_dense_b, b->z, sh->batch, L.dK, L.dN, s));
         // R3-R6 (+ tail backward)
+        trace.launch(3);
         DCCN_TRY(tail_impl(train, b->z, b->bits, P + L.o_tail, b->prob, b->metrics, b->dz, train ? G + L.o_tail : nullptr,
                            L.cells, sh->nbits, &pp, b->tx_power, ws_tail, L.ws_tail, s, train ? &fin : nullptr));
     }
     if (!train) return DCCN_OK;
+    trace.launch(4);
     fin.adam = b->adam;                 // the optimizer's per-step bookkeeping rides on the tail finalize stage
     fin.hp = hp;
 
@@ -1248,12 +1258,15 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
+    trace.launch(5);
     if (!fuse_bw)
         DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
+    trace.launch(6);
     AdamRxArgs aa;
+    aa.stamp = tl_stamp;
     aa.param = P; aa.grad = G; aa.m = b->adam_m; aa.v = b->adam_v;
     aa.reg_coef = b->reg_coef; aa.reg_gate = b->reg_coef ? &b->metrics->berlin : nullptr;
     aa.state = b->adam; aa.n = L.total;
@@ -1301,6 +1314,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         default: hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
     }
     DCCN_LAUNCH_CHECK();
+    trace.none();
     if (b->x_next != nullptr && !ride && !ride_bw) {
         // shapes the single-pass kernel does not take: the same normalisation as launches of their own
         PowerPartials np;
@@ -1513,6 +1527,29 @@ int dccn_rx_backward(const float* x_norm, const float* fft_out, const float* dz,
                        db_conv, kin, F, tilew);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
+}
+
+size_t dccn_step_trace_bytes(int ring_steps) {
+    if (ring_steps <= 0) return 0;
+    return (size_t)ring_steps * kStampLaunches * kStampBlocks * kStampWords * sizeof(unsigned long long);
+}
+int dccn_step_trace_enable(unsigned long long* buf, size_t bytes, int ring_steps) {
+    if (buf == nullptr) {
+        g_step_trace.buf.store(nullptr);
+        g_step_trace.ring.store(0);
+        return DCCN_OK;
+    }
+    if (ring_steps <= 0 || bytes < dccn_step_trace_bytes(ring_steps)) return DCCN_ERR_WORKSPACE;
+    g_step_trace.ring.store(ring_steps);
+    g_step_trace.step.store(0);
+    g_step_trace.buf.store(buf);
+    return DCCN_OK;
+}
+long long dccn_step_trace_steps(void) { return g_step_trace.step.load(); }
+void dccn_step_trace_geometry(int* launches, int* blocks, int* words) {
+    if (launches) *launches = kStampLaunches;
+    if (blocks) *blocks = kStampBlocks;
+    if (words) *words = kStampWords;
 }
 
 #ifdef DCCN_TRACE

@@ -722,8 +722,10 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
 template <int KA, int KB, int WGM, int WGN, int TM, int TN, int BK, int KS, int COLSUM, int EPI, int NB, bool BWD, int TAG,
           int PD = 1>
 __global__ __launch_bounds__(256 * KS) void gemm16_kernel(const GemmParams p, const TailEpiParams tp) {
+    stamp_mark(p.stamp, 0);
     gemm16_block<KA, KB, WGM, WGN, TM, TN, BK, KS, COLSUM, EPI, NB, BWD, PD>(p, tp, (int)blockIdx.x, (int)gridDim.x,
                                                                         (int)blockIdx.z, (int)blockIdx.x);
+    stamp_mark(p.stamp, 1);
 }
 
 // dense backward: dX = dY.W^T tiles and the split-K slabs of dW = X^T.dY in ONE grid (independent GEMMs sharing dY)

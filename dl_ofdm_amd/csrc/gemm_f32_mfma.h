@@ -77,6 +77,7 @@ struct GemmParams {
     const float* ad_reg; const float* ad_gate;
     const dccn_adam_state* ad_state;
     float ad_omb1, ad_omb2, ad_eps;
+    unsigned long long* stamp;   // step timeline stamps of this launch (common.h stamp_mark), nullptr = none
 };
 
 constexpr int kGemmThreads = 256;
@@ -596,7 +597,9 @@ __device__ __forceinline__ GemmParams group_params(const GemmParams& p, const Gr
 template <int KA, int KB, int BM, int BN, int BK, int TAG, bool VEC, int NBUF, int CMAP>
 __global__ __launch_bounds__(kGemmThreads) void gemm_grouped_kernel(const GemmParams p, const GroupStride gs) {
     const GemmParams q = group_params(p, gs, (int)blockIdx.y);
+    stamp_mark(p.stamp, 0);
     gemm_block<KA, KB, BM, BN, BK, 0, VEC, NBUF, CMAP>(q, (int)blockIdx.x, (int)gridDim.x, 0);
+    stamp_mark(p.stamp, 1);
 }
 template <int KA, int KB, int BM, int BN, int BK, int TAG, int NBUF, int CMAP>
 static int launch_gemm_grouped(const GemmParams& p, const GroupStride& gs, int groups, hipStream_t s) {
@@ -612,7 +615,9 @@ static int launch_gemm_grouped(const GemmParams& p, const GroupStride& gs, int g
 // TAG only makes the symbol unique per call site so profiles attribute time to the right operator
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int NBUF = 2>
 __global__ __launch_bounds__(kGemmThreads) void gemm_f32_mfma_kernel(const GemmParams p) {
+    stamp_mark(p.stamp, 0);
     gemm_block<KA, KB, BM, BN, BK, COLSUM, VEC, NBUF>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+    stamp_mark(p.stamp, 1);
 }
 
 // Two independent GEMMs in ONE grid (the dense layer's dX = dY.W^T and dW = X^T.dY share dY but not
@@ -626,12 +631,14 @@ __global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_kernel(const G
 #ifdef GROUPED_ABL          // timing experiments only: 1 = the dX blocks return at once, 2 = the dW blocks do
     if ((GROUPED_ABL == 1) == (b < nx)) return;
 #endif
+    stamp_mark(px.stamp, 0);
     if (b < nx) {
         gemm_block<OP_KCONTIG, OP_KCONTIG, BM, BN, BK, 0, VEC>(px, b, nx, 0);
     } else {
         const int c = b - nx;
         gemm_block<OP_ICONTIG, OP_ICONTIG, BM, BN, BK, 1, VEC>(pw, c % tw, tw, c / tw);
     }
+    stamp_mark(px.stamp, 1);
 }
 
 template <int KA, int KB, int BM, int BN, int BK, int COLSUM, int TAG, bool VEC, int NBUF = 2>

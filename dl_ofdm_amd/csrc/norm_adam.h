@@ -469,6 +469,7 @@ struct AdamRxArgs {
     float neps, npeak;
     // [skip_lo, skip_hi): elements whose update already happened in the epilogue of their weight-gradient GEMM
     long long skip_lo, skip_hi;
+    unsigned long long* stamp;             // step timeline stamps (common.h stamp_mark), nullptr = none
 };
 
 // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here.
@@ -624,17 +625,21 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
 
 template <int SPLITS>     // 0: runtime count
 __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const dccn_adam_hparams hp) {
+    stamp_mark(a.stamp, 0);
     if ((int)blockIdx.x < a.norm_blocks) {
         norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, a.neps, a.npeak, a.npower, nullptr, nullptr,
                                            nullptr, hp, (int)blockIdx.x, a.norm_blocks);
+        stamp_mark(a.stamp, 1);
         return;
     }
     const int bx = (int)blockIdx.x - a.norm_blocks, nbx = (int)gridDim.x - a.norm_blocks;
     if (bx < a.fold_blocks) {
         adam_fold_role<false>(a, hp, bx, HandoffWords{nullptr, nullptr, 0u, 0});
+        stamp_mark(a.stamp, 1);
         return;
     }
     adam_stream_role<SPLITS>(a, hp, bx - a.fold_blocks, nbx - a.fold_blocks);
+    stamp_mark(a.stamp, 1);
 }
 
 }  // namespace dccn

@@ -191,11 +191,13 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
                                                                     const dccn_adam_hparams hp) {
     int b = (int)blockIdx.x;
     DCCN_TRACE_MARK(0, 0);
+    stamp_mark(px.stamp, 0);
     if (b < nr.blocks) {
         norm_fused_body<kNormFusedCG, kNormFusedRPT>(nr.x, nr.y, nr.batch, nr.cols, nr.eps, nr.peak, nr.power, nullptr,
                                                      nullptr, nullptr, hp, b, nr.blocks);
         DCCN_TRACE_MARK(3, trace_hwid(0));
         DCCN_TRACE_MARK(2, 0);
+        stamp_mark(px.stamp, 1);
         return;
     }
     b -= nr.blocks;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
         demod_tail_finalize_body(fin, b);
         DCCN_TRACE_MARK(3, trace_hwid(1));
         DCCN_TRACE_MARK(2, 0);
+        stamp_mark(px.stamp, 1);
         return;
     }
     b -= fin_blocks;
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
         DCCN_TRACE_MARK(3, trace_hwid(3));
     }
     DCCN_TRACE_MARK(2, 0);
+    stamp_mark(px.stamp, 1);
 }
 
 // ---- optimizer launch that also runs the C-Conv forward of the NEXT batch -------------------------------------------
@@ -252,8 +256,10 @@ template <int SPLITS>
 __global__ __launch_bounds__(256) void rx_update_prefetch_kernel(const AdamRxArgs a, const dccn_adam_hparams hp,
                                                                  const PrefetchFwdArgs f) {
     const int b = (int)blockIdx.x;
+    stamp_mark(a.stamp, 0);
     if (b < a.fold_blocks) {
         adam_fold_role<true>(a, hp, b, f.hw);
+        stamp_mark(a.stamp, 1);
         return;
     }
     const int c = b - a.fold_blocks;
@@ -272,9 +278,11 @@ __global__ __launch_bounds__(256) void rx_update_prefetch_kernel(const AdamRxArg
         }
         __syncthreads();
         gemm_block<OP_KCONTIG, OP_CCONV_W, 64, 64, 32, 0, true>(f.pc, c, f.tiles, 0);
+        stamp_mark(a.stamp, 1);
         return;
     }
     adam_stream_role<SPLITS>(a, hp, c - f.tiles, (int)gridDim.x - a.fold_blocks - f.tiles);
+    stamp_mark(a.stamp, 1);
 }
 
 static int launch_rx_update_prefetch(const AdamRxArgs& a, dccn_adam_hparams hp, const PrefetchFwdArgs& f, int stream_blocks,

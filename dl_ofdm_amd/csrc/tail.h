@@ -580,8 +580,9 @@ template <bool WRITE_PROB>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
     const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
     float* __restrict__ prob, float* __restrict__ dz, long long cells,
-    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
+    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads, unsigned long long* stamp) {
     constexpr int NB = 4;
+    stamp_mark(stamp, 0);
     __shared__ __attribute__((aligned(8))) float sred[tail_quad4_lds_floats(kTailThreads)];
     const int q = threadIdx.x & 3;
     TailQuad4W W;
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
         if (q == 0) *reinterpret_cast<float2*>(dz + 2 * cell) = d;
     }
     tail_quad4_block_reduce<kTailThreads>(A, sred, blk_metrics, blk_grads, (int)blockIdx.x);
+    stamp_mark(stamp, 1);
 }
 
 // Slab reduction: wave g < P sums gradient column g over the per-block slabs (lane l owns slabs

@@ -391,6 +391,22 @@ int dccn_timer_elapsed_ms(dccn_timer* t, float* ms);     /* synchronises on the 
 int dccn_timer_destroy(dccn_timer* t);
 int dccn_stream_synchronize(dccn_stream_t stream);
 
+/* ---- step timeline: in-situ start / end of the launches of dccn_rx_train_step / dccn_rx_eval_step ----------------------
+ * Replaces nothing in the reference (TF1 has `RunMetadata` step stats for this: dev/py/ofdmreceiver_np.py:234 runs the
+ * step without them); it exists so that a step time can be decomposed into per-launch durations and the gaps between
+ * launches on whatever box the step runs on (bench.py `step.boundaries`).
+ * `buf` is DEVICE memory of dccn_step_trace_bytes(ring_steps) bytes, zeroed by the caller: a ring of `ring_steps` steps x
+ * `launches` slots x `blocks` workgroups x `words` 64-bit words (dccn_step_trace_geometry).  While enabled, every step call
+ * takes the next ring entry and thread 0 of each workgroup of its instrumented launches writes
+ *   {s_memrealtime at entry (100 MHz), s_memtime at entry (shader cycles), the same two at exit}
+ * into [step % ring][slot][blockIdx.x].  Slots: 1 C-Conv forward, 2 dense forward (+ tail), 3 tail (own launch),
+ * 4 backward, 5 C-Conv weight gradient (own launch), 6 optimizer; 0 and 7 unused.  buf = NULL disables (the default: a
+ * disabled mark is one scalar compare per workgroup).  Process-wide switch, meant for one measuring thread. */
+size_t dccn_step_trace_bytes(int ring_steps);
+int dccn_step_trace_enable(unsigned long long* buf, size_t bytes, int ring_steps);
+long long dccn_step_trace_steps(void);                 /* step calls recorded since the last enable */
+void dccn_step_trace_geometry(int* launches, int* blocks, int* words);
+
 /* ==== channel-equaliser stage: dev/py/model.py:349-478 =====================
  * The stage's dense / C-Conv layers use dccn_dense_* / dccn_cconv_gemm_* above; these are the
  * remaining operators.  All tensors fp32, IQ pairs interleaved on the last axis. */
