@@ -147,6 +147,8 @@ SIGNATURES = {
     "dccn_timer_elapsed_ms": (_i, [_vp, POINTER(c_float)]),
     "dccn_timer_destroy": (_i, [_vp]),
     "dccn_stream_synchronize": (_i, [_vp]),
+    "dccn_eq_monitor_workspace_size": (_sz, [_i, _i, _i]),
+    "dccn_eq_monitor_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dccn_step_trace_bytes": (_sz, [_i]),
     "dccn_step_trace_enable": (_i, [_vp, _sz, _i]),
     "dccn_step_trace_steps": (_ll, []),

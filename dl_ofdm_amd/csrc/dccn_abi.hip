@@ -12,6 +12,7 @@
 #include "gemm_kmajor.h"
 #include "rx_bwd.h"
 #include "equalizer.h"
+#include "fewrow.h"
 #include "eq_opt.h"
 #include "eq_bottleneck.h"
 #include "datagen.h"
@@ -60,12 +61,13 @@ enum TuneKey : int {
     TUNE_FWD_PREFETCH = 15,     // 1: double-buffered pipelining also runs the next batch's C-Conv forward on the optimizer launch
     TUNE_ADAM_IN_DW = 16,       // 1: large layers (unsplit dW tiles): the dense kernel's Adam update runs in the dW epilogue
     TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
-    TUNE_NORM_ON_BWD = 18,      // 1: double-buffered pipelining: R0 of the next batch rides on the backward launch
+    TUNE_NORM_ON_BWD = 18,      // 1 / 2: double-buffered pipelining: R0 of the next batch rides on the backward launch (leading / closing workgroups)
     TUNE_EQ_EPILOGUES = 19,     // equaliser step: tanh / tanh-gradient / gradient add in GEMM stores: 1 = the few-row GEMMs,
                                 //    2 = also the 48x64 / 64x64 tiles of larger batches
     TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
                                 //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
-    TUNE_COUNT = 21
+    TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
+    TUNE_COUNT = 22
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -91,7 +93,7 @@ struct TuneTable {
 //   20 = 1  equaliser re-plan: 73 frames 0.319 -> 0.263 ms, 1170 frames 0.570 -> 0.509 ms (tools/eqbench.py --ab 20=0,1,2);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -221,6 +223,18 @@ static int dense_fwd_impl(const float* x, const float* w, const float* bias, flo
     const bool eq_stage = act == 5 && act_done && aux && out2 && out3 && g_tune[TUNE_EQ_EPILOGUES] && (N % 2 == 0) &&
                           aligned16(aux) && aligned16(out2) && aligned16(out3);
     if (eq_stage) { p.aux = aux; p.out2 = out2; p.out3 = out3; }
+    if (g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && fewrow_ng(p) && aligned16(y)) {
+        // few rows, K = 640 / 896: every operand of a 16x16 tile requested at once, no LDS staging (fewrow.h)
+        if (eq_stage) {
+            *act_done = true;
+            return launch_fewrow<OP_ICONTIG, 5, TAG_DENSE_FWD>(p, s);
+        }
+        if (act == 2 && act_done && g_tune[TUNE_EQ_EPILOGUES]) {
+            *act_done = true;
+            return launch_fewrow<OP_ICONTIG, 2, TAG_DENSE_FWD>(p, s);
+        }
+        return launch_fewrow<OP_ICONTIG, 1, TAG_DENSE_FWD>(p, s);
+    }
     if (skinny_ok(p)) {
         if (eq_stage) {
             *act_done = true;
@@ -263,6 +277,7 @@ static GemmParams dense_bwd_x_params(const float* dy, const float* w, float* dx,
 static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
     if (!dy || !w || !dx || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     const GemmParams p = dense_bwd_x_params(dy, w, dx, M, K, N);
+    if (g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && fewrow_ng(p)) return launch_fewrow<OP_KCONTIG, 1, TAG_DENSE_BWD_X>(p, s);
     if (skinny_ok(p)) return skinny_launch<OP_KCONTIG, OP_KCONTIG, TAG_DENSE_BWD_X>(g_tune[TUNE_SKINNY], p, s);
     return launch_gemm<OP_KCONTIG, OP_KCONTIG, 0, TAG_DENSE_BWD_X>(p, 1, s);
 }
@@ -432,14 +447,18 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
         pw.C = dw; pw.colsum = dbias; pw.slab = 0;
         // the dX tiles may carry an element-wise stage of the caller's graph: 3 = times (1 - aux^2) (tanh gradient),
         // 4 = plus aux (gradient accumulation): two 5 us launches of the equaliser step less
+        const bool few = g_tune[TUNE_FEWROW] && fewrow_ng(px) != 0;        // dX on the one-latency 16x16 tiles of fewrow.h
         if (actx != 1 && act_done && aux && g_tune[TUNE_EQ_EPILOGUES]) {
             px.aux = aux;
             *act_done = true;
-            if (actx == 3) DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 3>(px, pw, 1, s, tune_smem_min())));
-            else if (actx == 4) DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 4>(px, pw, 1, s, tune_smem_min())));
+            if (actx == 3) DCCN_TRY(few ? launch_dense_bwd_fewrow<3>(px, pw, s)
+                                        : (launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 3>(px, pw, 1, s, tune_smem_min())));
+            else if (actx == 4) DCCN_TRY(few ? launch_dense_bwd_fewrow<4>(px, pw, s)
+                                             : (launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2, 4>(px, pw, 1, s, tune_smem_min())));
             else return DCCN_ERR_INVALID_ARG;
         } else
-        DCCN_TRY((launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2>(px, pw, 1, s, tune_smem_min())));
+        DCCN_TRY(few ? launch_dense_bwd_fewrow<1>(px, pw, s)
+                     : (launch_dense_bwd16<1, 4, 1, 1, 64, 2, 2, 2, 2>(px, pw, 1, s, tune_smem_min())));
         defer->dw_slabs = nullptr; defer->db_slabs = nullptr; defer->splits = 1;
         return DCCN_OK;
     }
@@ -1217,6 +1236,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             nr.x = b->x_next; nr.y = b->x_norm_next; nr.power = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
             nr.batch = sh->batch; nr.cols = L.cols; nr.blocks = norm_fused_blocks(L.cols);
             nr.eps = 1e-9f; nr.peak = 8.0f;
+            nr.trail = g_tune[TUNE_NORM_ON_BWD] >= 2 ? 1 : 0;
         }
         DCCN_TRY(rx_bwd_fused_impl(b->x_norm, b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_b, sh->batch, sh->S,
                                    sh->kin, sh->F, sh->D, ws_dbw, L.ws_dense_bw, ws_cbw, L.ws_conv_bw, nr, fin, hp, s, &ds, &fd,
@@ -2161,6 +2181,31 @@ int dccn_classical_detect(const float* Y, const float* G, const int* dat, const 
     DCCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)ep, nblk, (const double*)nullptr, 0,
                        errors, (double*)nullptr);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// ---- per-step monitors of the equaliser harness in one launch (equalizer.h eq_monitor_kernel) --------------------
+static int eq_monitor_blocks(int B, int K) {
+    long long n = ceil_div_ll((long long)B * K * 2, 256);
+    if (n > 256) n = 256;
+    return (int)(n < 1 ? 1 : n);
+}
+size_t dccn_eq_monitor_workspace_size(int B, int S, int K) {
+    if (B <= 0 || S <= 0 || K <= 0) return 0;
+    return align_up(256 + (size_t)eq_monitor_blocks(B, K) * sizeof(double), 256);
+}
+int dccn_eq_monitor_accumulate(const float* chest, const float* chan, int chan_per_symbol, int B, int S, int K,
+                               const dccn_metrics* metrics, const float* tx_power, const float* noise_power, float* acc5,
+                               float* rms_out, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    if (!chest || !chan || B <= 0 || S <= 0 || K <= 0 || (acc5 && !metrics) || (!acc5 && !rms_out)) return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_eq_monitor_workspace_size(B, S, K)) return DCCN_ERR_WORKSPACE;
+    EqMonitorArgs a;
+    a.chest = chest; a.chan = chan; a.gt_per_symbol = chan_per_symbol ? 1 : 0; a.B = B; a.S = S; a.K = K;
+    a.metrics = metrics; a.tx_power = tx_power; a.noise_power = noise_power; a.acc = acc5; a.rms_out = rms_out;
+    a.counter = static_cast<unsigned*>(workspace);
+    a.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) + 256);
+    hipLaunchKernelGGL(eq_monitor_kernel, dim3(eq_monitor_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

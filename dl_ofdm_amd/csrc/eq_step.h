@@ -286,16 +286,22 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
     TailFinalizeArgs fin;
     bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
-    if (dense_tail_planned(sh->nbits, train, B, L.dN) &&
+    // few rows (73 frames): the fused dense + tail launch is 20 tiles of 48x64 behind a 14-tile k-loop (23 us); the
+    // one-latency 16x16 tiles of fewrow.h (200 blocks) followed by the stand-alone tail launch take about half of that
+    const bool few_rx = g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && B <= 96 && (L.dK == 896 || L.dK == 640) &&
+                        (L.dN % 16) == 0 && aligned16(w.fft) && aligned16(Q + L.o_dense_w) && aligned16(w.z);
+    if (!few_rx && dense_tail_planned(sh->nbits, train, B, L.dN) &&
         dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
         fin_deferred = replan && train;
         DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
                                  b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, L.dK, L.dN, sh->nbits,
                                  &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? &fin : nullptr));
     } else {
+        fin_deferred = replan && train;     // (the tail's metric reduction rides on the optimizer launch either way)
         DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
         DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
-                           train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s));
+                           train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s,
+                           fin_deferred ? &fin : nullptr));
     }
     if (!train) return DCCN_OK;
 

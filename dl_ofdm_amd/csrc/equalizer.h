@@ -190,6 +190,76 @@ __global__ __launch_bounds__(256) void equalize_fwd_snr_kernel(const float2* __r
     if (frame < frames) pilot_snr_body<true>(nullptr, y, h, carriers, snr_db, S, K, P, frame, (int)(threadIdx.x & 63));
 }
 
+// ---- the harness's per-step monitors in one launch (dev/py/ofdmreceiver_np_mp.py:245, 325-333, 411-425) ------------------
+// chan_rms = mean((LN(chan) - LN(chest))^2) with LN = tf.keras.layers.LayerNormalization(axis=1, center=False, scale=False)
+// over the OFDM-symbol axis of the [B, S, K, 2] real views (moments over S only, Keras' epsilon 1e-3): a column
+// (b, k, iq) is S values of each tensor.  A static channel is the same row for every symbol: gt_per_symbol = 0 reads
+// chan [B, K, 2] for every s (its LN is exactly 0, as in the reference).  One thread per column, fixed-order block sums,
+// per-block partials summed in order by the LAST block to arrive (no block waits for another); that block also adds the
+// step's scalars onto the epoch accumulators acc[5] = {ce_mean, berlin, tx_power, noise_power, chan_rms}: what the
+// harness otherwise did with ~25 small framework launches per step.
+struct EqMonitorArgs {
+    const float* chest;         // [B, S, K, 2]
+    const float* chan;          // [B, S, K, 2] or [B, K, 2]
+    int gt_per_symbol, B, S, K;
+    const dccn_metrics* metrics;
+    const float* tx_power;      // nullable
+    const float* noise_power;   // nullable
+    float* acc;                 // [5]
+    float* rms_out;             // nullable: this step's chan_rms
+    double* partial;            // [blocks]
+    unsigned* counter;          // zero before the first launch; the last block leaves it zero again
+};
+__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a) {
+    __shared__ double red[4];
+    __shared__ unsigned s_last;
+    const long long cols = (long long)a.B * a.K * 2;
+    const int K2 = a.K * 2;
+    double sum = 0.0;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+        const int b = (int)(c / K2), r = (int)(c % K2);
+        const float* pe = a.chest + (size_t)b * a.S * K2 + r;
+        const float* pg = a.gt_per_symbol ? a.chan + (size_t)b * a.S * K2 + r : a.chan + (size_t)b * K2 + r;
+        const int gs = a.gt_per_symbol ? K2 : 0;
+        float me = 0.f, mg = 0.f;
+        for (int s = 0; s < a.S; ++s) { me += pe[(size_t)s * K2]; mg += pg[(size_t)s * gs]; }
+        me /= (float)a.S; mg /= (float)a.S;
+        float ve = 0.f, vg = 0.f;
+        for (int s = 0; s < a.S; ++s) {
+            const float de = pe[(size_t)s * K2] - me, dg = pg[(size_t)s * gs] - mg;
+            ve += de * de; vg += dg * dg;
+        }
+        const float ie = rsqrtf(ve / (float)a.S + 1e-3f), ig = rsqrtf(vg / (float)a.S + 1e-3f);
+        for (int s = 0; s < a.S; ++s) {
+            const float d = (pg[(size_t)s * gs] - mg) * ig - (pe[(size_t)s * K2] - me) * ie;
+            sum += (double)(d * d);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();                                            // the partial is visible before the arrival is
+        s_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    double tot = 0.0;
+    for (unsigned i = 0; i < gridDim.x; ++i) tot += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float rms = (float)(tot / ((double)cols * (double)a.S));
+    if (a.rms_out) *a.rms_out = rms;
+    if (a.acc) {
+        a.acc[0] += a.metrics->ce_mean;
+        a.acc[1] += a.metrics->berlin;
+        if (a.tx_power) a.acc[2] += *a.tx_power;
+        if (a.noise_power) a.acc[3] += *a.noise_power;
+        a.acc[4] += rms;
+    }
+    *a.counter = 0u;
+}
+
 // ---- one-channel, one-filter complex "same" convolution as a dense layer ---------------------
 // layers_conv2d_complex(chest, 1, (n_sym, K), padding='same') (model.py:428) slides a kL x kW
 // complex kernel over an L x W complex image with TF's SAME zero padding.  At L x W = 7 x 64 the

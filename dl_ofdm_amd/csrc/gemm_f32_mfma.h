@@ -848,18 +848,21 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     const size_t eoff = tilew > 0 ? (size_t)((2 * f) / tilew) * (size_t)(2 * kin) * tilew + (2 * f) % tilew : (size_t)(2 * f);
     const size_t coff = tilew > 0 ? (size_t)((2 * f) / tilew) * tilew + (2 * f) % tilew : (size_t)(2 * f);
     const size_t cstride = tilew > 0 ? (size_t)(N2 / tilew) * tilew : (size_t)N2;
+    // terms per batch of independent loads: 133 terms over 16 groups = 9 per thread -> ONE batch (with 8 the five groups that
+    // own a ninth term walked a second, dependent batch: one more memory latency on the optimizer launch's long pole)
+    constexpr int UB = LANES == kFoldLanesTiled ? 9 : 8;
     if (is_w) {
-        for (int zb = grp; zb < splits; zb += 8 * GROUPS) {
-            float2 top[8], bot[8];
+        for (int zb = grp; zb < splits; zb += UB * GROUPS) {
+            float2 top[UB], bot[UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const float* P = partial + (size_t)min(zb + u * GROUPS, splits - 1) * slab + eoff;
                 top[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n) * ld);
                 bot[u] = *reinterpret_cast<const float2*>(P + (size_t)(2 * n + 1) * ld);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 if (zb + u * GROUPS < splits) {
                     a += top[u].x - bot[u].y;
                     b += top[u].y - bot[u].x;

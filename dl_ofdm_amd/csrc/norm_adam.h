@@ -495,6 +495,23 @@ __device__ __forceinline__ void adam_fold_role(const AdamRxArgs& a, const dccn_a
     const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
     long long idx[2];
     float gv[2];
+    // the two parameters this thread will update (group 0 of the fold: the same (n, f) / bias mapping as cconv_fold_body) are
+    // known before the fold: their Adam operands are requested now and arrive under the fold's own loads
+    float pre_p[2] = {0.f, 0.f}, pre_m[2] = {0.f, 0.f}, pre_v[2] = {0.f, 0.f}, pre_c[2] = {0.f, 0.f};
+    {
+        const int LANES = a.cw_tilew > 0 ? kFoldLanesTiled : kRedLanes;
+        const int lane = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+        const int e = bx * LANES + lane, total = a.kin * a.F, N2 = 2 * a.F;
+        if (grp == 0 && e < total + a.F) {
+            const bool is_w = e < total;
+            const int n = is_w ? e / a.F : a.kin, f = is_w ? e % a.F : e - total;
+            const long long j0 = a.o_cw + (long long)n * N2 + f, j1 = j0 + a.F;
+            pre_p[0] = a.param[j0]; pre_p[1] = a.param[j1];
+            pre_m[0] = a.m[j0]; pre_m[1] = a.m[j1];
+            pre_v[0] = a.v[j0]; pre_v[1] = a.v[j1];
+            if (a.reg_coef) { pre_c[0] = a.reg_coef[j0]; pre_c[1] = a.reg_coef[j1]; }
+        }
+    }
     if (a.cw_tilew > 0)
         cconv_fold_body<kFoldLanesTiled>(a.cw_slabs, a.cw_splits, a.cw_slab, a.cw_colsum, a.grad + a.o_cw,
                                          a.grad + a.o_cw + (long long)a.kin * 2 * a.F, a.kin, a.F, bx, idx, gv, a.cw_tilew);
@@ -505,8 +522,8 @@ __device__ __forceinline__ void adam_fold_role(const AdamRxArgs& a, const dccn_a
     for (int e = 0; e < 2; ++e) {
         if (idx[e] < 0) continue;
         const long long j = a.o_cw + idx[e];
-        float p = a.param[j], mm = a.m[j], vv = a.v[j];
-        const float ge = gv[e] + (gate * (a.reg_coef ? a.reg_coef[j] : 0.f)) * p;
+        float p = pre_p[e], mm = pre_m[e], vv = pre_v[e];
+        const float ge = gv[e] + (gate * pre_c[e]) * p;
         mm += (ge - mm) * omb1;
         vv += (ge * ge - vv) * omb2;
         p -= (mm * alpha) / (sqrtf(vv) + hp.eps);

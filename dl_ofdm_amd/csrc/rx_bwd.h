@@ -176,10 +176,12 @@ __device__ __forceinline__ unsigned long long trace_hwid(int role) {
 #define DCCN_TRACE_MARK(slot, extra) do { } while (0)
 #endif
 
-struct NormRideArgs {      // R0 of the next batch on the leading blocks (blocks == 0: none)
+struct NormRideArgs {      // R0 of the next batch on `blocks` extra workgroups (0: none)
     const float* x; float* y; double* power;
     int batch, cols, blocks;
     float eps, peak;
+    int trail;             // 0: they lead the grid; 1: they close it -- dispatched into the slots the last dW items free, where
+                           // the launch otherwise ends with a mostly idle chip (profiles/r03_blocktrace.txt: 4-5 us of tail)
 };
 
 // grid: [R0 blocks][tail-finalize blocks][dX tiles (+ dWeff partial)][dW (tile, k range) items]
@@ -192,15 +194,17 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
     int b = (int)blockIdx.x;
     DCCN_TRACE_MARK(0, 0);
     stamp_mark(px.stamp, 0);
-    if (b < nr.blocks) {
+    const int nlead = nr.trail ? 0 : nr.blocks;
+    const int ntrail0 = (int)gridDim.x - (nr.trail ? nr.blocks : 0);           // first trailing R0 block
+    if (b < nlead || b >= ntrail0) {
         norm_fused_body<kNormFusedCG, kNormFusedRPT>(nr.x, nr.y, nr.batch, nr.cols, nr.eps, nr.peak, nr.power, nullptr,
-                                                     nullptr, nullptr, hp, b, nr.blocks);
+                                                     nullptr, nullptr, hp, b < nlead ? b : b - ntrail0, nr.blocks);
         DCCN_TRACE_MARK(3, trace_hwid(0));
         DCCN_TRACE_MARK(2, 0);
         stamp_mark(px.stamp, 1);
         return;
     }
-    b -= nr.blocks;
+    b -= nlead;
     if (b < fin_blocks) {
         demod_tail_finalize_body(fin, b);
         DCCN_TRACE_MARK(3, trace_hwid(1));

@@ -123,14 +123,19 @@ class DeviceDataGen:
         return w["tx"], out_bits
 
     def channel(self, tx: torch.Tensor, snr_db, out_x: Optional[torch.Tensor] = None, taps: Optional[torch.Tensor] = None,
-                noise: Optional[torch.Tensor] = None, want_H: bool = False, offset: Optional[int] = None):
+                noise: Optional[torch.Tensor] = None, want_H: bool = False, offset: Optional[int] = None,
+                out_H: Optional[torch.Tensor] = None):
         """fading + AWGN on [n,S,n_sc,2] frames; ``taps`` / ``noise``: external draws instead of the Philox streams
         (static: standard normals [n,n_taps,2]; mobile: uniform phases [n,2,48,n_taps]; noise: normals [n,T,2]).
         H: complex [n,K] (static) or [n,S,K] (mobile)."""
         n = tx.shape[0]
         w = self._workspace(n)
         off = self.offset if offset is None else int(offset)
-        if isinstance(snr_db, torch.Tensor):
+        snr_t = w["snr"]
+        if (isinstance(snr_db, torch.Tensor) and snr_db.device == self.device and snr_db.dtype == torch.float32 and
+                snr_db.is_contiguous() and snr_db.numel() == n):
+            snr_t = snr_db              # per-frame SNRs already on the device (a row of the epoch's table): no copy, no launch
+        elif isinstance(snr_db, torch.Tensor):
             w["snr"].copy_(snr_db.reshape(-1).to(torch.float32))
             w["snr_scalar"] = None
         elif np.isscalar(snr_db):
@@ -143,7 +148,12 @@ class DeviceDataGen:
         if out_x is None:
             out_x = torch.empty(n, self.S, self.n_sc, 2, dtype=torch.float32, device=self.device)
         hshape = (n, self.S, self.K, 2) if (self.doppler or self.mixed) else (n, self.K, 2)
-        H = torch.empty(*hshape, dtype=torch.float32, device=self.device) if want_H else None
+        if out_H is not None:
+            if tuple(out_H.shape) != hshape or out_H.dtype != torch.float32 or not out_H.is_contiguous():
+                raise ValueError("out_H must be a contiguous float32 tensor of shape %s" % (hshape,))
+            H, want_H = out_H, True
+        else:
+            H = torch.empty(*hshape, dtype=torch.float32, device=self.device) if want_H else None
         if taps is not None and not self.mixed:
             taps = torch.as_tensor(taps, dtype=torch.float32).to(self.device).contiguous()
         if noise is not None:
@@ -161,19 +171,19 @@ class DeviceDataGen:
                 th = torch.as_tensor(th, dtype=torch.float32).to(self.device).contiguous()
             arr, keep = self._frame_groups(n)
             check(self.lib.dccn_channel_groups_awgn(self._p(tx), arr, len(arr), self._p(tn), self._p(th), self.t_sym,
-                                                    self.S, self.n_sc, self._p(w["snr"]), self._p(noise), self._p(out_x),
+                                                    self.S, self.n_sc, self._p(snr_t), self._p(noise), self._p(out_x),
                                                     self._p(H), self.K, npw, n, self.seed, off,
                                                     self._p(w["ws"]), w["nws"], self._stream()), "dccn_channel_groups_awgn")
             return out_x, npw_t, (torch.view_as_complex(H) if want_H else None)
         if self.doppler:
             check(self.lib.dccn_channel_doppler_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
                                                      self.n_taps, self.L, self.Fd, self.t_sym, self.S, self.n_sc,
-                                                     self._p(w["snr"]), self._p(noise), self._p(out_x), self._p(H),
+                                                     self._p(snr_t), self._p(noise), self._p(out_x), self._p(H),
                                                      self.K, npw, n, self.seed, off, self._p(w["ws"]),
                                                      w["nws"], self._stream()), "dccn_channel_doppler_awgn")
             return out_x, npw_t, (torch.view_as_complex(H) if want_H else None)
         check(self.lib.dccn_channel_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
-                                         self.n_taps, self.L, 1 if self.identity else 0, self._p(w["snr"]),
+                                         self.n_taps, self.L, 1 if self.identity else 0, self._p(snr_t),
                                          self._p(noise), self._p(out_x), self._p(H), self.K, npw, n,
                                          self.T, self.seed, off, self._p(w["ws"]), w["nws"], self._stream()),
               "dccn_channel_awgn")

@@ -256,6 +256,60 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
     return result
 
 
+class DeviceEpochLoop:
+    """One training step of the on-device epoch loop as four library calls and nothing else on the host: transmit, channel
+    (+ AWGN at this step's row of the epoch's SNR table, already on the device), the fused equaliser step, and ONE monitor
+    launch that computes `chan_rms` (ofdmreceiver_np_mp.py:245, 325-333) and adds the step's scalars onto the epoch
+    accumulators.  Round 3 did the last part with ~25 framework launches and a host-to-device copy per step, which made the
+    loop host-bound at twice the fused step's own time (tools/eqloop.py)."""
+
+    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int):
+        import ctypes as C
+        import torch
+        self.C, self.torch = C, torch
+        self.F, self.o, self.tr, self.gen, self.pl, self.steps = FLAGS, ofdmobj, trainer, gen, pl, int(steps)
+        dev, B = trainer.device, pl.batch
+        self.per_symbol = 1 if (gen.doppler or gen.mixed) else 0
+        hshape = (B, FLAGS.nsymbol, ofdmobj.K, 2) if self.per_symbol else (B, ofdmobj.K, 2)
+        self.H = torch.empty(*hshape, dtype=torch.float32, device=dev)
+        self.acc = torch.zeros(5, dtype=torch.float32, device=dev)
+        self.snr = torch.zeros(self.steps, B, dtype=torch.float32, device=dev)
+        self.snr_rows = [self.snr[i] for i in range(self.steps)]
+        self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
+        self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
+        self.i = 0
+
+    def begin_epoch(self, snr_table: np.ndarray):
+        """snr_table [steps, B]: the epoch's per-frame training SNRs (one host draw + ONE copy per epoch, :407)"""
+        self.snr.copy_(self.torch.from_numpy(np.ascontiguousarray(snr_table, dtype=np.float32).reshape(self.steps, -1)))
+        self.acc.zero_()
+        self.i = 0
+
+    def step(self):
+        C, pl, gen, tr = self.C, self.pl, self.gen, self.tr
+        i = self.i % self.steps
+        self.i += 1
+        tx, _ = gen.transmit(pl.batch, out_bits=pl.bits)
+        _, npow, _ = gen.channel(tx, self.snr_rows[i], out_x=pl.x, out_H=self.H)
+        gen.offset += 1
+        pl.run(True)
+        from ._lib import check
+        check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H.data_ptr(), self.per_symbol, pl.batch,
+                                                self.F.nsymbol, self.o.K, pl.metrics_buf.data_ptr(), pl.tx_power.data_ptr(),
+                                                None if npow is None else npow.data_ptr(), self.acc.data_ptr(), None,
+                                                self.ws.data_ptr(), self.nws, pl._stream()), "dccn_eq_monitor_accumulate")
+
+    def epoch_means(self) -> np.ndarray:
+        return self.acc.cpu().numpy() / max(self.steps, 1)
+
+
+def device_epoch_runner(FLAGS, ofdmobj, trainer, gen, pl, steps: int = 197):
+    """tools/eqloop.py: one step of the loop below as a callable (SNR table drawn once)"""
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps)
+    loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, pl.batch], p=TRAIN_SNR_PROB))
+    return loop.step
+
+
 def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, run_test):
     """the epoch loop of :func:`train` with every batch drawn on the GPU (static channels) straight into the fused
     plan's buffers; per-step scalars are accumulated on the device and fetched once per epoch."""
@@ -264,22 +318,16 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     # :389-392,409: fading0 (static) unless --mobile, then the mixed-Doppler simulator (mobile=True, mix=True)
     gen = DeviceDataGen(FLAGS, ofdmobj, device=trainer.device, seed=FLAGS.seed, mobile=FLAGS.mobile, mix=FLAGS.mobile)
     pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
-    mview = pl.metrics_buf.view(torch.float32)                      # dccn_metrics: [12] ce_mean, [13] berlin
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
     steps = frame_cnt // batch_size
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps)
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))
-        acc = torch.zeros(5, dtype=torch.float32, device=trainer.device)
+        # :407 one draw for the epoch's frames (the same stream of values as `steps` draws of one batch each)
+        loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, batch_size], p=TRAIN_SNR_PROB))
         for i in range(steps):
-            snr = np.random.choice(TRAIN_SNR_GRID, [batch_size], p=TRAIN_SNR_PROB)         # :407
-            tx, _ = gen.transmit(batch_size, out_bits=pl.bits)
-            _, npow, H = gen.channel(tx, snr, out_x=pl.x, want_H=True)
-            gen.offset += 1
-            pl.run(True)
-            chan_gt = H if H.dim() == 3 else H[:, None, :].expand(-1, FLAGS.nsymbol, -1)
-            rms = trainer.chan_rms(torch.view_as_complex(pl.chest), chan_gt)
-            acc[0:2].add_(mview[12:14]); acc[2:3].add_(pl.tx_power); acc[3:4].add_(npow); acc[4:5].add_(rms)
-        a = acc.cpu().numpy() / max(steps, 1)
+            loop.step()
+        a = loop.epoch_means()
         train_loss_epoch = float(a[0])
         snr = np.random.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)       # :438
         tx, _ = gen.transmit(FLAGS.eval_frames, out_bits=ev.bits)

@@ -391,6 +391,18 @@ int dccn_timer_elapsed_ms(dccn_timer* t, float* ms);     /* synchronises on the 
 int dccn_timer_destroy(dccn_timer* t);
 int dccn_stream_synchronize(dccn_stream_t stream);
 
+/* ---- per-step monitors of the equaliser harness (dev/py/ofdmreceiver_np_mp.py:245, 325-333: `chan_rms`; :411-425: the
+ * per-epoch means of ce_mean, berlin, tx_power, noise power and chan_rms) in ONE launch -------------------------------
+ * chan_rms = mean((LN(chan) - LN(chest))^2), LN = LayerNormalization(axis=1, center=False, scale=False, eps 1e-3) over the
+ * OFDM-symbol axis of the [B, S, K, 2] views.  chan is [B, S, K, 2] (chan_per_symbol = 1) or one row per frame [B, K, 2]
+ * (static channels: its LN is 0, as in the reference).  acc5 (nullable) += {metrics->ce_mean, metrics->berlin, *tx_power,
+ * *noise_power, chan_rms}; rms_out (nullable) = chan_rms.  The workspace (dccn_eq_monitor_workspace_size bytes) must be
+ * ZERO before the first call and belongs to the calls of one stream; each call leaves it ready for the next. */
+size_t dccn_eq_monitor_workspace_size(int B, int S, int K);
+int dccn_eq_monitor_accumulate(const float* chest, const float* chan, int chan_per_symbol, int B, int S, int K,
+                               const dccn_metrics* metrics, const float* tx_power, const float* noise_power, float* acc5,
+                               float* rms_out, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+
 /* ---- step timeline: in-situ start / end of the launches of dccn_rx_train_step / dccn_rx_eval_step ----------------------
  * Replaces nothing in the reference (TF1 has `RunMetadata` step stats for this: dev/py/ofdmreceiver_np.py:234 runs the
  * step without them); it exists so that a step time can be decomposed into per-launch durations and the gaps between

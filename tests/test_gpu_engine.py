@@ -324,16 +324,18 @@ def test_forward_prefetch_on_the_optimizer_launch_is_bitwise():
         lib.dccn_set_tuning(18, default[1])
 
 
-def test_double_buffered_normalisation_on_the_backward_launch_is_bitwise():
-    """Tuning knob 18 (off by default: measured neutral): R0 of the next batch rides on the backward launch into a second
-    x_norm buffer instead of the optimizer launch; eager double-buffered steps, captured single-buffer replays of either
-    parity and the closing step interleave freely and stay bit-identical to plain steps."""
+@pytest.mark.parametrize("placement", [1, 2])
+def test_double_buffered_normalisation_on_the_backward_launch_is_bitwise(placement):
+    """Tuning knob 18: R0 of the next batch rides on the backward launch into a second x_norm buffer instead of the optimizer
+    launch (1: on the leading workgroups of that grid, 2: on its closing ones, in the slots the last dW items free); eager
+    double-buffered steps, captured single-buffer replays of either parity and the closing step interleave freely and stay
+    bit-identical to plain steps."""
     from dl_ofdm_amd import _lib
     from dl_ofdm_amd.engine import RxDims, RxEngine
     lib = _lib.load()
     default = lib.dccn_get_tuning(18)
     try:
-        assert lib.dccn_set_tuning(18, 1) == 0
+        assert lib.dccn_set_tuning(18, placement) == 0
         frames, nbits = 300, 2
         dims = RxDims(S=7, kin=80, F=64, D=320, nbits=nbits)
         rng = np.random.RandomState(10)

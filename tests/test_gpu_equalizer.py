@@ -498,6 +498,49 @@ def test_chan_rms_monitor_is_keras_layer_normalization_over_the_symbol_axis():
     assert abs(got - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("B,per_symbol", [(6, 1), (73, 0), (73, 1), (1024, 0)])
+def test_monitor_launch_equals_the_framework_monitors(B, per_symbol):
+    """dccn_eq_monitor_accumulate: chan_rms (same Keras LayerNormalization as above, fp64 NumPy as the judge; a static
+    channel is one row per frame whose normalisation is exactly zero) and the epoch accumulators
+    {ce_mean, berlin, tx_power, noise_power, chan_rms} over three calls, in one launch per step."""
+    import ctypes as C
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    S, K = 7, 64
+    rng = np.random.RandomState(B + per_symbol)
+    est = (rng.standard_normal((B, S, K, 2)) * 0.7 + 0.1).astype(np.float32)
+    gt = (rng.standard_normal((B, S, K, 2) if per_symbol else (B, K, 2))).astype(np.float32)
+
+    def keras_ln(t):
+        t = t.astype(np.float64)
+        return (t - t.mean(axis=1, keepdims=True)) / np.sqrt(t.var(axis=1, keepdims=True) + 1e-3)
+    gfull = gt if per_symbol else np.broadcast_to(gt[:, None], (B, S, K, 2))
+    want = float(((keras_ln(gfull) - keras_ln(est)) ** 2).mean())
+    nws = lib.dccn_eq_monitor_workspace_size(B, S, K)
+    ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
+    acc = torch.zeros(5, dtype=torch.float32, device="cuda")
+    rms = torch.zeros(1, dtype=torch.float32, device="cuda")
+    m = np.zeros(16, np.float32)
+    m[12], m[13] = 0.625, 0.03125                                             # dccn_metrics.ce_mean / berlin
+    mbuf = torch.as_tensor(m).cuda()
+    txp, npw = torch.tensor([1.5], device="cuda"), torch.tensor([0.25], device="cuda")
+    e, g = dev(est), dev(gt)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        _lib.check(lib.dccn_eq_monitor_accumulate(e.data_ptr(), g.data_ptr(), per_symbol, B, S, K, mbuf.data_ptr(),
+                                                  txp.data_ptr(), npw.data_ptr(), acc.data_ptr(), rms.data_ptr(),
+                                                  ws.data_ptr(), nws, st), "monitor")
+    torch.cuda.synchronize()
+    assert abs(float(rms) - want) <= 2e-6 * max(want, 1e-3)
+    got = acc.cpu().numpy()
+    np.testing.assert_allclose(got, 3 * np.array([0.625, 0.03125, 1.5, 0.25, want]), rtol=3e-6)
+    assert int(ws[:4].view(torch.int32)) == 0                                  # arrival counter left ready for the next call
+    # the framework-side monitor the host-data path keeps using gives the same number
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer(seed=3, cp=True)
+    ref = float(tr.chan_rms(torch.view_as_complex(e), torch.view_as_complex(dev(np.ascontiguousarray(gfull)))))
+    assert abs(ref - float(rms)) <= 1e-5 * max(want, 1e-3)
+
+
 def test_equalizer_harness_on_device_generated_data():
     """receiver_mp.train(device_data=True): bits, frames, fading, noise and the true channel response all come
     from the GPU generator; same learning criterion as the host-data test above."""

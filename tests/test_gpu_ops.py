@@ -303,7 +303,7 @@ def test_dense_tail_fused(ops, nbits, M, K, N):
     # and the two-launch path (dense, then tail) agrees to rounding
     z = ops.dense(dev(x), dev(w), dev(b))
     ce3, prob3, _ = ops.demod_tail_eval(z.view(M, D, 2), dev(flat), dev(bits, torch.int32), nbits)
-    assert_close(prob3.cpu().numpy().reshape(-1), prob.cpu().numpy().reshape(-1), "fused vs separate prob", tol=2e-6)
+    assert_close(prob3.cpu().numpy().reshape(-1), prob.cpu().numpy().reshape(-1), "fused vs separate prob", tol=5e-6)
 
 
 # ---- R7 -------------------------------------------------------------------------------------
