@@ -1729,6 +1729,24 @@ size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train) {
     if (!eq_shape_ok(shape)) return 0;
     return eq_ws_bytes(shape, train);
 }
+size_t dccn_eq_rx_folded_floats(const dccn_eq_shape* shape) {
+    if (!eq_shape_ok(shape)) return 0;
+    const size_t N2 = 2 * (size_t)(shape->K + shape->CP), dN = 2 * (size_t)shape->D;
+    return (size_t)shape->S * N2 * dN + dN;
+}
+int dccn_eq_rx_fold(const dccn_eq_shape* shape, const float* rx_params, float* out, dccn_stream_t stream) {
+    if (!eq_shape_ok(shape) || !rx_params || !out) return DCCN_ERR_INVALID_ARG;
+    const EqDims d = eq_dims(shape);
+    dccn_rx_shape rsh;
+    rsh.batch = 1; rsh.S = d.S; rsh.kin = d.cp ? d.nsc : d.K; rsh.F = d.F; rsh.D = d.D; rsh.nbits = shape->nbits;
+    const RxLayout L = rx_layout(&rsh);
+    const int N2 = 2 * d.nsc, rows = d.S * N2;
+    hipLaunchKernelGGL(eq_rx_fold_kernel, dim3(rows + 1), dim3(256), 0, (hipStream_t)stream, rx_params + L.o_conv_w,
+                       rx_params + L.o_conv_b, rx_params + L.o_dense_w, rx_params + L.o_dense_b, out, out + (size_t)rows * L.dN,
+                       d.S, N2, d.win, rsh.kin, d.F, L.dN);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
 int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream) {
     return eq_step_impl(shape, buf, false, dccn_adam_hparams(), (hipStream_t)stream);
 }

@@ -283,13 +283,19 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     }
     DCCN_TRY(dense_fwd_impl(w.cat, P + d.o[18], P + d.o[19], b->out_eq, R, 4 * K, N2, s));
     // frozen basic receiver (model.py:1222-1292) + loss/BER
-    DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
-    TailFinalizeArgs fin;
-    bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
     // few rows (73 frames): the fused dense + tail launch is 20 tiles of 48x64 behind a 14-tile k-loop (23 us); the
     // one-latency 16x16 tiles of fewrow.h (200 blocks) followed by the stand-alone tail launch take about half of that
-    const bool few_rx = g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && B <= 96 && (L.dK == 896 || L.dK == 640) &&
-                        (L.dN % 16) == 0 && aligned16(w.fft) && aligned16(Q + L.o_dense_w) && aligned16(w.z);
+    const bool few_rx = g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && B <= 96 && (L.dK % 16) == 0 && L.dK >= 128 &&
+                        L.dK <= 1152 && (L.dN % 16) == 0 && aligned16(w.fft) && aligned16(Q + L.o_dense_w) && aligned16(w.z);
+    // ... and with the receiver's C-Conv and dense layer folded into one matrix (dccn_eq_rx_fold: the receiver is frozen)
+    // both run as ONE such GEMM over the flattened frame, K = S * 2 n_sc
+    const float* Mf = b->rx_folded;
+    const int fK = d.S * N2;
+    const bool folded = few_rx && Mf != nullptr && g_tune[TUNE_FEWROW] >= 1 && aligned16(Mf) && aligned16(b->out_eq) &&
+                        (fK % 16) == 0 && fK <= 1152;
+    if (!folded) DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
+    TailFinalizeArgs fin;
+    bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
     if (!few_rx && dense_tail_planned(sh->nbits, train, B, L.dN) &&
         dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
         fin_deferred = replan && train;
@@ -298,7 +304,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                                  &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? &fin : nullptr));
     } else {
         fin_deferred = replan && train;     // (the tail's metric reduction rides on the optimizer launch either way)
-        DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
+        if (folded) DCCN_TRY(dense_fwd_impl(b->out_eq, Mf, Mf + (size_t)fK * L.dN, w.z, B, fK, L.dN, s));
+        else DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
         DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
                            train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s,
                            fin_deferred ? &fin : nullptr));
@@ -306,13 +313,18 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     if (!train) return DCCN_OK;
 
     // ---- backward: through the frozen receiver to its input ...
-    DCCN_TRY(dense_bwd_x_impl(w.dz, Q + L.o_dense_w, w.dfft, B, L.dK, L.dN, s));
-    if (!d.cp) {                                        // nothing flows back into the cyclic-prefix samples
-        hipLaunchKernelGGL(zero_fill_kernel, dim3(ew_blocks_n((long long)R * N2)), dim3(256), 0, s, w.dout,
-                           (long long)R * N2);
-        DCCN_LAUNCH_CHECK();
+    if (folded) {
+        // dout = dz . Mf^T in one GEMM (the zero rows of Mf leave zeros in the cyclic-prefix samples when cp = 0)
+        DCCN_TRY(dense_bwd_x_impl(w.dz, Mf, w.dout, B, fK, L.dN, s));
+    } else {
+        DCCN_TRY(dense_bwd_x_impl(w.dz, Q + L.o_dense_w, w.dfft, B, L.dK, L.dN, s));
+        if (!d.cp) {                                        // nothing flows back into the cyclic-prefix samples
+            hipLaunchKernelGGL(zero_fill_kernel, dim3(ew_blocks_n((long long)R * N2)), dim3(256), 0, s, w.dout,
+                               (long long)R * N2);
+            DCCN_LAUNCH_CHECK();
+        }
+        DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout + d.win, R, rsh.kin, d.F, s, N2));
     }
-    DCCN_TRY(cconv_bwd_x_impl(w.dfft, Q + L.o_conv_w, w.dout + d.win, R, rsh.kin, d.F, s, N2));
     // ... then the equaliser, last layer first.  replan: every weight gradient stays where its GEMM left it (finished
     // in the gradient arena, or as split-K slabs in the layer's own workspace) until the optimizer launch
     DeferredSlabs ds5{}, dsT{}, ds4{}, ds3{}, ds2{}, ds1{}, ds0{};       // (null slabs: the gradient arena holds the result)

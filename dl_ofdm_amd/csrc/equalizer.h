@@ -260,6 +260,38 @@ __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a) 
     *a.counter = 0u;
 }
 
+// ---- the FROZEN receiver's two linear layers as one matrix (equaliser training, ofdmreceiver_np_mp.py:264-330) -------------
+// z[b] = sum_s (x_s . Weff) . Wd_s + ... = out_eq_flat[b] . Mf + bf with Mf[s*N2 + k][j] = sum_c Weff[k'][c] Wd[s*2F + c][j]
+// (k' = k - win, rows of the cyclic prefix are zero when cp = 0) and bf = bd + sum_s cb . Wd_s.  The receiver's weights do
+// not change while the equaliser trains, so Mf is built once; the step then runs ONE few-row GEMM where it ran the
+// C-Conv and the dense layer, and its transpose on the way back (dout = dz . Mf^T).  Block r = row of Mf, block `rows` = bf.
+__global__ __launch_bounds__(256) void eq_rx_fold_kernel(const float* __restrict__ cw, const float* __restrict__ cb,
+                                                         const float* __restrict__ wd, const float* __restrict__ bd,
+                                                         float* __restrict__ Mf, float* __restrict__ bf, int S, int N2,
+                                                         int win, int kin, int F, int dN) {
+    const int rows = S * N2, r = (int)blockIdx.x, F2 = 2 * F;
+    if (r == rows) {
+        for (int j = threadIdx.x; j < dN; j += 256) {
+            float acc = bd ? bd[j] : 0.f;
+            for (int s = 0; s < S; ++s)
+                for (int c = 0; c < F2; ++c) {
+                    float b = 0.f;
+                    if (cb) { const float d = cb[c >> 1] - cb[F + (c >> 1)]; b = (c & 1) ? -d : d; }
+                    acc += b * wd[(size_t)(s * F2 + c) * dN + j];
+                }
+            bf[j] = acc;
+        }
+        return;
+    }
+    const int s = r / N2, k = r % N2 - win;
+    for (int j = threadIdx.x; j < dN; j += 256) {
+        float acc = 0.f;
+        if (k >= 0 && k < 2 * kin)
+            for (int c = 0; c < F2; ++c) acc += cconv_weff(cw, F, k, c) * wd[(size_t)(s * F2 + c) * dN + j];
+        Mf[(size_t)r * dN + j] = acc;
+    }
+}
+
 // ---- one-channel, one-filter complex "same" convolution as a dense layer ---------------------
 // layers_conv2d_complex(chest, 1, (n_sym, K), padding='same') (model.py:428) slides a kL x kW
 // complex kernel over an L x W complex image with TF's SAME zero padding.  At L x W = 7 x 64 the

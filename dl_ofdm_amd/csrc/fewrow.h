@@ -116,18 +116,127 @@ __global__ __launch_bounds__(256) void fewrow_kernel(const GemmParams p) {
     stamp_mark(p.stamp, 1);
 }
 
+// dW[Ko, N] = X^T . dY with the FEW rows as the contraction (k <= 96): one block per 64x64 output tile, every operand
+// requested up front.  X[k][.] and dY[k][.] are k-major as they lie in memory: lane (c, kq) loads the float4 X[k][m0 + 4c ..]
+// and dY[k][n0 + 4c ..] of row k = 4 t + kq and uses their four components as the operands of 4 x 4 MFMA sub-tiles whose rows /
+// columns interleave (sub-tile (ai, bj) holds rows m0 + 4 i + ai, columns n0 + 4 j + bj): no transposes, no LDS staging.
+// Wave w owns the k steps t = w, w + 4, ...; the waves meet once in LDS (fixed order), wave w finishes the sub-tiles ai = w
+// and stores rows of four consecutive columns as float4.  Column sums of dY (bias gradient) by the m0 = 0 tiles.
+constexpr int kFewrowDwSteps = 6;             // k steps per wave: 4 waves x 6 steps x 4 rows = 96 rows
+constexpr size_t kFewrowDwSmem = (size_t)(4 * 16 * 4 * 64 + 4 * 64 * 4) * sizeof(float);
+__device__ __forceinline__ void fewrow_dw_tile(const GemmParams& p, const int tile, float* __restrict__ smem) {
+    float* xch = smem;                         // [wave][ai][bj][r][lane]
+    float* csx = smem + 4 * 16 * 4 * 64;       // [wave][bj][lane]   (column sums, m0 = 0 tiles)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int ntn = p.N >> 6;
+    const int m0 = (tile / ntn) * 64, n0 = (tile % ntn) * 64;
+    const int rows = p.K;                      // the few rows
+    float4 a[kFewrowDwSteps], b[kFewrowDwSteps];
+#pragma unroll
+    for (int i = 0; i < kFewrowDwSteps; ++i) {
+        const int k = 4 * (w + 4 * i) + kq;
+        const int kc = min(k, rows - 1);
+        const float4 ta = *reinterpret_cast<const float4*>(p.A + (size_t)kc * p.lda + m0 + 4 * c);
+        const float4 tb = *reinterpret_cast<const float4*>(p.B + (size_t)kc * p.ldb + n0 + 4 * c);
+        const bool ok = k < rows;
+        a[i] = ok ? ta : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[i] = ok ? tb : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) acc[ai][bj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = p.colsum != nullptr && m0 == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kFewrowDwSteps; ++i) {
+        const float av[4] = {a[i].x, a[i].y, a[i].z, a[i].w}, bv[4] = {b[i].x, b[i].y, b[i].z, b[i].w};
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+                acc[ai][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ai], bv[bj], acc[ai][bj], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) cs[bj] += bv[bj];
+        }
+    }
+    // every wave leaves the sub-tiles it does not finish itself
+#pragma unroll
+    for (int ai = 0; ai < 4; ++ai) {
+        if (ai == w) continue;
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[(((w * 4 + ai) * 4 + bj) * 4 + r) * 64 + lane] = acc[ai][bj][r];
+    }
+    if (do_cs) {
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+            float v = cs[bj];
+            v += __shfl_xor(v, 16, 64);        // the four k quarters of the wave
+            v += __shfl_xor(v, 32, 64);
+            csx[(w * 4 + bj) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+    // wave w: sub-tiles (ai = w, bj = 0..3), partial sums in wave order 0..3 (its own share taken from registers)
+    f32x4 own[4];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) {
+        own[bj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+            if (ai == w) own[bj] = acc[ai][bj];                    // (wave-uniform select)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float o[4];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+            float v = 0.f;
+#pragma unroll
+            for (int ws = 0; ws < 4; ++ws)
+                v += (ws == w) ? own[bj][r] : xch[(((ws * 4 + w) * 4 + bj) * 4 + r) * 64 + lane];
+            o[bj] = v;
+        }
+        const int row = m0 + 4 * (4 * kq + r) + w;
+        *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + n0 + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (do_cs && w == 0 && kq == 0) {
+        float o[4];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+            o[bj] = ((csx[(0 * 4 + bj) * 64 + lane] + csx[(1 * 4 + bj) * 64 + lane]) + csx[(2 * 4 + bj) * 64 + lane]) +
+                    csx[(3 * 4 + bj) * 64 + lane];
+        *reinterpret_cast<float4*>(p.colsum + n0 + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+static inline bool fewrow_dw_ok(const GemmParams& pw) {
+    return pw.K >= 1 && pw.K <= 4 * 4 * kFewrowDwSteps && (pw.M % 64) == 0 && (pw.N % 64) == 0 && pw.vecA && pw.vecB &&
+           (pw.lda % 4) == 0 && (pw.ldb % 4) == 0 && (pw.ldc % 4) == 0 && aligned16(pw.C) &&
+           (pw.colsum == nullptr || aligned16(pw.colsum));
+}
+
 // dense backward of a few-row batch in ONE grid: dX tiles as above (ACTX: element-wise stage of the caller's graph on the
 // way out) and the unsplit dW = X^T . dY tiles of gemm16.h behind them (k = the few rows: one or two k-tiles)
-template <int NG, int ACTX, int WWGM, int WWGN, int WTM, int WTN, int BK>
+template <int NG, int ACTX, int WWGM, int WWGN, int WTM, int WTN, int BK, bool DWFEW>
 __global__ __launch_bounds__(256) void dense_bwd_fewrow_kernel(const GemmParams px, const GemmParams pw, const int nx, const int tw) {
     const int b = (int)blockIdx.x;
     stamp_mark(px.stamp, 0);
     if (b < nx) {
         fewrow_tile<OP_KCONTIG, NG, ACTX>(px, b, nx);
     } else {
-        TailEpiParams none{};
         const int c = b - nx;
-        gemm16_block<OP_ICONTIG, OP_ICONTIG, WWGM, WWGN, WTM, WTN, BK, 1, 1, EPI_STORE, 1, false>(pw, none, c % tw, tw, c / tw, 0);
+        if constexpr (DWFEW) {
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            fewrow_dw_tile(pw, c, smem);
+        } else {
+            TailEpiParams none{};
+            gemm16_block<OP_ICONTIG, OP_ICONTIG, WWGM, WWGN, WTM, WTN, BK, 1, 1, EPI_STORE, 1, false>(pw, none, c % tw, tw, c / tw, 0);
+        }
     }
     stamp_mark(px.stamp, 1);
 }
@@ -168,10 +277,16 @@ static int launch_dense_bwd_fewrow_ng(const GemmParams& px, const GemmParams& pw
     using CW = Cfg16<OP_ICONTIG, OP_ICONTIG, 2, 2, 2, 2, 64, 1>;
     const int nx = ceil_div(px.M, 16) * (px.N / 16);
     const int tw = ceil_div(pw.N, CW::BN) * ceil_div(pw.M, CW::BM);
-    const size_t smem = CW::smem_bytes(0);
-    auto kern = dense_bwd_fewrow_kernel<NG, ACTX, 2, 2, 2, 2, 64>;
-    DCCN_TRY(set_smem_attr(kern, smem));
-    hipLaunchKernelGGL(kern, dim3(nx + tw), dim3(256), smem, s, px, pw, nx, tw);
+    if (fewrow_dw_ok(pw)) {                      // the weight gradient on one-latency tiles as well
+        auto kern = dense_bwd_fewrow_kernel<NG, ACTX, 2, 2, 2, 2, 64, true>;
+        DCCN_TRY(set_smem_attr(kern, kFewrowDwSmem));
+        hipLaunchKernelGGL(kern, dim3(nx + tw), dim3(256), kFewrowDwSmem, s, px, pw, nx, tw);
+    } else {
+        const size_t smem = CW::smem_bytes(0);
+        auto kern = dense_bwd_fewrow_kernel<NG, ACTX, 2, 2, 2, 2, 64, false>;
+        DCCN_TRY(set_smem_attr(kern, smem));
+        hipLaunchKernelGGL(kern, dim3(nx + tw), dim3(256), smem, s, px, pw, nx, tw);
+    }
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

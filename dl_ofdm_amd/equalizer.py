@@ -58,7 +58,7 @@ class _FusedPlan:
         self.buffers = EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
                                  p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
                                  p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
-                                 p(self.ws), nws)
+                                 p(self.ws), nws, p(tr.rx_folded(self.shape)))
         self.graphs: Dict[int, C.c_void_p] = {}
 
     def _stream(self):
@@ -134,6 +134,17 @@ class EqualizerTrainer:
         self.pilot_carriers = torch.as_tensor(np.asarray(ofdmobj.pilotCarriers, dtype=np.int32)).to(self.device)
         self.fused_ok = True
         self._plans: Dict[int, _FusedPlan] = {}
+        self._rx_folded = None
+
+    def rx_folded(self, shape) -> torch.Tensor:
+        """The frozen receiver's C-Conv + dense layer as one matrix (include/dccn.h dccn_eq_rx_fold): built once -- the
+        receiver's weights do not change while the equaliser trains (ofdmreceiver_np_mp.py:330)."""
+        if self._rx_folded is None:
+            n = int(self.lib.dccn_eq_rx_folded_floats(C.byref(shape)))
+            self._rx_folded = torch.empty(n, dtype=torch.float32, device=self.device)
+            check(self.lib.dccn_eq_rx_fold(C.byref(shape), self.rx_arena.data_ptr(), self._rx_folded.data_ptr(),
+                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "dccn_eq_rx_fold")
+        return self._rx_folded
 
     # ---- arena ---------------------------------------------------------------------------------
     def _flatten(self):

@@ -492,7 +492,16 @@ typedef struct dccn_eq_buffers {
     float* tx_power;              /* device float[1], nullable */
     void* workspace;
     size_t workspace_bytes;
+    const float* rx_folded;       /* nullable: dccn_eq_rx_fold(rx_params) -- the frozen receiver's C-Conv and dense layer as one
+                                     matrix.  When given, few-row batches (<= 96 frames) run ONE GEMM where the step ran the two
+                                     layers (and one on the way back); must be rebuilt whenever rx_params change. */
 } dccn_eq_buffers;
+
+/* The frozen receiver's linear part folded into one matrix: out [S*2n_sc*2D + 2D] floats = Mf [S*2n_sc, 2D] then bf [2D], with
+ * z = out_eq_flat . Mf + bf  ==  dense(C-Conv(out_eq)) of dev/py/model.py:1246-1275 (rows of cyclic-prefix samples are zero
+ * when cp = 0).  Valid as long as rx_params do not change (they are frozen: ofdmreceiver_np_mp.py:330 trains Equalizer/ only). */
+size_t dccn_eq_rx_folded_floats(const dccn_eq_shape* shape);
+int dccn_eq_rx_fold(const dccn_eq_shape* shape, const float* rx_params, float* out, dccn_stream_t stream);
 
 int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets /* [21] */);
 size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train);

@@ -25,6 +25,24 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1e7 and abs(d["value"] - 8190 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    # ---- headline guards (a 24 % regression of the driver-timed step passed every test) ----------------------
+    st = d["step"]
+    diag = json.dumps({"regions_ms": st["regions_ms"], "boundaries": st.get("boundaries"),
+                       "clocks": d["device"].get("clocks_before_timed_regions")})
+    assert len(st["regions_ms"]) == 7 and abs(sorted(st["regions_ms"])[3] - d["ms_per_step"]) < 1e-4, diag
+    assert st["mfma_frac"] >= 0.33, "C2 step below 33 %% of the fp32 MFMA peak: %s" % diag
+    bd = st["boundaries"]
+    names = [l["name"] for l in bd["launches"]]
+    assert names == ["cconv_fwd", "dense_fwd_tail", "backward", "optimizer"], names       # the 4-launch plan, in stream order
+    assert bd["samples"] >= 200 and all(l["us"] > 1.0 and l["sclk_mhz"] > 500 for l in bd["launches"]), diag
+    # the step is its launches: a step time well above the in-situ launch time means the chip idles between them
+    assert d["ms_per_step"] * 1e3 <= 1.15 * bd["sum_launch_us"], "step %.1f us vs launches %.1f us: %s" % (
+        d["ms_per_step"] * 1e3, bd["sum_launch_us"], diag)
+    assert bd["sum_gap_us"] <= 0.2 * bd["sum_launch_us"], diag
+    assert max(st["regions_ms"]) <= 1.25 * min(st["regions_ms"]), diag
+    assert 0.9 * st["sclk_mhz_in_step"] <= 2400.0 and st["mfma_frac_at_measured_sclk"] >= st["mfma_frac"] * 0.99
+    box = d["device"]["box"]
+    assert box["cards"] and "kernel" in box and d["device"]["clocks_after_timed_regions"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0

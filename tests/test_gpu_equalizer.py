@@ -498,6 +498,47 @@ def test_chan_rms_monitor_is_keras_layer_normalization_over_the_symbol_axis():
     assert abs(got - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("cp", [True, False])
+def test_frozen_receiver_folds_into_one_matrix(cp):
+    """dccn_eq_rx_fold: Mf / bf with out_eq_flat . Mf + bf == dense(C-Conv(out_eq)) of the frozen receiver (model.py:1246-1275)
+    against float64 NumPy; cp = False reads the window behind the cyclic prefix (zero rows for the prefix samples)."""
+    import ctypes as C
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    S, K, CP, F, D = 7, 64, 16, 64, 320
+    kin, N2, F2, dN = (K + CP if cp else K), 2 * (K + CP), 2 * F, 2 * D
+    rng = np.random.RandomState(3 + cp)
+    cw = rng.standard_normal((kin, F2)).astype(np.float32)
+    cb = rng.standard_normal(F2).astype(np.float32)
+    wd = (rng.standard_normal((S * F2, dN)) / 30).astype(np.float32)
+    bd = rng.standard_normal(dN).astype(np.float32)
+    tail = np.zeros(40, np.float32)
+    arena = dev(np.concatenate([cw.ravel(), cb, wd.ravel(), bd, tail]))
+    sh = _lib.EqShape(5, S, K, CP, 1 if cp else 0, F, D, 2, 8, 8)
+    n = lib.dccn_eq_rx_folded_floats(C.byref(sh))
+    assert n == S * N2 * dN + dN
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.dccn_eq_rx_fold(C.byref(sh), arena.data_ptr(), out.data_ptr(),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fold")
+    Mf = out[:S * N2 * dN].view(S * N2, dN).cpu().numpy().astype(np.float64)
+    bf = out[S * N2 * dN:].cpu().numpy().astype(np.float64)
+    # reference: push a random frame through the two layers in float64
+    Wa, Wb = cw[:, :F].astype(np.float64), cw[:, F:].astype(np.float64)
+    Weff = np.zeros((2 * kin, F2))
+    Weff[0::2, 0::2], Weff[0::2, 1::2], Weff[1::2, 0::2], Weff[1::2, 1::2] = Wa, Wb, -Wb, -Wa
+    ba, bb = cb[:F].astype(np.float64), cb[F:].astype(np.float64)
+    cbe = np.empty(F2)
+    cbe[0::2], cbe[1::2] = ba - bb, bb - ba
+    x = rng.standard_normal((4, S, N2))
+    win = 0 if cp else 2 * CP
+    fft = x[:, :, win:win + 2 * kin] @ Weff + cbe                      # [4, S, 2F]
+    z = fft.reshape(4, S * F2) @ wd.astype(np.float64) + bd
+    got = x.reshape(4, S * N2) @ Mf + bf
+    assert np.abs(got - z).max() <= 2e-6 * np.abs(z).max()
+    if not cp:
+        assert not Mf.reshape(S, N2, dN)[:, :win].any()
+
+
 @pytest.mark.parametrize("B,per_symbol", [(6, 1), (73, 0), (73, 1), (1024, 0)])
 def test_monitor_launch_equals_the_framework_monitors(B, per_symbol):
     """dccn_eq_monitor_accumulate: chan_rms (same Keras LayerNormalization as above, fp64 NumPy as the judge; a static

@@ -167,7 +167,8 @@ def test_rx_backward_fused(ops, batch, kin, D):
 # ---- R2 -------------------------------------------------------------------------------------
 DENSE_SHAPES = [(36, 896, 640), (1170, 896, 640), (7, 13, 5), (300, 2048, 1024), (65, 130, 67), (1, 896, 640),
                 (600, 260, 132), (2000, 64, 64),       # k-major weight gradient: ragged tiles / ragged last k range
-                (73, 896, 896), (90, 512, 300)]        # <= 96 rows: the skinny 16x64 tiles (forward and dX)
+                (73, 896, 896), (90, 512, 300),        # <= 96 rows: the skinny 16x64 tiles (forward and dX)
+                (96, 896, 896), (5, 640, 896), (50, 256, 128), (73, 1120, 640)]   # fewrow.h: one-latency 16x16 / 64x64 tiles
 
 
 @pytest.mark.parametrize("M,K,N", DENSE_SHAPES)
