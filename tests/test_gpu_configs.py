@@ -152,7 +152,7 @@ def test_bench_two_ranks_over_gloo_one_json_line():
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 * 8190 / (out["ms_per_step"] * 6e-3)) <= 1e-6 * out["value"]
 
 
-def _c5_worker(rank, world, port, out_dir, q, kw):
+def _c5_worker(rank, world, port, out_dir, q, kw, classical_every=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from dl_ofdm_amd import config5
@@ -166,8 +166,8 @@ def _c5_worker(rank, world, port, out_dir, q, kw):
         torch.cuda.empty_cache()
         # ... and the whole pipeline (training chains, sweep points, classical units all dealt to ranks) through run()
         _, ber = config5.run(out_dir + "_run", kw["frames"], kw["eq_epochs"], kw["classical_frames"], kw["scale"], kw["nbits"],
-                             kw["channels"], kw["snrs"], classical_every=2, rank=r, world=w, device="cuda:%d" % local,
-                             verbose=False)
+                             kw["channels"], kw["snrs"], classical_every=classical_every, rank=r, world=w,
+                             device="cuda:%d" % local, verbose=False)
         q.put((r, table, eq, ber))
     finally:
         torch.distributed.destroy_process_group()
@@ -226,6 +226,59 @@ def test_c5_scaled_sharded_equals_serial_and_ber_falls_with_snr(tmp_path):
             cur = ber[(b * 3 + c) * 4:(b * 3 + c) * 4 + 4]
             assert cur[0] > cur[-1] and np.all(np.diff(cur) <= 0.02), (b + 1, config5.CHANNELS[c], cur)
     assert ber[0] < 0.45 and ber[3] < ber[0]
+
+
+def test_c5_full_size_sweep_sharded_equals_serial(tmp_path):
+    """BASELINE.json configs[4] at FULL size under `-m gpu`: 4 modulations x {EPA, EVA, ETU} x 40 SNRs = 480 points of
+    20 000 frames each (dev/py/run_local_ofdm.py:61-118, ofdmreceiver_np.py:59-91) plus the classical LMMSE / LS-Spline /
+    perfect-CSI columns -- only the TRAINING is shortened (a handful of epochs per model; the full schedules are the
+    builder-run profiles/r04_config5).  Serial and on 2 ranks (gloo, sharing this box's GPU): every point counts exactly
+    frames x 320 x nbits bits, the 2-rank table equals the serial one exactly, the CSV byte for byte; BER curves do not
+    rise with SNR; the perfect-CSI receiver is at least as good as every estimator on every curve."""
+    import time
+    import torch.multiprocessing as mp
+    from dl_ofdm_amd import config5
+    kw = dict(nbits=(1, 2, 3, 4), channels=config5.CHANNELS, snrs=config5.SNRS, frames=20000, eq_epochs=3, scale=0.004,
+              classical_frames=300)
+    t0 = time.time()
+    pts, ber_run = config5.run(str(tmp_path / "serial_run"), kw["frames"], kw["eq_epochs"], kw["classical_frames"], kw["scale"],
+                               kw["nbits"], kw["channels"], kw["snrs"], classical_every=3, verbose=False)
+    t_serial = time.time() - t0
+    torch.cuda.empty_cache()
+    assert len(pts) == 480 and ber_run.shape == (480,)
+    tj = json.load(open(str(tmp_path / "serial_run" / "config5_timing.json")))
+    assert tj["points"] == 480 and tj["frames"] == 20000 and tj["per_rank_seconds"][0]["sweep"] < 60
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 2, port, str(tmp_path / "sharded"), q, kw, 3)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        r, table, eq, ber2 = q.get(timeout=1500)
+        results[r] = (table, ber2)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        table, ber2 = results[r]
+        assert table.shape == (480, 6)
+        assert np.all(table[:, 5] == np.array([kw["frames"] * 320 * p.nbits for p in pts]))     # bits_counted, every point
+        assert np.array_equal(ber2, ber_run)
+    a = open(str(tmp_path / "serial_run" / "config5_ber.csv")).read()
+    b_ = open(str(tmp_path / "sharded_run" / "config5_ber.csv")).read()
+    assert a == b_ and a.count("\n") == 481
+    rows = [l.split(",") for l in a.splitlines()[1:]]
+    for b in range(4):
+        for c in range(3):
+            cur = ber_run[(b * 3 + c) * 40:(b * 3 + c) * 40 + 40]
+            assert cur[0] >= cur[-1] - 0.01 and np.all(np.diff(cur) <= 0.03), (b + 1, config5.CHANNELS[c], cur)
+            # classical columns (every third SNR): perfect CSI <= LMMSE and <= LS-Spline (within sampling error), falling
+            cl = np.array([[float(v) for v in r_[4:7]] for r_ in rows[(b * 3 + c) * 40:(b * 3 + c) * 40 + 40] if r_[4] != ""])
+            assert cl.shape == (14, 3)
+            assert np.all(cl[:, 2] <= cl[:, 0] + 0.01) and np.all(cl[:, 2] <= cl[:, 1] + 0.01), (b + 1, c, cl)
+            assert cl[0, 2] > cl[-1, 2]
+    print("full-size config 5 (short training): serial %.1f s, stages %s" % (t_serial, tj["per_rank_seconds"][0]))
 
 
 def test_classical_receivers_on_device_generated_frames():
