@@ -101,6 +101,10 @@ class ClassicalReceiverGPU:
         bits = bits.to(torch.int32).contiguous()
         f32 = dict(dtype=torch.float32, device=self.device)
         adv = self.advance if aligned else 0
+        if adv > self.CP:
+            # the delayed FFT window would start before the first symbol's cyclic prefix (the host receiver zero-fills
+            # there); no profile of radio.py has a centre tap that far out
+            raise NotImplementedError("FFT-window advance %d exceeds the cyclic prefix %d: use dl_ofdm_amd.benchmark" % (adv, self.CP))
         # FFT window: the frame delayed by `adv` samples = the K samples from CP - adv of every symbol row (the first
         # symbol's window then starts adv samples inside its own prefix; ClassicalReceiver shifts the flat frame instead,
         # which reads the same samples for every symbol: CP >= adv)
@@ -126,7 +130,7 @@ class ClassicalReceiverGPU:
             Hc = Hc.to(torch.float32)
             if Hc.dim() == 3:                                            # static channel: one response per frame
                 Hc = Hc[:, None, :, :].expand(n, S, K, 2)
-            if adv > 0 or (not aligned and self.advance > 0) or self.advance > 0:
+            if self.advance > 0:                                          # (aligned or not: the host does the same)
                 r = self.host.ramp(self.advance)                          # phase reference = the centre tap
                 rr = torch.as_tensor(np.stack([r.real, r.imag], -1).astype(np.float32), device=self.device)
                 Hc = torch.stack([Hc[..., 0] * rr[:, 0] - Hc[..., 1] * rr[:, 1],

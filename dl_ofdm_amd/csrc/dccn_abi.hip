@@ -780,6 +780,8 @@ static int cconv_bwd_grouped_impl(const float* x, const float* dout, const float
     if (!x || !dout || !w || !dx || !defer || rows <= 0 || groups < 1 || groups > 2) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < cconv_bwd_grouped_ws_bytes(rows, kin, F, groups)) return DCCN_ERR_WORKSPACE;
     SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    // (one output tile and > 16 384 rows would plan more slabs than the workspace holds: clamp like cconv_bwd_w_impl does)
+    if (sp.splits > kCconvBwMaxSplits) sp = plan_splitk_n(rows, kCconvBwMaxSplits, 64);
     if (sp.splits > kCconvBwMaxSplits) return DCCN_ERR_STATE;
     const size_t per = cconv_bw_ws_bytes(rows, kin, F) / sizeof(float);
     float* slabs = static_cast<float*>(ws);
@@ -2158,7 +2160,7 @@ int dccn_classical_gain(const float* Y, const float* H, const float* Gls, const 
     if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
     Carver c(workspace, workspace_bytes);
     double* partial = c.take<double>((size_t)kClassicalPartials * 4);
-    const int nblk = classical_blocks(n);
+    const int nblk = classical_blocks(n);       // (dccn_classical_estimate modes 1 / 3 read these partials: dccn.h order contract)
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(classical_gain_kernel, dim3(nblk), dim3(256), 0, s, (const float2*)Y, (const float2*)H, Gls, pil, partial,
                        n, SK, P, make_float2(pv_re, pv_im));

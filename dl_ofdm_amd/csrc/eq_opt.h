@@ -25,6 +25,7 @@ struct EqOptJob {
     const float* src;        // slabs (SUM: nullptr = the gradient arena holds the finished gradient)
     const float* src2;       // folds: column-sum slabs
     long long slab, slab2;   // elements between consecutive slabs of src / src2
+    int vec;                 // SUM: float4 loads of the slabs are legal (slab % 4 == 0, 16-byte aligned base)
     int kin, F;              // CCONV_FOLD: kin, F; CONV2D_FOLD: L, W
 };
 constexpr int kEqOptJobs = 24;
@@ -56,7 +57,7 @@ __device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J
     const long long stride = (long long)J.blocks * 256 * 4;
     for (long long i = ((long long)bx * 256 + threadIdx.x) * 4; i < J.n; i += stride) {
         const long long j = J.off + i;
-        if (i + 4 <= J.n) {                        // (segments start on 16-byte boundaries: eq_dims)
+        if (i + 4 <= J.n && J.vec) {               // (segments start on 16-byte boundaries: eq_dims)
             const float4 p4 = *reinterpret_cast<const float4*>(a.param + j);
             const float4 m4 = *reinterpret_cast<const float4*>(a.m + j);
             const float4 v4 = *reinterpret_cast<const float4*>(a.v + j);
@@ -275,11 +276,13 @@ struct EqOptBuilder {
             }
         }
         EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
-        if (J) { J->off = off; J->n = n; J->splits = 1; }
+        if (J) { J->off = off; J->n = n; J->splits = 1; J->vec = 1; }
     }
     void slabs(long long off, long long n, const float* src, int splits, long long slab) {
         EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
-        if (J) { J->off = off; J->n = n; J->src = src; J->splits = splits; J->slab = slab; }
+        // odd K or K + CP (e.g. CP = 9: a 146-float bias slab) leaves slabs that are not multiples of four floats apart:
+        // those jobs take the element-wise branch
+        if (J) { J->off = off; J->n = n; J->src = src; J->splits = splits; J->slab = slab; J->vec = (slab % 4 == 0 && aligned16(src)) ? 1 : 0; }
     }
     void cconv_fold(long long off, long long off_b, const float* slabs_, const float* colsum, int splits, long long slab,
                     int kin, int F) {

@@ -210,7 +210,11 @@ int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal
  *                            response onto the power-normalised frames and of sum |G_ls|^2; sums4 (nullable, device
  *                            double[4]) = {Re, Im of sum Y_p conj(H_p pv), sum |H_p pv|^2, sum |G_ls|^2}
  *   dccn_classical_estimate  mode 0 LS (planes -> interleaved), 1 ideal per-symbol LMMSE (:353-372), 2 ALMMSE (:437-446),
- *                            3 Perfect, 4 frame mean V [n, K, 2] (input of the PDP variants :399-416); Gls [2][n][S*K]
+ *                            3 Perfect, 4 frame mean V [n, K, 2] (input of the PDP variants :399-416); Gls [2][n][S*K].
+ *                            ORDER CONTRACT: modes 1 and 3 scale H by the gain whose block partials dccn_classical_gain
+ *                            left in the SAME workspace -- call dccn_classical_gain(..., H != NULL, same n, same workspace)
+ *                            on the same stream first; without it the partials are whatever the workspace held and G is
+ *                            garbage (no error can be raised: the partials carry no tag)
  *   dccn_classical_detect    x = Y / G at the data cells, nearest point of table [m, 2], labels [m, nbits]; det (nullable)
  *                            [n, D, nbits]; errors[0] = bit errors against bits [n, D, nbits]; G rows of g_row cells per
  *                            frame, cell index taken modulo g_mod when g_mod > 0 (one estimate row per frame)      */
@@ -503,6 +507,12 @@ typedef struct dccn_eq_buffers {
 size_t dccn_eq_rx_folded_floats(const dccn_eq_shape* shape);
 int dccn_eq_rx_fold(const dccn_eq_shape* shape, const float* rx_params, float* out, dccn_stream_t stream);
 
+/* offsets[i] = first float of tensor i, offsets[20] = ARENA size.  Every tensor starts on a 16-byte boundary: the arena has
+ * up to three floats of PADDING behind a tensor whose element count is not a multiple of four (conv3d_1's two-float bias),
+ * so offsets[i+1] - offsets[i] is NOT the tensor's size and offsets[20] is not the parameter count -- take sizes from the
+ * shapes above.  The padding floats of eq_params, eq_grads, adam_m, adam_v and reg_coef must be ZERO when the arenas are
+ * created (zero gradient and zero Adam state keep them zero): the optimizer launch and the merged element-wise jobs stream
+ * over whole arena segments, padding included. */
 int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets /* [21] */);
 size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train);
 int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream);
