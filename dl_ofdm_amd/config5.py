@@ -72,7 +72,7 @@ def _broadcast(t, src: int, group=None):
 
 def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs: int, rx_epoch_scale: float = 1.0,
                  rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
-                 timing: Optional[dict] = None):
+                 timing: Optional[dict] = None, ckpt_dir: Optional[str] = None):
     """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
     eq_epochs <= 0: the reference driver's cap of 4000 * nbits epochs (run_local_ofdm.py:96; early stopping ends it sooner).
 
@@ -86,7 +86,7 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
     owners = job_owners(nbits_list, world)
     t0, trainers, flags = time.time(), {}, {}
     for nbits in sorted(owners, reverse=True):
-        save = os.path.join(out_dir, "ckpt_r%d/" % rank)
+        save = os.path.join(ckpt_dir or out_dir, "ckpt_r%d/" % rank)      # (~90 MB of best-model archives per rank)
         rf = R.Flags(nbits=nbits, nfilter=64, channel="AWGN", SNR=5.0 * nbits,
                      max_epoch_num=max(1, int(1200 * nbits * rx_epoch_scale)), early_stop=200, token="C5_%dmod" % nbits,
                      save_dir=save, device_data=True, seed=nbits)
@@ -210,7 +210,8 @@ def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: S
 
 def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frames: int = 1500, rx_epoch_scale: float = 1.0,
         nbits_list: Sequence[int] = (1, 2, 3, 4), channels: Sequence[str] = CHANNELS, snrs: Sequence[int] = SNRS,
-        classical_every: int = 3, rank: int = 0, world: int = 1, device="cuda", verbose: bool = True):
+        classical_every: int = 3, rank: int = 0, world: int = 1, device="cuda", verbose: bool = True,
+        ckpt_dir: Optional[str] = None):
     """Train (chains dealt to ranks), sweep (points dealt to ranks), classical curves (units dealt to ranks); rank 0
     writes ``<out_dir>/config5_ber.csv`` and ``config5_timing.json`` (wall time per stage and rank).  Returns
     (points, BER per point)."""
@@ -220,7 +221,7 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     t0 = time.time()
     timing = {}
     trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
-                            timing=timing)
+                            timing=timing, ckpt_dir=ckpt_dir)
     t1 = time.time()
     pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world)
     ber, _ = sweep.ber_loss(table)

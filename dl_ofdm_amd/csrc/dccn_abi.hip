@@ -67,7 +67,9 @@ enum TuneKey : int {
     TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
                                 //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
     TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
-    TUNE_COUNT = 22
+    TUNE_ADAM_NT = 22,          // 1: large arenas: the optimizer launch loads the gradient with non-temporal hints
+    TUNE_DENSE_FWD_BIG = 23,    // > 0: dense + tail variant of LARGE layers (14 / 15: 160x64 tiles, 16: 128x64) instead of 80x64
+    TUNE_COUNT = 24
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -93,7 +95,7 @@ struct TuneTable {
 //   20 = 1  equaliser re-plan: 73 frames 0.319 -> 0.263 ms, 1170 frames 0.570 -> 0.509 ms (tools/eqbench.py --ab 20=0,1,2);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {1}, {0}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -975,6 +977,8 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
 static void dense_tail_tiles(int variant, int& bm, int& bn) {
     bn = 64;
     bm = (variant == 5 || variant == 6) ? 64 : ((variant == 7 || variant == 8) ? 32 : (variant == 13 ? 80 : 48));
+    if (variant == 14 || variant == 15) bm = 160;
+    if (variant == 16) bm = 128;
 }
 static int dense_tail_max_blocks(int M, int N) { return ceil_div(M, 32) * ceil_div(N, 64); }
 static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
@@ -1016,6 +1020,10 @@ static int dense_tail_launch(int variant, const GemmParams& p, const TailEpiPara
         case 8: return launch_dense_tail16<1, 4, 2, 1, 64, 2, NB, BWD>(p, tp, s, sm);
         case 9: return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);  // 48x64, loads two k-tiles ahead
         case 13: return launch_dense_tail16<1, 4, 5, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);    // 80x64 (large layers)
+        // large layers, two resident blocks per CU in ONE round: 585 rows = 4 row tiles of 160 x 125 column tiles = 500 blocks
+        case 14: return launch_dense_tail16<1, 4, 10, 1, 32, 1, NB, BWD, 2>(p, tp, s, sm);   // 160x64, 32-deep k-tiles
+        case 15: return launch_dense_tail16<1, 4, 10, 1, 32, 1, NB, BWD, 1>(p, tp, s, sm);
+        case 16: return launch_dense_tail16<1, 4, 8, 1, 32, 1, NB, BWD, 2>(p, tp, s, sm);    // 128x64
         default: return DCCN_ERR_INVALID_ARG;
     }
 }
@@ -1042,6 +1050,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     // large layers (several rounds of 48x64 tiles): 80x64 tiles re-use the B tile for five row blocks instead of three
     // (C4: 1.42 -> 1.34 ms); the lane's ten cells go through the tail in two batches of five
     if (variant == 9 && (long long)ceil_div(M, 48) * ceil_div(N, 64) >= 4LL * kCUs) variant = 13;
+    if (g_tune[TUNE_DENSE_FWD_BIG] && variant == 13 && nbits <= 2) variant = g_tune[TUNE_DENSE_FWD_BIG];
     if (nbits >= 3 && variant != 13) variant = 9;
     int bm, bn;
     dense_tail_tiles(variant, bm, bn);
@@ -1299,6 +1308,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.kin = sh->kin; aa.F = sh->F; aa.o_cw = L.o_conv_w; aa.cw_tilew = fd.slabs ? fold_tilew : 0;
     aa.n_conv = L.o_dense_w;                      // C-Conv kernel + bias come first in the arena
     aa.skip_lo = aa.skip_hi = 0;
+    aa.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
+    // large arenas (N = 1024: 0.47 GB of gradient, far beyond the 256 MB Infinity Cache) are pure streams
+    aa.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
     if (ds.adam_done) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
     aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, fold_tilew > 0 ? kFoldLanesTiled : kRedLanes) : 0;
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);

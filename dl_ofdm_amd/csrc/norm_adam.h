@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ par
 // ---- R7 fused into the receiver step: one launch does the split-K reduction of the dense weight
 // gradient and the Adam update over the whole arena.  alpha comes from the optimizer state, which the
 // first kernel of the step (moments_kernel) has already advanced. ----
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
 struct AdamRxArgs {
     float* param; float* grad; float* m; float* v;
     const float* reg_coef; const float* reg_gate;
@@ -470,6 +471,8 @@ struct AdamRxArgs {
     // [skip_lo, skip_hi): elements whose update already happened in the epilogue of their weight-gradient GEMM
     long long skip_lo, skip_hi;
     unsigned long long* stamp;             // step timeline stamps (common.h stamp_mark), nullptr = none
+    int reg_uniform_dw;                    // reg_coef is one value over [o_dw, o_dw + n_dw): read once, not streamed
+    int nt;                                // streaming hints: the gradient is loaded non-temporal (read exactly once)
 };
 
 // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here.
@@ -554,6 +557,8 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
     const float gate = a.reg_gate ? a.reg_gate[0] : 1.0f;
     const float omb1 = 1.0f - hp.beta1, omb2 = 1.0f - hp.beta2;
     const bool seg4 = ((a.o_dw | a.n_dw | a.o_db | a.n_db) & 3) == 0;
+    const bool uni = a.reg_uniform_dw != 0 && a.reg_coef != nullptr && seg4;
+    const float cdw = uni ? a.reg_coef[a.o_dw] : 0.f;          // (uniform address: one scalar load)
     const int splits = SPLITS > 0 ? SPLITS : a.splits;
     const long long first = a.fold_blocks > 0 ? a.n_conv : 0;
     const long long stride = (long long)nbx * blockDim.x * 4;
@@ -568,7 +573,8 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
             p4 = *reinterpret_cast<const float4*>(a.param + i);
             m4 = *reinterpret_cast<const float4*>(a.m + i);
             v4 = *reinterpret_cast<const float4*>(a.v + i);
-            if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + i);
+            if (uni && i >= a.o_dw && i < a.o_dw + a.n_dw) c4 = make_float4(cdw, cdw, cdw, cdw);
+            else if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + i);
         }
         // ---- gradient: plain arena, or the fixed-order sum of the split-K slabs ----
         if (full && seg4 && a.dw_slabs && i >= a.o_dw && i < a.o_dw + a.n_dw) {
@@ -591,7 +597,13 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
             *reinterpret_cast<float4*>(a.grad + i) = s;
         } else if (full && !(a.dw_slabs && i < a.o_dw + a.n_dw && i + 4 > a.o_dw) &&
                    !(a.db_slabs && i < a.o_db + a.n_db && i + 4 > a.o_db)) {
-            const float4 s = *reinterpret_cast<const float4*>(a.grad + i);
+            float4 s;
+            if (a.nt) {
+                const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.grad + i));
+                s = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+                s = *reinterpret_cast<const float4*>(a.grad + i);
+            }
             g[0] = s.x; g[1] = s.y; g[2] = s.z; g[3] = s.w;
         } else {
             for (int e = 0; e < cnt; ++e) {

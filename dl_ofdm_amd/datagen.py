@@ -43,6 +43,12 @@ class DeviceDataGen:
         self.n_sc, self.T = o.K + o.CP, o.nSymbol * (o.K + o.CP)
         self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
         self.want_noise_power = True
+        # extension (not in the reference): receiver-side timing alignment.  radio.py filters with np.convolve(.., 'same'), i.e.
+        # the L-tap response is centred and the received frame arrives (L-1)//2 samples EARLY: the FFT window of the reference
+        # then catches the head of the next symbol (inter-symbol interference the cyclic prefix cannot absorb; the high-SNR
+        # floor of profiles/r02_ber_floor).  align_window delays every generated frame by that advance (single-profile
+        # channels), which is what a receiver with timing synchronisation sees.
+        self.align_window = bool(getattr(FLAGS, "align_window", False))
         dev = self.device
         cell = np.full(self.S * self.K, -2, dtype=np.int32)
         cell[o.dataSc] = np.arange(self.D, dtype=np.int32)
@@ -181,13 +187,21 @@ class DeviceDataGen:
                                                      self._p(snr_t), self._p(noise), self._p(out_x), self._p(H),
                                                      self.K, npw, n, self.seed, off, self._p(w["ws"]),
                                                      w["nws"], self._stream()), "dccn_channel_doppler_awgn")
+            self._align(out_x)
             return out_x, npw_t, (torch.view_as_complex(H) if want_H else None)
         check(self.lib.dccn_channel_awgn(self._p(tx), self._p(taps), self._p(self.coeff), self._p(self.alpha),
                                          self.n_taps, self.L, 1 if self.identity else 0, self._p(snr_t),
                                          self._p(noise), self._p(out_x), self._p(H), self.K, npw, n,
                                          self.T, self.seed, off, self._p(w["ws"]), w["nws"], self._stream()),
               "dccn_channel_awgn")
+        self._align(out_x)
         return out_x, npw_t, (torch.view_as_complex(H) if want_H else None)
+
+    def _align(self, out_x: torch.Tensor):
+        adv = (self.L - 1) // 2 if (self.align_window and not self.mixed and not self.identity) else 0
+        if adv > 0:
+            flat = out_x.view(out_x.shape[0], self.T, 2)
+            out_x.copy_(torch.roll(flat, adv, dims=1).view_as(out_x))
 
     def frame_plan(self, n: int):
         """per frame (profile index, doppler?) exactly as radio.py:438-452 decides it"""

@@ -61,6 +61,7 @@ class Flags:
     snr_lo: int = -10
     snr_hi: int = 30                # inclusive (:72)
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py) instead of NumPy
+    align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
     tf_checkpoint: bool = False     # also write <save_dir>/<token>.index/.data-00000-of-00001 (tf.train.Saver format)
     iq_dump: bool = False           # per-epoch <token>_txiq.csv / _rxiq.csv constellation dumps (ofdmreceiver_np.py:264-265),
     #                                 written into save_dir; off by default: two syncs + two files per epoch

@@ -73,6 +73,7 @@ class Flags:
     snr_hi: int = 30
     snr_step: int = 5               # :81
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py)
+    align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 

@@ -345,6 +345,10 @@ typedef struct dccn_rx_buffers {
     /* Large layers (dccn_get_tuning(16), N = 1024): the dense kernel's optimizer update runs in the epilogue of its
        weight-gradient tiles and its gradient is not written to `grads` unless keep_dense_grad != 0. */
     int keep_dense_grad;
+    /* reg_coef holds ONE value over the whole dense-kernel segment (what the reference's keras l2(0.01) regulariser gives:
+       dev/py/model.py:1271-1272): the optimizer then reads that value once instead of streaming a parameter-sized array
+       (12 % of the optimizer launch's traffic at N = 1024).  0 = per-element coefficients everywhere (the general form). */
+    int reg_uniform_dense;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);

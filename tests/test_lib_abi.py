@@ -39,8 +39,8 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.AdamState) == 16
     assert C.sizeof(_lib.AdamHParams) == 24
     assert C.sizeof(_lib.RxShape) == 24
-    # 18 pointers/sizes + x_next + x_prenormalised (padded) + x_norm_next + norm_slot + keep_dense_grad
-    assert C.sizeof(_lib.RxBuffers) == 22 * 8
+    # 18 pointers/sizes + x_next + x_prenormalised (padded) + x_norm_next + (norm_slot, keep_dense_grad) + reg_uniform_dense (padded)
+    assert C.sizeof(_lib.RxBuffers) == 23 * 8
 
 
 def test_host_side_queries(lib):

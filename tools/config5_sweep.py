@@ -18,12 +18,15 @@ def main():
     ap.add_argument("--eq_epochs", type=int, default=600, help="<= 0: the reference's 4000 * nbits cap")
     ap.add_argument("--rx_epoch_scale", type=float, default=1.0)
     ap.add_argument("--classical_frames", type=int, default=1500)
+    ap.add_argument("--ckpt_dir", default="", help="where the best-model checkpoints go (default: a temporary directory; they are "
+                                                   "~90 MB per rank and would push a gpurun_out/ result directory over its 64 MiB limit)")
     ap.add_argument("--backend", default=None, help="nccl (default; RCCL over xGMI) or gloo; also DCCN_DIST_BACKEND")
     a = ap.parse_args()
     import torch
     rank, world, local = config5.init_distributed(a.backend)
+    import tempfile
     config5.run(a.out, a.frames, a.eq_epochs, a.classical_frames, a.rx_epoch_scale, rank=rank, world=world,
-                device="cuda:%d" % local)
+                device="cuda:%d" % local, ckpt_dir=a.ckpt_dir or tempfile.mkdtemp(prefix="dccn_c5_"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
