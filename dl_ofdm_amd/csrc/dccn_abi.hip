@@ -95,7 +95,10 @@ struct TuneTable {
 //   20 = 1  equaliser re-plan: 73 frames 0.319 -> 0.263 ms, 1170 frames 0.570 -> 0.509 ms (tools/eqbench.py --ab 20=0,1,2);
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {1}, {0}}};
+//   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
+//   22 = 0  non-temporal gradient loads in the optimizer launch of large arenas: C4 step 4933 vs 4898 us -- slower, off;
+//   23 = 0  160x64 / 128x64 tiles for the fused dense + tail launch of large layers: C4 step 5012 / 5423 vs 4933 us with 80x64 -- off.
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot

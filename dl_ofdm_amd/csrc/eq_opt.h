@@ -26,6 +26,8 @@ struct EqOptJob {
     const float* src2;       // folds: column-sum slabs
     long long slab, slab2;   // elements between consecutive slabs of src / src2
     int vec;                 // SUM: float4 loads of the slabs are legal (slab % 4 == 0, 16-byte aligned base)
+    int reg_uniform;         // SUM: reg_coef holds one value over the job's segment (a dense kernel or bias: keras l2(0.01) on
+                             // every element, model.py:371-462; a C-Conv kernel: zero) -- read once instead of streamed
     int kin, F;              // CCONV_FOLD: kin, F; CONV2D_FOLD: L, W
 };
 constexpr int kEqOptJobs = 24;
@@ -55,6 +57,7 @@ __device__ __forceinline__ void eq_adam_one(const EqOptArgs& a, const AdamCoef& 
 
 __device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
     const long long stride = (long long)J.blocks * 256 * 4;
+    const float creg = (J.reg_uniform && a.reg_coef) ? a.reg_coef[J.off] : 0.f;      // (uniform address: one scalar load)
     for (long long i = ((long long)bx * 256 + threadIdx.x) * 4; i < J.n; i += stride) {
         const long long j = J.off + i;
         if (i + 4 <= J.n && J.vec) {               // (segments start on 16-byte boundaries: eq_dims)
@@ -62,7 +65,8 @@ __device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J
             const float4 m4 = *reinterpret_cast<const float4*>(a.m + j);
             const float4 v4 = *reinterpret_cast<const float4*>(a.v + j);
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + j);
+            if (J.reg_uniform) c4 = make_float4(creg, creg, creg, creg);
+            else if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + j);
             float4 g4;
             if (J.src) {
                 // the summation order of splitk_reduce_body (four interleaved runs, then 0+1+2+3): the step's gradients
@@ -191,6 +195,26 @@ __device__ __forceinline__ void eq_opt_conv2d(const EqOptArgs& a, const EqOptJob
     }
     const int ta = tap / W, tb = tap % W;
     float ga = 0.f, gb = 0.f;
+    if (J.splits == 1 && L * W <= 8 * 64) {
+        // the usual case (one finished dT): a lane's <= 8 cells x 4 gathers are requested together -- one memory latency
+        // instead of eight dependent ones on the long pole of the optimizer launch; same order of additions
+        float v[8][4];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = lane + 64 * u;
+            const int cc = min(c, L * W - 1);
+            const int s = cc / W, kk = cc % W;
+            const int sp = s + ta - padL, kp = kk + tb - padW;
+            ok[u] = c < L * W && sp >= 0 && sp < L && kp >= 0 && kp < W;
+            const size_t r0 = ok[u] ? (size_t)((sp * W + kp) * 2) * n + (size_t)cc * 2 : 0;
+            v[u][0] = J.src[r0]; v[u][1] = J.src[r0 + n + 1]; v[u][2] = J.src[r0 + 1]; v[u][3] = J.src[r0 + n];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ok[u]) { ga += v[u][0] - v[u][1]; gb += v[u][2] - v[u][3]; }
+        }
+    } else
     for (int c = lane; c < L * W; c += 64) {
         const int s = c / W, kk = c % W;
         const int sp = s + ta - padL, kp = kk + tb - padW;
@@ -260,14 +284,18 @@ struct EqOptBuilder {
     }
     static int stream_blocks(long long n) {
         long long b = ceil_div_ll(ceil_div_ll(n, 4), 256);
-        if (b > 2 * kCUs) b = 2 * kCUs;
+        if (b > 8 * kCUs) b = 8 * kCUs;             // (one float4 per thread up to 2 M elements: no dependent second round)
         return (int)(b < 1 ? 1 : b);
     }
     // [off, off+n): finished gradient in the arena (adjacent segments merge into one job)
-    void plain(long long off, long long n) {
+    // uniform: reg_coef is one value over [off, off + n) (see EqOptJob::reg_uniform); merged segments must agree on it AND
+    // on the value, which only the caller knows: kernel + bias of one layer share their coefficient, different layers' values
+    // are equal in this model, so segments merge when both are uniform (or both are not)
+    void plain(long long off, long long n, bool uniform = false) {
         if (a.njobs > 0) {
             EqOptJob& P = a.job[a.njobs - 1];
-            if (P.kind == EQJ_SUM && P.src == nullptr && P.off + P.n <= off && off - (P.off + P.n) < 4) {
+            if (P.kind == EQJ_SUM && P.src == nullptr && P.off + P.n <= off && off - (P.off + P.n) < 4 &&
+                (P.reg_uniform != 0) == uniform && !uniform) {
                 blocks -= P.blocks;                     // (the gap is alignment padding: zero gradient, zero state)
                 P.n = off + n - P.off;
                 P.blocks = stream_blocks(P.n);
@@ -276,13 +304,17 @@ struct EqOptBuilder {
             }
         }
         EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
-        if (J) { J->off = off; J->n = n; J->splits = 1; J->vec = 1; }
+        if (J) { J->off = off; J->n = n; J->splits = 1; J->vec = 1; J->reg_uniform = uniform ? 1 : 0; }
     }
-    void slabs(long long off, long long n, const float* src, int splits, long long slab) {
+    void slabs(long long off, long long n, const float* src, int splits, long long slab, bool uniform = false) {
         EqOptJob* J = add(EQJ_SUM, stream_blocks(n));
         // odd K or K + CP (e.g. CP = 9: a 146-float bias slab) leaves slabs that are not multiples of four floats apart:
         // those jobs take the element-wise branch
-        if (J) { J->off = off; J->n = n; J->src = src; J->splits = splits; J->slab = slab; J->vec = (slab % 4 == 0 && aligned16(src)) ? 1 : 0; }
+        if (J) {
+            J->off = off; J->n = n; J->src = src; J->splits = splits; J->slab = slab;
+            J->vec = (slab % 4 == 0 && aligned16(src)) ? 1 : 0;
+            J->reg_uniform = uniform ? 1 : 0;
+        }
     }
     void cconv_fold(long long off, long long off_b, const float* slabs_, const float* colsum, int splits, long long slab,
                     int kin, int F) {

@@ -154,11 +154,12 @@ static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, 
 }
 
 // optimizer jobs of a dense layer (kernel variable i, bias variable i + 1)
-static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const DeferredSlabs& ds, long long N) {
-    if (ds.dw_slabs) ob.slabs(d.o[i], d.sz[i], ds.dw_slabs, ds.splits, d.sz[i]);
-    else ob.plain(d.o[i], d.sz[i]);
-    if (ds.dw_slabs && ds.db_slabs) ob.slabs(d.o[i + 1], d.sz[i + 1], ds.db_slabs, ds.splits, N);
-    else ob.plain(d.o[i + 1], d.sz[i + 1]);
+// (uni: the caller's reg_coef is one value over each dense kernel / bias -- dccn_eq_buffers.reg_uniform)
+static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const DeferredSlabs& ds, long long N, bool uni) {
+    if (ds.dw_slabs) ob.slabs(d.o[i], d.sz[i], ds.dw_slabs, ds.splits, d.sz[i], uni);
+    else ob.plain(d.o[i], d.sz[i], uni);
+    if (ds.dw_slabs && ds.db_slabs) ob.slabs(d.o[i + 1], d.sz[i + 1], ds.db_slabs, ds.splits, N, uni);
+    else ob.plain(d.o[i + 1], d.sz[i + 1], uni);
 }
 
 static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool train, dccn_adam_hparams hp,
@@ -424,20 +425,21 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     memset(&ob.a, 0, sizeof(ob.a));
     ob.a.param = b->eq_params; ob.a.grad = G; ob.a.m = b->adam_m; ob.a.v = b->adam_v; ob.a.reg_coef = b->reg_coef;
     ob.a.state = b->adam;
-    eq_opt_dense(ob, d, 0, ds0, K2);
+    const bool uni = b->reg_uniform != 0 && b->reg_coef != nullptr;
+    eq_opt_dense(ob, d, 0, ds0, K2, uni);
     if (fconv.slabs) ob.cconv_fold(d.o[2], d.o[3], fconv.slabs, fconv.colsum, fconv.splits, fconv.slab, K, K);
     else { ob.plain(d.o[2], d.sz[2]); ob.plain(d.o[3], d.sz[3]); }
     if (bn) {
-        ob.slabs(d.o[4], d.sz[4], bn_w1, bn_tiles, (long long)SK2 * d.Pp);
-        ob.slabs(d.o[5], d.sz[5], bn_b1, bn_tiles, d.Pp);
-        ob.slabs(d.o[6], d.sz[6], bn_w2, bn_tiles, (long long)d.Pp * SK2);
-        ob.slabs(d.o[7], d.sz[7], bn_b2, bn_tiles, SK2);
+        ob.slabs(d.o[4], d.sz[4], bn_w1, bn_tiles, (long long)SK2 * d.Pp, uni);
+        ob.slabs(d.o[5], d.sz[5], bn_b1, bn_tiles, d.Pp, uni);
+        ob.slabs(d.o[6], d.sz[6], bn_w2, bn_tiles, (long long)d.Pp * SK2, uni);
+        ob.slabs(d.o[7], d.sz[7], bn_b2, bn_tiles, SK2, uni);
     } else {
-        eq_opt_dense(ob, d, 4, ds1, d.Pp);
-        eq_opt_dense(ob, d, 6, ds2, SK2);
+        eq_opt_dense(ob, d, 4, ds1, d.Pp, uni);
+        eq_opt_dense(ob, d, 6, ds2, SK2, uni);
     }
-    eq_opt_dense(ob, d, 8, ds3, SK2);
-    eq_opt_dense(ob, d, 10, ds4, SK2);
+    eq_opt_dense(ob, d, 8, ds3, SK2, uni);
+    eq_opt_dense(ob, d, 10, ds4, SK2, uni);
     ob.conv2d_fold(d.o[12], d.o[13], dsT.dw_slabs ? dsT.dw_slabs : w.dT, (dsT.dw_slabs && dsT.db_slabs) ? dsT.db_slabs : w.dbe,
                    dsT.dw_slabs ? dsT.splits : 1, (long long)SK2 * SK2, SK2, d.S, K);
     for (int g = 1; g >= 0; --g) {          // arena order: conv3d_2 (corr, group 1), then conv3d_3 (eq, group 0)
@@ -445,7 +447,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         if (fpair[g].slabs) ob.cconv_fold(d.o[i], d.o[i + 1], fpair[g].slabs, fpair[g].colsum, fpair[g].splits, fpair[g].slab, K, K);
         else { ob.plain(d.o[i], d.sz[i]); ob.plain(d.o[i + 1], d.sz[i + 1]); }
     }
-    eq_opt_dense(ob, d, 18, ds5, N2);
+    eq_opt_dense(ob, d, 18, ds5, N2, uni);
     if (fin_deferred) ob.tail_finalize(fin);
     if (snr_pending) ob.pilot_snr(w.eq, b->pilot_carriers, b->snr_db, B, d.S, K, sh->P);
     return launch_eq_opt(ob, hp, s);

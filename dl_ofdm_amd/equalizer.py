@@ -58,7 +58,7 @@ class _FusedPlan:
         self.buffers = EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
                                  p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
                                  p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
-                                 p(self.ws), nws, p(tr.rx_folded(self.shape)))
+                                 p(self.ws), nws, 1, p(tr.rx_folded(self.shape)))        # reg_uniform: _flatten() fills one value per dense tensor
         self.graphs: Dict[int, C.c_void_p] = {}
 
     def _stream(self):

@@ -500,6 +500,10 @@ typedef struct dccn_eq_buffers {
     float* tx_power;              /* device float[1], nullable */
     void* workspace;
     size_t workspace_bytes;
+    int reg_uniform;              /* 1: reg_coef holds ONE value over each dense kernel / bias tensor (keras l2(0.01) on every dense
+                                     layer, model.py:371-462) and is not consulted for the C-Conv tensors' segments other than
+                                     element-wise: the optimizer launch reads one coefficient per dense tensor instead of
+                                     streaming a parameter-sized array.  0: per-element coefficients everywhere. */
     const float* rx_folded;       /* nullable: dccn_eq_rx_fold(rx_params) -- the frozen receiver's C-Conv and dense layer as one
                                      matrix.  When given, few-row batches (<= 96 frames) run ONE GEMM where the step ran the two
                                      layers (and one on the way back); must be rebuilt whenever rx_params change. */

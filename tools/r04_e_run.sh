@@ -1,5 +1,5 @@
 set -x
-O=gpurun_out/r04g; mkdir -p $O
+O=gpurun_out/r04l; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_equalizer.py tests/test_gpu_ops.py -x -q -m gpu 2>&1 | tail -8 > $O/pytest_eq.txt
 timeout 300 python tools/eqbench.py --frames 73 --ab 21=0,1 --rounds 5 > $O/eqbench_ab.txt 2>&1
 timeout 300 python tools/eqbench.py --frames 73 1170 --paths fused-graph fused-eager > $O/eqbench.jsonl 2>$O/eqbench.err
