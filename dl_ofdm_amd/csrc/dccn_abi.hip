@@ -983,7 +983,12 @@ static void dense_tail_tiles(int variant, int& bm, int& bn) {
     if (variant == 14 || variant == 15) bm = 160;
     if (variant == 16) bm = 128;
 }
-static int dense_tail_max_blocks(int M, int N) { return ceil_div(M, 32) * ceil_div(N, 64); }
+static int dense_tail_max_blocks(int M, int N) {
+    const int b = ceil_div(M, 32) * ceil_div(N, 64);
+    // few rows: the one-latency 16x16 tiles of fewrow.h carry the tail as well (one slab per tile)
+    const int few = (M <= 96 && (N % 16) == 0) ? ceil_div(M, 16) * (N / 16) : 0;
+    return few > b && few <= kTailBlocksMax ? few : b;
+}
 static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
     const size_t nb = (size_t)dense_tail_max_blocks(M, N);
     size_t o = 0;
@@ -1071,8 +1076,14 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     TailEpiParams tp;
     tp.bits = bits; tp.tailp = tailp; tp.prob = prob; tp.dz = dz; tp.blk_metrics = bmx; tp.blk_grads = bg;
     tp.inv_count = 1.0f / (float)(cells * nbits);
+    // few rows, BPSK / QPSK: every operand of a 16x16 tile requested at once, the tail on the tile's own registers (fewrow.h)
+    const int few_tiles = ceil_div(M, 16) * (N / 16);
+    const bool few = g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && nbits <= 2 && M <= 96 && fewrow_ng_c(p, false) >= 10 &&
+                     few_tiles <= kTailBlocksMax && few_tiles <= dense_tail_max_blocks(M, N);
     int st;
-    if (nbits == 1) st = bwd ? dense_tail_launch<1, true>(variant, p, tp, s) : dense_tail_launch<1, false>(variant, p, tp, s);
+    if (few && nbits == 1) st = bwd ? launch_fewrow_tail<1, true>(p, tp, s) : launch_fewrow_tail<1, false>(p, tp, s);
+    else if (few && nbits == 2) st = bwd ? launch_fewrow_tail<2, true>(p, tp, s) : launch_fewrow_tail<2, false>(p, tp, s);
+    else if (nbits == 1) st = bwd ? dense_tail_launch<1, true>(variant, p, tp, s) : dense_tail_launch<1, false>(variant, p, tp, s);
     else if (nbits == 2) st = bwd ? dense_tail_launch<2, true>(variant, p, tp, s) : dense_tail_launch<2, false>(variant, p, tp, s);
     else if (nbits == 3) st = bwd ? dense_tail_hi_launch<3, true>(variant, p, tp, s) : dense_tail_hi_launch<3, false>(variant, p, tp, s);
     else st = bwd ? dense_tail_hi_launch<4, true>(variant, p, tp, s) : dense_tail_hi_launch<4, false>(variant, p, tp, s);
@@ -1080,7 +1091,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     const int P = bwd ? tail_param_count(nbits) : 0;
     const bool pw = pp != nullptr && power_out != nullptr;
     TailFinalizeArgs fa;
-    fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
+    fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = few ? few_tiles : nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
     fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;

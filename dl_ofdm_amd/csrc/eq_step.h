@@ -297,11 +297,18 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     if (!folded) DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
     TailFinalizeArgs fin;
     bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
-    if (!few_rx && dense_tail_planned(sh->nbits, train, B, L.dN) &&
-        dense_tail_ok(w.fft, Q + L.o_dense_w, B, L.dK, L.dN, sh->nbits)) {       // dense + tail in one launch
+    // the receiver's linear part as this step runs it: (input rows, weights, bias, k extent)
+    const float* rxA = folded ? b->out_eq : w.fft;
+    const float* rxW = folded ? Mf : Q + L.o_dense_w;
+    const float* rxb = folded ? Mf + (size_t)fK * L.dN : Q + L.o_dense_b;
+    const int rxK = folded ? fK : L.dK;
+    // BPSK / QPSK: the tail rides on the few-row tiles themselves (dense_tail_impl picks the fewrow.h form for <= 96 rows)
+    const bool few_tail = few_rx && sh->nbits <= 2 && dense_tail_ok(rxA, rxW, B, rxK, L.dN, sh->nbits);
+    if ((few_tail || !few_rx) && dense_tail_planned(sh->nbits, train, B, L.dN) &&
+        dense_tail_ok(rxA, rxW, B, rxK, L.dN, sh->nbits)) {                      // dense + tail in one launch
         fin_deferred = replan && train;
-        DCCN_TRY(dense_tail_impl(train, w.fft, Q + L.o_dense_w, Q + L.o_dense_b, nullptr, b->bits, Q + L.o_tail, b->prob,
-                                 b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, L.dK, L.dN, sh->nbits,
+        DCCN_TRY(dense_tail_impl(train, rxA, rxW, rxb, nullptr, b->bits, Q + L.o_tail, b->prob,
+                                 b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, rxK, L.dN, sh->nbits,
                                  &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? &fin : nullptr));
     } else {
         fin_deferred = replan && train;     // (the tail's metric reduction rides on the optimizer launch either way)

@@ -109,6 +109,87 @@ __device__ __forceinline__ void fewrow_tile(const GemmParams& p, const int L, co
     }
 }
 
+// The same tile with the demodulation tail (R3-R6 forward, and backward to dz when BWD) behind it, for NB <= 2
+// (dev/py/model.py:1278-1291 on the frozen receiver of the equaliser step): after the k quarters have met, wave w holds
+// row 4 kq + w of the tile, lanes 2d / 2d+1 its columns 2d (I) and 2d+1 (Q) of data cell d -- the pair swaps halves on the
+// DPP crossbar and the EVEN lane runs the cell (tail.h tail_cells, one cell per lane), the odd lane contributes nothing.
+// Per-block metric / tail-gradient slabs as the fused gemm16 launch leaves them (slab = the block's index).
+template <int NG, int NB, bool BWD>
+__device__ __forceinline__ void fewrow_tail_tile(const GemmParams& p, const TailEpiParams& tp, const int L, const int T) {
+    static_assert(NB == 1 || NB == 2, "register tail: BPSK / QPSK");
+    __shared__ float xch[4][4][64];
+    __shared__ __attribute__((aligned(8))) float red[tail_reduce_lds_floats<NB, BWD>(256)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int ntm = (p.M + 15) >> 4;
+    int tile;
+    {
+        const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int n0 = (tile / ntm) * 16, m0 = (tile % ntm) * 16;
+    const int row = min(m0 + c, p.M - 1);
+    const int G = p.K >> 4;
+    float4 a[NG], b[NG];
+    const float* Ap = p.A + (size_t)row * p.lda + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int g = w + 4 * i;
+        const float4 t = *reinterpret_cast<const float4*>(Ap + 16 * min(g, G - 1));
+        a[i] = g < G ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* Bp = p.B + (size_t)(4 * kq) * p.ldb + n0 + c;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const float* q = Bp + (size_t)(16 * min(w + 4 * i, G - 1)) * p.ldb;
+        b[i].x = q[0];
+        b[i].y = q[(size_t)p.ldb];
+        b[i].z = q[(size_t)2 * p.ldb];
+        b[i].w = q[(size_t)3 * p.ldb];
+    }
+    // this lane's cell: row orow, data cell (n0 + c) / 2 (even lanes run it); its labels and bias are requested now
+    const int orow = m0 + 4 * kq + w, ocol = n0 + c;
+    const int Dn = p.N >> 1;
+    const bool live = orow < p.M && (c & 1) == 0;
+    const long long cell = (long long)min(orow, p.M - 1) * Dn + (ocol >> 1);
+    int lab[1][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) lab[0][j] = tp.bits[cell * NB + j];
+    const float bj = p.bias != nullptr ? p.bias[ocol] : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xch[w][r][lane] = acc[r];
+    __syncthreads();
+    const float o = (((xch[0][w][lane] + xch[1][w][lane]) + xch[2][w][lane]) + xch[3][w][lane]) + bj;
+    if (p.C != nullptr && orow < p.M) p.C[(size_t)orow * p.ldc + ocol] = o;          // z, when the caller wants it
+    const float partner = __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, o), 0));      // quad_perm [1,0,3,2]
+    const float z0[1] = {o}, z1[1] = {partner};
+    const bool vd[1] = {live};
+    float* const pc[1] = {(tp.prob != nullptr && live) ? tp.prob + cell * NB * 2 : nullptr};
+    float2 dv[1];
+    TailLaneAcc<NB, BWD> A;
+    A.clear();
+    tail_cells<NB, BWD, 1>(z0, z1, lab, vd, tp.tailp, tp.inv_count, pc, A, dv);
+    if constexpr (BWD) {
+        if (live) *reinterpret_cast<float2*>(tp.dz + cell * 2) = dv[0];
+    }
+    tail_block_reduce<NB, BWD, 256>(A, red, tp.blk_metrics, tp.blk_grads, L);
+}
+
+template <int NG, int NB, bool BWD>
+__global__ __launch_bounds__(256) void fewrow_tail_kernel(const GemmParams p, const TailEpiParams tp) {
+    stamp_mark(p.stamp, 0);
+    fewrow_tail_tile<NG, NB, BWD>(p, tp, (int)blockIdx.x, (int)gridDim.x);
+    stamp_mark(p.stamp, 1);
+}
+
 template <int BKIND, int NG, int NB, int TAG>
 __global__ __launch_bounds__(256) void fewrow_kernel(const GemmParams p) {
     stamp_mark(p.stamp, 0);
@@ -244,8 +325,11 @@ __global__ __launch_bounds__(256) void dense_bwd_fewrow_kernel(const GemmParams 
 // shapes the kernel takes: vector-legal operands, 16-column strips, K a multiple of 16 up to 1152; few rows (<= 96), or a
 // short k range (<= 256) on at most 640 tiles (the equaliser's [511, 160] . [160, 128] and [511, 256] . [256, 160] layers).
 // Returns the instantiated depth (k-group slots per wave) that covers K, 0 = not taken.
-static inline int fewrow_ng(const GemmParams& p) {
-    if (p.M < 1 || (p.N % 16) != 0 || (p.K % 16) != 0 || !p.vecA || !p.vecB || p.C == nullptr) return 0;
+static inline int fewrow_ng_c(const GemmParams& p, bool need_c);
+static inline int fewrow_ng(const GemmParams& p) { return fewrow_ng_c(p, true); }
+// need_c = false: the fused dense + tail form, whose output z is optional
+static inline int fewrow_ng_c(const GemmParams& p, bool need_c) {
+    if (p.M < 1 || (p.N % 16) != 0 || (p.K % 16) != 0 || !p.vecA || !p.vecB || (need_c && p.C == nullptr)) return 0;
     if ((p.lda % 4) != 0 || (p.ldb % 4) != 0 || p.K < 128 || p.K > 1152) return 0;
     const long long tiles = (long long)ceil_div(p.M, 16) * (p.N / 16);
     if (!(p.M <= 96 || (p.K <= 256 && tiles <= 640))) return 0;
@@ -266,6 +350,20 @@ static int launch_fewrow(const GemmParams& p, hipStream_t s) {
         case 10: hipLaunchKernelGGL((fewrow_kernel<BKIND, 10, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
         case 4: hipLaunchKernelGGL((fewrow_kernel<BKIND, 4, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
         case 3: hipLaunchKernelGGL((fewrow_kernel<BKIND, 3, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        default: return DCCN_ERR_INVALID_ARG;
+    }
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
+// dense forward + tail of a few-row batch in one launch (NB <= 2); blocks = tiles <= kTailBlocksMax slabs
+template <int NB, bool BWD>
+static int launch_fewrow_tail(const GemmParams& p, const TailEpiParams& tp, hipStream_t s) {
+    const int T = ceil_div(p.M, 16) * (p.N / 16);
+    switch (fewrow_ng_c(p, false)) {
+        case 18: hipLaunchKernelGGL((fewrow_tail_kernel<18, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
+        case 14: hipLaunchKernelGGL((fewrow_tail_kernel<14, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
+        case 10: hipLaunchKernelGGL((fewrow_tail_kernel<10, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
         default: return DCCN_ERR_INVALID_ARG;
     }
     DCCN_LAUNCH_CHECK();
