@@ -524,6 +524,7 @@ def main():
             from dl_ofdm_amd.steptrace import trace_steps
             t1 = HipTimer()
             bd = trace_steps(step, dev, ring=16, bursts=14)
+            prewarm(step, dev, 0.3)
             t1.start(eng._stream())
             for _ in range(200):
                 step()

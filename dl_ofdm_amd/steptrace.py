@@ -131,10 +131,12 @@ def summarise(bursts: List[List[Dict[int, dict]]]) -> dict:
     return out
 
 
-def trace_steps(step_fn, device="cuda", ring: int = 16, bursts: int = 14, lead: int = 8,
+def trace_steps(step_fn, device="cuda", ring: int = 16, bursts: int = 14, lead: int = 500,
                 trace: Optional[StepTrace] = None) -> dict:
     """Run `bursts` bursts of lead + ring calls of `step_fn` with the timeline on; every burst contributes its last `ring`
-    steps (the queue is `lead` steps deep by then: steady state), so bursts * (ring - 1) step periods are sampled."""
+    steps, so bursts * (ring - 1) step periods are sampled.  `lead` steps run first in every burst: reading a burst's stamps
+    back leaves the GPU idle for milliseconds, after which it restarts ~10 % below its sustained clock and needs tens of
+    milliseconds of work to recover (profiles/r04_gap.md) -- 500 C2 steps are 40 ms."""
     tr = trace or StepTrace(device, ring)
     out = []
     try:

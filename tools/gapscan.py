@@ -91,7 +91,7 @@ def main():
         res = {"region_ms_median": round(statistics.median(regs), 5), "region_ms": [round(r, 5) for r in regs],
                "region_event_ms_median": round(statistics.median(evs), 5), "long_ms": round(long_ms, 5)}
         if not graph and not args.no_trace:
-            res["timeline"] = trace_steps(step, dev, ring=16, bursts=8)
+            res["timeline"] = trace_steps(step, dev, ring=16, bursts=8, lead=300)
         return res
 
     out = open(args.out, "a") if args.out else None

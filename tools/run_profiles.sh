@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (gpurun): bench line, kernel-trace stats, separate --pmc passes (never combined
 # with sys/hip/hsa traces), stage timings.  Results land under gpurun_out/$1; the summaries to keep go to profiles/.
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$R
 mkdir -p $O
@@ -28,6 +28,10 @@ python tools/profile_summary.py $(find $O/eq73_kt -name "*.db" | head -1) > $O/e
 rocprofv3 --kernel-trace --stats -d $O/eq_kt -o kt -- python tools/eqbench.py --frames 1170 --steps 50 --paths fused-eager > $O/eq_kt.log 2>&1
 python tools/profile_summary.py $(find $O/eq_kt -name "*.db" | head -1) > $O/eq_kernel_stats.txt 2>&1
 python tools/eqbench.py --steps 100 --ab 20=0,1 2>&1 | grep -v amdgpu.ids > $O/eqbench_replan_ab.jsonl
+python tools/eqbench.py --frames 73 --steps 100 --ab 21=0,1 2>&1 | grep -v amdgpu.ids > $O/eqbench_fewrow_ab.jsonl
+python tools/eqloop.py 2>&1 | grep -v amdgpu.ids > $O/eqloop.jsonl
+python tools/gapscan.py --modes eager,graph,ride2,sleepy,eager 2>/dev/null > $O/gapscan.jsonl
+python tools/ramp.py --idles 0,5,50,1000 --steps 60 --reps 2 2>/dev/null > $O/ramp.jsonl
 python tools/convbench.py 2>&1 | grep -v amdgpu.ids > $O/convbench.jsonl
 rocprofv3 --kernel-trace --stats -d $O/e2e_kt -o kt -- python tools/e2ebench.py --host-steps 0 > $O/e2e_kt.log 2>&1
 python tools/profile_summary.py $(find $O/e2e_kt -name "*.db" | head -1) > $O/e2e_kernel_stats.txt 2>&1
