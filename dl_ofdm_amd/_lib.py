@@ -51,7 +51,7 @@ class RxBuffers(C.Structure):
                 ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
-                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int)]
+                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p)]
 
 
 class EqShape(C.Structure):

@@ -1249,9 +1249,12 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     const bool ride_bw = fuse_bw && b->x_next != nullptr && b->x_norm_next != nullptr && kNormFusedCG == 2 &&
                          norm_fused_ok(b->x_next, b->x_norm_next, sh->batch, L.cols);
     if (b->x_norm_next != nullptr && b->x_next != nullptr && !ride_bw) return DCCN_ERR_INVALID_ARG;   // ask dccn_rx_norm_rides_backward first
+    // a producer on another stream is filling x_next: the launch that reads it waits for the producer's event
+    const bool wait_x = b->x_next != nullptr && b->x_next_ready != nullptr;
     if (fuse_bw) {
         NormRideArgs nr;
         memset(&nr, 0, sizeof(nr));
+        if (ride_bw && wait_x) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
         if (ride_bw) {
             // the update + prefetch launch of this step counts arrivals from zero and publishes into cleared flag words
             fin.zero_word = ws_sync; fin.zero_flags = ws_sync + 64; fin.zero_stride = kFlagStride;
@@ -1309,6 +1312,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
+    if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
     AdamRxArgs aa;
     aa.stamp = tl_stamp;

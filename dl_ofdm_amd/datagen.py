@@ -130,7 +130,7 @@ class DeviceDataGen:
 
     def channel(self, tx: torch.Tensor, snr_db, out_x: Optional[torch.Tensor] = None, taps: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None, want_H: bool = False, offset: Optional[int] = None,
-                out_H: Optional[torch.Tensor] = None):
+                out_H: Optional[torch.Tensor] = None, out_npow: Optional[torch.Tensor] = None):
         """fading + AWGN on [n,S,n_sc,2] frames; ``taps`` / ``noise``: external draws instead of the Philox streams
         (static: standard normals [n,n_taps,2]; mobile: uniform phases [n,2,48,n_taps]; noise: normals [n,T,2]).
         H: complex [n,K] (static) or [n,S,K] (mobile)."""
@@ -166,7 +166,7 @@ class DeviceDataGen:
             noise = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()
         # the noise-power monitor (`noise_power:0` of the reference's log line) costs one more reduction launch per batch:
         # sweeps and benchmarks that never read it switch it off (want_noise_power = False -> None is returned)
-        npw_t = w["npow"] if self.want_noise_power else None
+        npw_t = (out_npow if out_npow is not None else w["npow"]) if self.want_noise_power else None
         npw = self._p(npw_t)
         if self.mixed:
             # taps: (normals [n,16,2] for the static frames, phases [n,2,48,16] for the Doppler frames), or None
@@ -238,3 +238,52 @@ class DeviceDataGen:
         x, npow, H = self.channel(tx, snr_db, out_x=out_x, want_H=want_H)
         self.offset = (self.offset + 1) & 0xFFFFFFFF
         return (x, bits, npow, H) if want_H else (x, bits, npow)
+
+
+class SideStreamFeeder:
+    """The generator on its own HIP stream: batch i+1 is produced while the forward and backward launches of step i run.
+
+    The pipelined receiver step reads ``eng.x`` only in its LAST launch (R0 of the next batch rides on the optimizer launch) and
+    reads the labels of the batch it trains on from one of two slots, so the generation of batch i+1 into ``eng.x`` / the other
+    slot depends on nothing step i's first three launches touch.  Two events order the rest: the step's x_next_ready event
+    (include/dccn.h) makes the optimizer launch wait for the generator, and the generator waits for the previous step (whose
+    optimizer launch read the batch that ``eng.x`` held).  The generator's four latency-bound launches (~35 us of a mostly
+    idle chip) then cost the loop nothing but the join.
+
+        feed = SideStreamFeeder(eng, lambda slot: gen.make_batch(n, snr, out_x=eng.x, out_bits=eng.label_slot(slot)))
+        feed.first()                                   # batch 0 on the caller's stream + eng.prime()
+        for i in range(steps):
+            feed.next((i + 1) & 1)                     # batch i+1 on the side stream
+            eng.train_step_pipelined(slot=i & 1, x_ready=feed.ready)
+            feed.step_issued()
+    """
+
+    def __init__(self, eng, make):
+        self.eng, self.make = eng, make
+        self.stream = torch.cuda.Stream(device=eng.device)
+        self.ready = torch.cuda.Event()
+        self._step = torch.cuda.Event()
+        self._have_step = False
+
+    def first(self, slot: int = 0):
+        self.make(slot)
+        self.eng.prime()
+
+    def next(self, slot: int):
+        main = torch.cuda.current_stream(self.eng.device)
+        if self._have_step:
+            self.stream.wait_event(self._step)         # eng.x was read by the previous step's last launch
+        else:
+            self.stream.wait_stream(main)              # (first call: everything issued so far, incl. prime())
+        with torch.cuda.stream(self.stream):
+            out = self.make(slot)
+            self.ready.record(self.stream)
+        return out
+
+    def step_issued(self):
+        self._step.record(torch.cuda.current_stream(self.eng.device))
+        self._have_step = True
+
+    def drain(self):
+        torch.cuda.current_stream(self.eng.device).wait_stream(self.stream)
+

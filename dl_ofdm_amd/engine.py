@@ -138,7 +138,8 @@ class RxEngine:
                                  p(self.adam_v), p(self.reg_coef), p(self.adam_state), p(self.x_norm),
                                  p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
                                  p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0, 0, 0, 1 if want_grads else 0,
-                                 1)       # reg_uniform_dense: self.reg_coef is one value over the dense kernel (above)
+                                 1,       # reg_uniform_dense: self.reg_coef is one value over the dense kernel (above)
+                                 0)       # x_next_ready
         # pipelined training, double-buffered: the next batch is normalised into the OTHER x_norm buffer by leading blocks of
         # the backward launch (dccn.h: x_norm_next / norm_slot); `x_norm` stays the buffer plain steps use (parity 0)
         self._norm_bufs = [self.x_norm, None]
@@ -224,8 +225,9 @@ class RxEngine:
             self.bits_alt = torch.zeros_like(self.bits)
         return self.bits_alt
 
-    def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1) -> RxBuffers:
-        key = (slot, last, parity, double, pre)
+    def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1,
+                      ready: int = 0) -> RxBuffers:
+        key = (slot, last, parity, double, pre, ready)
         if key not in self._pipe_bufs:
             vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
             vals["bits"] = self.label_slot(slot).data_ptr()
@@ -234,10 +236,12 @@ class RxEngine:
             vals["x_norm"] = self._norm_bufs[parity].data_ptr()
             vals["norm_slot"] = parity
             vals["x_norm_next"] = self._norm_bufs[parity ^ 1].data_ptr() if (double and not last) else 0
+            vals["x_next_ready"] = 0 if last else ready
             self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
         return self._pipe_bufs[key]
 
-    def train_step_pipelined(self, next_x=None, bits=None, graph: bool = False, slot: int = 0, last: bool = False):
+    def train_step_pipelined(self, next_x=None, bits=None, graph: bool = False, slot: int = 0, last: bool = False,
+                             x_ready=None):
         """One training step with R0 software-pipelined across steps: the step runs on the batch whose normalisation is
         already in ``x_norm`` (written by the previous pipelined call, or by ``prime()``; the first call primes itself from
         ``eng.x``), with the labels of THAT batch (``bits``, or what ``label_slot(slot)`` already holds), and normalises
@@ -245,7 +249,9 @@ class RxEngine:
         one kernel boundary less per step.  ``eng.x`` is only read by R0, so the caller refills the same buffer between
         calls; the labels lag one batch behind the input, hence the two label slots for producers that write both at once.
         ``last=True``: nothing follows (end of an epoch), no normalisation is issued and the next call primes again.
-        Results are bit-identical to ``train_step`` fed the same batches in the same order."""
+        ``x_ready`` (a recorded ``torch.cuda.Event``): the next batch is being written into ``eng.x`` on ANOTHER stream; the
+        launch that normalises it waits for that event, everything before it runs concurrently with the producer
+        (datagen.SideStreamFeeder).  Results are bit-identical to ``train_step`` fed the same batches in the same order."""
         if not self.train:
             raise _lib.DccnError("engine built with train=False")
         if not self._norm_ready:
@@ -256,14 +262,19 @@ class RxEngine:
             self.x.copy_(torch.as_tensor(next_x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
         double = self._norm_bufs[1] is not None
         if graph:
-            if slot != 0 or last:
-                raise _lib.DccnError("captured pipelined steps use label slot 0 and always prefetch")
+            if slot != 0 or last or x_ready is not None:
+                raise _lib.DccnError("captured pipelined steps use label slot 0, always prefetch and take no producer event")
             # a captured step replays fixed buffers: it keeps the batch in whichever x_norm buffer holds it now and
             # normalises the next one into the same buffer on its optimizer launch (the single-buffer form)
             self._launch_graph(1 | 4 | (8 if self._norm_parity else 0))
             self._fwd_prefetched = False
         else:
-            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1)
+            ready = 0
+            if x_ready is not None and not last:
+                ready = int(x_ready.cuda_event)
+                if not ready:
+                    raise _lib.DccnError("x_ready must be an event that has been recorded")
+            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1, ready)
             check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(bufs), self.hp, self._stream()), "dccn_rx_train_step")
             self._fwd_prefetched = False
             if double and not last:

@@ -282,15 +282,26 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             steps = n_use // batch_size
             # R0 is software-pipelined across the steps (RxEngine.train_step_pipelined): batch i+1 is generated into
             # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
+            # ... and the generator runs on its own stream (datagen.SideStreamFeeder): batch i+1 is produced while the forward
+            # and backward launches of step i run; the step's last launch waits for it
+            from .datagen import SideStreamFeeder
+
+            def make(slot, eng=eng, bs=batch_size):
+                npow = _gen_into(gen, eng, FLAGS, ofdmobj, bs, FLAGS.SNR, slot=slot)
+                return None if npow is None else npow.clone()       # (the generator's monitor buffer is reused per batch)
+            feed = SideStreamFeeder(eng, make)
             noise_t = None
             if steps:
-                noise_t = _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=0)
+                noise_t = make(0)
                 eng.prime()
             for i in range(steps):
                 last = i + 1 == steps
-                noise_next = None if last else _gen_into(gen, eng, FLAGS, ofdmobj, batch_size, FLAGS.SNR, slot=(i + 1) & 1)
-                eng.train_step_pipelined(slot=i & 1, last=last)      # stream launches
-                acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power); acc[2:3].add_(noise_t)
+                noise_next = None if last else feed.next((i + 1) & 1)
+                eng.train_step_pipelined(slot=i & 1, last=last, x_ready=None if last else feed.ready)
+                feed.step_issued()
+                acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power)
+                if noise_t is not None:
+                    acc[2:3].add_(noise_t)
                 noise_t = noise_next
             a = acc.cpu().numpy() / max(steps, 1)
             losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])

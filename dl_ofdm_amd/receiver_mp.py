@@ -74,6 +74,7 @@ class Flags:
     snr_step: int = 5               # :81
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py)
     align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
+    overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 
@@ -262,43 +263,99 @@ class DeviceEpochLoop:
     (+ AWGN at this step's row of the epoch's SNR table, already on the device), the fused equaliser step, and ONE monitor
     launch that computes `chan_rms` (ofdmreceiver_np_mp.py:245, 325-333) and adds the step's scalars onto the epoch
     accumulators.  Round 3 did the last part with ~25 framework launches and a host-to-device copy per step, which made the
-    loop host-bound at twice the fused step's own time (tools/eqloop.py)."""
+    loop host-bound at twice the fused step's own time (tools/eqloop.py).
 
-    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int):
+    ``overlap`` (built, bitwise-tested, measured, OFF by default): two resident buffer sets (input, labels, channel truth,
+    noise power, step workspace) and the generator on its own HIP stream -- batch i+1 is produced into the other set while
+    step i runs; two events per set order producer and consumer.  Same batches, same step: the trained model is bit-identical
+    to the one-stream loop (tests/test_gpu_equalizer.py) -- but not faster: 0.2222 vs 0.2172 ms per step (tools/eqloop.py);
+    the two cross-stream edges per step cost what hiding the generator's 26 us gains."""
+
+    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int, overlap: bool = False):
         import ctypes as C
         import torch
+        from .equalizer import _FusedPlan
         self.C, self.torch = C, torch
-        self.F, self.o, self.tr, self.gen, self.pl, self.steps = FLAGS, ofdmobj, trainer, gen, pl, int(steps)
+        self.F, self.o, self.tr, self.gen, self.steps = FLAGS, ofdmobj, trainer, gen, int(steps)
         dev, B = trainer.device, pl.batch
+        self.overlap = bool(overlap)
+        self.pls = [pl, _FusedPlan(trainer, B)] if self.overlap else [pl]
+        self.pl = pl
         self.per_symbol = 1 if (gen.doppler or gen.mixed) else 0
         hshape = (B, FLAGS.nsymbol, ofdmobj.K, 2) if self.per_symbol else (B, ofdmobj.K, 2)
-        self.H = torch.empty(*hshape, dtype=torch.float32, device=dev)
+        n = len(self.pls)
+        self.H = [torch.empty(*hshape, dtype=torch.float32, device=dev) for _ in range(n)]
+        self.npow = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(n)]
         self.acc = torch.zeros(5, dtype=torch.float32, device=dev)
         self.snr = torch.zeros(self.steps, B, dtype=torch.float32, device=dev)
         self.snr_rows = [self.snr[i] for i in range(self.steps)]
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
         self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
         self.i = 0
+        if self.overlap:
+            self.side = torch.cuda.Stream(device=dev)
+            self.ready = [torch.cuda.Event() for _ in range(2)]      # set q holds a finished batch
+            self.done = [torch.cuda.Event() for _ in range(2)]       # the step that read set q has completed
+            self.used = [False, False]
+        self.pending = -1                                            # index (within the epoch) of the batch already generated
+        self.fresh_epoch = True
+
+    def _generate(self, i: int, q: int):
+        pl, gen = self.pls[q], self.gen
+        tx, _ = gen.transmit(pl.batch, out_bits=pl.bits)
+        gen.channel(tx, self.snr_rows[i], out_x=pl.x, out_H=self.H[q], out_npow=self.npow[q])
+        gen.offset += 1
 
     def begin_epoch(self, snr_table: np.ndarray):
         """snr_table [steps, B]: the epoch's per-frame training SNRs (one host draw + ONE copy per epoch, :407)"""
-        self.snr.copy_(self.torch.from_numpy(np.ascontiguousarray(snr_table, dtype=np.float32).reshape(self.steps, -1)))
+        torch = self.torch
+        if self.overlap:
+            torch.cuda.current_stream(self.tr.device).wait_stream(self.side)     # (nothing of the last epoch is in flight)
+        self.snr.copy_(torch.from_numpy(np.ascontiguousarray(snr_table, dtype=np.float32).reshape(self.steps, -1)))
         self.acc.zero_()
         self.i = 0
+        self.pending = -1
+        self.fresh_epoch = True                                      # the side stream has not seen this epoch's SNR table yet
+
+    def _produce(self, i: int, q: int):
+        """batch i of the epoch into buffer set q, on the side stream"""
+        torch = self.torch
+        main = torch.cuda.current_stream(self.tr.device)
+        if self.used[q]:
+            self.side.wait_event(self.done[q])
+        if self.fresh_epoch or not self.used[q]:
+            self.side.wait_stream(main)                              # the SNR table copy / first use: the plan's construction
+            self.fresh_epoch = False
+        with torch.cuda.stream(self.side):
+            self._generate(i, q)
+            self.ready[q].record(self.side)
+        self.pending = i
 
     def step(self):
-        C, pl, gen, tr = self.C, self.pl, self.gen, self.tr
+        from ._lib import check
+        tr = self.tr
         i = self.i % self.steps
         self.i += 1
-        tx, _ = gen.transmit(pl.batch, out_bits=pl.bits)
-        _, npow, _ = gen.channel(tx, self.snr_rows[i], out_x=pl.x, out_H=self.H)
-        gen.offset += 1
+        if not self.overlap:
+            q = 0
+            self._generate(i, 0)
+        else:
+            q = i & 1
+            if self.pending != i:                                    # first step of an epoch: nothing was produced ahead
+                self._produce(i, q)
+            if i + 1 < self.steps:
+                self._produce(i + 1, q ^ 1)                          # the next batch, while this step runs
+            self.torch.cuda.current_stream(tr.device).wait_event(self.ready[q])
+        pl = self.pls[q]
         pl.run(True)
-        from ._lib import check
-        check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H.data_ptr(), self.per_symbol, pl.batch,
+        npow = self.npow[q] if self.gen.want_noise_power else None
+        check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H[q].data_ptr(), self.per_symbol, pl.batch,
                                                 self.F.nsymbol, self.o.K, pl.metrics_buf.data_ptr(), pl.tx_power.data_ptr(),
                                                 None if npow is None else npow.data_ptr(), self.acc.data_ptr(), None,
                                                 self.ws.data_ptr(), self.nws, pl._stream()), "dccn_eq_monitor_accumulate")
+        if self.overlap:
+            self.done[q].record(self.torch.cuda.current_stream(tr.device))
+            self.used[q] = True
 
     def epoch_means(self) -> np.ndarray:
         return self.acc.cpu().numpy() / max(self.steps, 1)
@@ -340,9 +397,9 @@ class BestSnapshot:
         return self.path if self.written else ""
 
 
-def device_epoch_runner(FLAGS, ofdmobj, trainer, gen, pl, steps: int = 197):
+def device_epoch_runner(FLAGS, ofdmobj, trainer, gen, pl, steps: int = 197, overlap: bool = False):
     """tools/eqloop.py: one step of the loop below as a callable (SNR table drawn once)"""
-    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps)
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=overlap)
     loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, pl.batch], p=TRAIN_SNR_PROB))
     return loop.step
 
@@ -357,7 +414,7 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
     steps = frame_cnt // batch_size
-    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps)
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=bool(getattr(FLAGS, "overlap_generator", False)))
     best = BestSnapshot(trainer, os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), FLAGS)
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))

@@ -349,6 +349,10 @@ typedef struct dccn_rx_buffers {
        dev/py/model.py:1271-1272): the optimizer then reads that value once instead of streaming a parameter-sized array
        (12 % of the optimizer launch's traffic at N = 1024).  0 = per-element coefficients everywhere (the general form). */
     int reg_uniform_dense;
+    /* hipEvent_t (nullable) that the launch reading x_next waits for on `stream`: lets a producer fill x_next on ANOTHER
+       stream while the forward and backward launches of this step run (the device-side generator: dl_ofdm_amd/datagen.py
+       SideStreamFeeder).  Eager launches only (not inside dccn_rx_graph_create). */
+    void* x_next_ready;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);

@@ -41,14 +41,34 @@ def main():
         for i in range(n):
             gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.label_slot((i + 1) & 1))
             eng.train_step_pipelined(slot=i & 1)
-    run(20, True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(a.steps, False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps(dict(mode="device-generated", channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
-                          symbols_per_s=round(a.frames * 7 / dt), final_ce=round(eng.metrics()["ce_mean"], 4))))
+    from dl_ofdm_amd.datagen import SideStreamFeeder
+    feed = SideStreamFeeder(eng, lambda slot: gen.make_batch(a.frames, F.SNR, out_x=eng.x, out_bits=eng.label_slot(slot)))
+
+    def run_overlapped(n, first):
+        if first:
+            feed.first(0)
+        for i in range(n):
+            feed.next((i + 1) & 1)
+            eng.train_step_pipelined(slot=i & 1, x_ready=feed.ready)
+            feed.step_issued()
+
+    for mode, fn in (("device-generated, one stream", run), ("device-generated, generator on a side stream", run_overlapped)):
+        eng.drop_prefetch()
+        gen.offset = 0
+        fn(20, True)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.3:
+            fn(50, False)
+            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(a.steps, False)
+        t_issue = (time.perf_counter() - t0) / a.steps
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps(dict(mode=mode, channel=a.channel, frames=a.frames, ms_per_step=round(dt * 1e3, 4),
+                              host_issue_ms_per_step=round(t_issue * 1e3, 4),
+                              symbols_per_s=round(a.frames * 7 / dt), final_ce=round(eng.metrics()["ce_mean"], 4))))
     if a.host_steps <= 0:
         return
     eng.drop_prefetch()                    # the pipelined loop above left a normalised batch behind

@@ -72,8 +72,8 @@ def main():
     variants = [("harness_loop", full), ("no_monitor", no_monitor), ("generator_only", gen_only), ("step_graph", step_graph),
                 ("step_eager", step_eager)]
     if hasattr(M, "device_epoch_runner"):
-        run = M.device_epoch_runner(F, o, tr, gen, pl)
-        variants.insert(0, ("r04_loop", run))
+        variants.insert(0, ("r04_loop_generator_on_side_stream", M.device_epoch_runner(F, o, tr, gen, pl, overlap=True)))
+        variants.insert(0, ("r04_loop", M.device_epoch_runner(F, o, tr, gen, pl)))
     for name, fn in variants:
         for _ in range(30):
             fn()
