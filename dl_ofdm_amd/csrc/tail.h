@@ -413,26 +413,32 @@ struct TailQuad4Acc {
         c00 = c01 = c10 = c11 = 0;
     }
 };
-// the tail weights a lane of the quad form needs, in registers for the whole cell loop (92 values: the 1x1 conv and its
-// bias, this lane's two columns of dense_1 and their bias, the conv rows of its four hidden units) -- re-reading them from
-// LDS for every cell (~80 broadcast reads, each a full LDS latency for the single wave of a SIMD) was most of a cell's time
+// the tail weights a lane of the quad form needs, in registers for the whole cell loop (50 values: this lane's two columns
+// of dense_1 and their bias, the 1x1-conv rows and bias of its four hidden units) -- re-reading them from LDS for every
+// cell (~80 broadcast reads, each a full LDS latency for the single wave of a SIMD) was most of a cell's time
 struct TailQuad4W {
     static constexpr int M = 16, O = 8;
-    float w1a[M], w1b[M], b1[M];
     float w2[M + 2][2], b2[2];
-    float own_a[4], own_b[4];
+    float own_a[4], own_b[4], own_b1[4];
     __device__ __forceinline__ void load(const float* __restrict__ sw, const int q) {
         constexpr int oW1 = 0, oB1 = 2 * M, oW2 = 3 * M, oB2 = 3 * M + (M + 2) * O;
-#pragma unroll
-        for (int j = 0; j < M; ++j) { w1a[j] = sw[oW1 + j]; w1b[j] = sw[oW1 + M + j]; b1[j] = sw[oB1 + j]; }
 #pragma unroll
         for (int i = 0; i < M + 2; ++i) { w2[i][0] = sw[oW2 + i * O + 2 * q]; w2[i][1] = sw[oW2 + i * O + 2 * q + 1]; }
         b2[0] = sw[oB2 + 2 * q];
         b2[1] = sw[oB2 + 2 * q + 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { own_a[u] = sw[oW1 + 4 * q + u]; own_b[u] = sw[oW1 + M + 4 * q + u]; }
+        for (int u = 0; u < 4; ++u) {
+            own_a[u] = sw[oW1 + 4 * q + u];
+            own_b[u] = sw[oW1 + M + 4 * q + u];
+            own_b1[u] = sw[oB1 + 4 * q + u];
+        }
     }
 };
+// lane k of every quad to all four lanes
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
     v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
@@ -446,14 +452,31 @@ __device__ __forceinline__ float2 tail_quad4_cell(const float z0, const float z1
                                                   const TailQuad4W& W, const float inv_count,
                                                   float* __restrict__ prob_q, const int q, TailQuad4Acc& A) {
     constexpr int M = 16;
-    auto pick4 = [&](const float* a, int u) {           // a[4*q + u] without dynamic register indexing
-        return q == 0 ? a[u] : (q == 1 ? a[4 + u] : (q == 2 ? a[8 + u] : a[12 + u]));
+    // a[4*q + u] without dynamic register indexing: three lane-mask selects.  (Written as ?: the compiler turned the
+    // eight picks into nested exec-mask regions -- 130 scalar instructions per cell around ~330 vector ones -- although
+    // every quad takes all four paths.)
+    const unsigned long long qm1 = __builtin_amdgcn_ballot_w64(q == 1), qm2 = __builtin_amdgcn_ballot_w64(q == 2),
+                             qm3 = __builtin_amdgcn_ballot_w64(q == 3);
+    auto sel = [](float a, float b, unsigned long long m) {
+        float r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+        return r;
     };
-    float c[M + 2], pre1[M];
+    auto pick4 = [&](const float* a, int u) { return sel(sel(sel(a[u], a[4 + u], qm1), a[8 + u], qm2), a[12 + u], qm3); };
+    // the 1x1 conv: every lane evaluates its own four hidden units (same expression as tail_cells) and the quad trades them
+    // on the DPP crossbar -- 16 + 16 instructions where four redundant evaluations of all 16 units took 64
+    float c[M + 2], pre_own[4], c_own[4];
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-        pre1[j] = __builtin_fmaf(z1, W.w1b[j], __builtin_fmaf(z0, W.w1a[j], W.b1[j]));   // as tail_cells
-        c[j] = leaky_relu(pre1[j]);
+    for (int u = 0; u < 4; ++u) {
+        pre_own[u] = __builtin_fmaf(z1, W.own_b[u], __builtin_fmaf(z0, W.own_a[u], W.own_b1[u]));
+        c_own[u] = leaky_relu(pre_own[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        c[u] = quad_bcast<0>(c_own[u]);
+        c[4 + u] = quad_bcast<1>(c_own[u]);
+        c[8 + u] = quad_bcast<2>(c_own[u]);
+        c[12 + u] = quad_bcast<3>(c_own[u]);
     }
     c[M] = z0;
     c[M + 1] = z1;
@@ -507,7 +530,7 @@ __device__ __forceinline__ float2 tail_quad4_cell(const float z0, const float z1
     float d0p = 0.f, d1p = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                    // hidden units 4q .. 4q+3
-        const float dp = pick4(dc, u) * (pick4(pre1, u) > 0.f ? 1.f : kLeaky);
+        const float dp = pick4(dc, u) * (pre_own[u] > 0.f ? 1.f : kLeaky);
         A.gw1a[u] = __builtin_fmaf(z0, dp, A.gw1a[u]);
         A.gw1b[u] = __builtin_fmaf(z1, dp, A.gw1b[u]);
         A.gb1[u] += dp;
@@ -591,12 +614,29 @@ __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
     A.clear();
     const float inv_count = 1.0f / (float)(cells * NB);
     const long long stride = (long long)gridDim.x * (kTailThreads / 4);
-    for (long long cell = (long long)blockIdx.x * (kTailThreads / 4) + (threadIdx.x >> 2); cell < cells; cell += stride) {
-        const float2 zv = *reinterpret_cast<const float2*>(z + 2 * cell);
-        const int label = bits[cell * NB + q];
+    // the next cell's operands are requested before this cell's ~250 instructions run: with two waves per SIMD nothing
+    // else would cover the load latency of every pass
+    long long cell = (long long)blockIdx.x * (kTailThreads / 4) + (threadIdx.x >> 2);
+    float2 zv = make_float2(0.f, 0.f);
+    int label = 0;
+    if (cell < cells) {
+        zv = *reinterpret_cast<const float2*>(z + 2 * cell);
+        label = bits[cell * NB + q];
+    }
+    while (cell < cells) {
+        const long long nxt = cell + stride;
+        float2 zn = zv;
+        int ln = label;
+        if (nxt < cells) {
+            zn = *reinterpret_cast<const float2*>(z + 2 * nxt);
+            ln = bits[nxt * NB + q];
+        }
         const float2 d = tail_quad4_cell(zv.x, zv.y, label, true, W, inv_count,
                                          WRITE_PROB ? prob + (cell * NB + q) * 2 : nullptr, q, A);
         if (q == 0) *reinterpret_cast<float2*>(dz + 2 * cell) = d;
+        zv = zn;
+        label = ln;
+        cell = nxt;
     }
     tail_quad4_block_reduce<kTailThreads>(A, sred, blk_metrics, blk_grads, (int)blockIdx.x);
     stamp_mark(stamp, 1);
