@@ -66,7 +66,8 @@ class EqBuffers(C.Structure):
                 ("adam_m", c_void_p), ("adam_v", c_void_p), ("reg_coef", c_void_p), ("adam", c_void_p),
                 ("rx_params", c_void_p), ("out_eq", c_void_p), ("chest", c_void_p), ("snr_db", c_void_p),
                 ("pilot_carriers", c_void_p), ("prob", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("reg_uniform", c_int), ("rx_folded", c_void_p)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("reg_uniform", c_int), ("rx_folded", c_void_p),
+                ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int)]
 
 
 class ChannelGroup(C.Structure):
@@ -148,6 +149,7 @@ SIGNATURES = {
     "dccn_timer_destroy": (_i, [_vp]),
     "dccn_stream_synchronize": (_i, [_vp]),
     "dccn_eq_rx_folded_floats": (_sz, [POINTER(EqShape)]),
+    "dccn_eq_norm_rides": (_i, [POINTER(EqShape)]),
     "dccn_eq_rx_fold": (_i, [POINTER(EqShape), _vp, _vp, _vp]),
     "dccn_eq_monitor_workspace_size": (_sz, [_i, _i, _i]),
     "dccn_eq_monitor_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1786,6 +1786,12 @@ int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, d
                        dccn_stream_t stream) {
     return eq_step_impl(shape, buf, true, hp, (hipStream_t)stream);
 }
+int dccn_eq_norm_rides(const dccn_eq_shape* shape) {
+    if (!eq_shape_ok(shape)) return 0;
+    const EqDims d = eq_dims(shape);
+    const int ncols = d.S * 2 * d.nsc;
+    return (g_tune[TUNE_EQ_REPLAN] != 0 && kNormFusedCG == 2 && (ncols % 4) == 0 && d.B <= 128 * kNormFusedRPT) ? 1 : 0;
+}
 int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,
                          dccn_stream_t stream, dccn_rx_graph** out) {
     if (!out || !eq_shape_ok(shape) || !buf) return DCCN_ERR_INVALID_ARG;

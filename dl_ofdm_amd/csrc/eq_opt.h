@@ -17,7 +17,8 @@
 
 namespace dccn {
 
-enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3, EQJ_PILOT_SNR = 4 };
+enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3, EQJ_PILOT_SNR = 4,
+                        EQJ_NORM_NEXT = 5 };
 struct EqOptJob {
     int kind, block0, blocks, splits;
     long long off, n;        // arena segment of the (first) variable
@@ -41,6 +42,9 @@ struct EqOptArgs {
     // EQJ_PILOT_SNR
     const float2* ps_eq; const int* ps_carriers; float* ps_out;
     int ps_frames, ps_S, ps_K, ps_P;
+    // EQJ_NORM_NEXT: `input:0` of the NEXT batch (dccn_eq_buffers.x_next), norm_adam.h norm_fused_body
+    const float* nx; float* ny; double* npower;
+    int nbatch, ncols;
 };
 
 struct AdamCoef {
@@ -239,6 +243,11 @@ __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dc
     while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].block0) ++j;      // (block-uniform scan of the table)
     const EqOptJob& J = a.job[j];
     const int bx = (int)blockIdx.x - J.block0;
+    if (J.kind == EQJ_NORM_NEXT) {
+        norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, 1e-9f, 8.0f, a.npower, nullptr, nullptr, nullptr,
+                                                     hp, bx, J.blocks);
+        return;
+    }
     if (J.kind == EQJ_TAIL_FINALIZE) {
         demod_tail_finalize_body(a.fin, bx);
         return;
@@ -332,6 +341,11 @@ struct EqOptBuilder {
             a.ps_eq = reinterpret_cast<const float2*>(eq); a.ps_carriers = carriers; a.ps_out = out;
             a.ps_frames = frames; a.ps_S = S; a.ps_K = K; a.ps_P = P;
         }
+    }
+    // (first job of the table: its blocks are dispatched first -- a latency chain, not a stream)
+    void norm_next(const float* x, float* y, int batch, int cols, double* power_partial, int nblocks) {
+        EqOptJob* J = add(EQJ_NORM_NEXT, nblocks);
+        if (J) { a.nx = x; a.ny = y; a.nbatch = batch; a.ncols = cols; a.npower = power_partial; }
     }
     void tail_finalize(const TailFinalizeArgs& fin) {
         EqOptJob* J = add(EQJ_TAIL_FINALIZE, tail_finalize_blocks(fin.P));

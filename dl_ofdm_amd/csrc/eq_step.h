@@ -200,13 +200,21 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     // `input:0` (ofdmreceiver_np.py:128-137) + tx_power partials
     PowerPartials pp;
     // (training: the optimizer's per-step bookkeeping rides on this first launch)
-    DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, d.S * N2, 1e-9f, 8.0f,
-                       train ? b->adam : nullptr, hp, w.ws_norm, w.n_norm, s));
+    // pipelined: the previous step ran this launch for us on its optimizer launch (dccn_eq_buffers.x_next)
+    const int ncols = d.S * N2;
+    const bool rides = replan && train && norm_fused_ok(b->x, w.x_norm, B, ncols) && kNormFusedCG == 2;
+    const bool pre = rides && b->x_prenormalised != 0;
+    if (b->x_prenormalised != 0 && !pre) return DCCN_ERR_INVALID_ARG;
+    const int nslot = b->norm_slot ? 1 : 0;
+    if (pre) norm_power_partials(B, ncols, w.ws_norm, w.n_norm, b->x, w.x_norm, &pp, nslot);
+    else DCCN_TRY(norm_impl(b->x, w.x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, B, ncols, 1e-9f, 8.0f,
+                            train ? b->adam : nullptr, hp, w.ws_norm, w.n_norm, s, nslot));
     // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"; the expansion of the :428 smoothing C-Conv (S x K, same)
     // into the block-Toeplitz matrix of a dense layer depends on the parameters only and shares the launch
     if (replan) {
         hipLaunchKernelGGL(eq_prep_kernel, dim3(B + ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s, (const float*)w.x_norm,
-                           w.ln, B, d.S * N2, 1e-12f, P + d.o[12], P + d.o[13], w.T, w.be, d.S, K);
+                           w.ln, B, d.S * N2, 1e-12f, P + d.o[12], P + d.o[13], w.T, w.be, d.S, K,
+                           pre ? b->adam : (dccn_adam_state*)nullptr, hp);
         DCCN_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
@@ -433,6 +441,13 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     ob.a.param = b->eq_params; ob.a.grad = G; ob.a.m = b->adam_m; ob.a.v = b->adam_v; ob.a.reg_coef = b->reg_coef;
     ob.a.state = b->adam;
     const bool uni = b->reg_uniform != 0 && b->reg_coef != nullptr;
+    if (rides && b->x_next != nullptr && norm_fused_ok(b->x_next, w.x_norm, B, ncols)) {
+        // `input:0` of the next batch: x_norm is read by the layer norm only, long before this launch
+        PowerPartials pn;
+        norm_power_partials(B, ncols, w.ws_norm, w.n_norm, b->x_next, w.x_norm, &pn, nslot ^ 1);
+        ob.norm_next(b->x_next, w.x_norm, B, ncols, b->tx_power != nullptr ? const_cast<double*>(pn.partial) : nullptr,
+                     norm_fused_blocks(ncols));
+    }
     eq_opt_dense(ob, d, 0, ds0, K2, uni);
     if (fconv.slabs) ob.cconv_fold(d.o[2], d.o[3], fconv.slabs, fconv.colsum, fconv.splits, fconv.slab, K, K);
     else { ob.plain(d.o[2], d.sz[2]); ob.plain(d.o[3], d.sz[3]); }

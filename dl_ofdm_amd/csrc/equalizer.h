@@ -333,9 +333,17 @@ __global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* _
 }
 // the equaliser step's second launch: layer_norm of the normalised frames (one block per frame) and, in the blocks behind
 // them, the expansion of the smoothing kernel -- two independent 5 us launches as one
+// adam != nullptr: the optimizer's per-step bookkeeping rides here (steps whose normalisation the previous step already ran)
 __global__ __launch_bounds__(256) void eq_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int cols,
                                                       float eps, const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ T, float* __restrict__ bias_eff, int L, int W) {
+                                                      float* __restrict__ T, float* __restrict__ bias_eff, int L, int W,
+                                                      dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp) {
+    if (adam != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        adam->alpha = adam_alpha(adam, hp);
+        adam->beta1_power = adam->beta1_power * hp.beta1;
+        adam->beta2_power = adam->beta2_power * hp.beta2;
+        adam->global_step = adam->global_step + 1.0f;
+    }
     if ((int)blockIdx.x < frames) layer_norm_fwd_body(x, y, nullptr, nullptr, cols, eps, (int)blockIdx.x);
     else cconv2d_same_expand_body(w, bias, T, bias_eff, L, W, L, W, (int)blockIdx.x - frames, (int)gridDim.x - frames);
 }

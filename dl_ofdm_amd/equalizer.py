@@ -35,9 +35,13 @@ class _FusedPlan:
     """Resident buffers + captured hipGraphs of ``dccn_eq_train_step`` / ``dccn_eq_eval_step`` for one batch
     size (include/dccn.h: "the fused equaliser transfer-learning step")."""
 
-    def __init__(self, tr: "EqualizerTrainer", batch: int):
+    def __init__(self, tr: "EqualizerTrainer", batch: int, twin_of: "Optional[_FusedPlan]" = None):
+        """twin_of: a plan of the same batch size whose workspace and outputs this one shares -- only the input frames and
+        labels are its own.  Two twins hold consecutive batches of a training loop: while one's step runs, the generator
+        fills the other's input, and the running step normalises it on its optimizer launch (``pipe_with``)."""
         F, o, dev = tr.FLAGS, tr.ofdmobj, tr.device
         self.tr, self.batch = tr, int(batch)
+        self.pipe_buffers: Dict[int, EqBuffers] = {}
         self.shape = EqShape(self.batch, F.nsymbol, o.K, o.CP, 1 if F.cp else 0, F.nfilter, o.frame_size, F.nbits, o.pilot_size,
                              len(o.pilotCarriers))
         offs = (C.c_longlong * 21)()
@@ -47,19 +51,37 @@ class _FusedPlan:
         B, S, n_sc = self.batch, F.nsymbol, o.K + o.CP
         self.x = torch.zeros(B, S, n_sc, 2, **f32)
         self.bits = torch.zeros(B, o.frame_size, F.nbits, dtype=torch.int32, device=dev)
-        self.out_eq = torch.empty(B, S, n_sc, 2, **f32)
-        self.chest = torch.empty(B, S, o.K, 2, **f32)
-        self.snr_db = torch.empty(B, 1, **f32)
-        self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=dev)
-        self.tx_power = torch.zeros(1, **f32)
-        nws = tr.lib.dccn_eq_workspace_size(C.byref(self.shape), 1)
-        self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        if twin_of is not None:
+            assert twin_of.batch == self.batch
+            for n in ("out_eq", "chest", "snr_db", "metrics_buf", "tx_power", "ws", "nws"):
+                setattr(self, n, getattr(twin_of, n))
+        else:
+            self.out_eq = torch.empty(B, S, n_sc, 2, **f32)
+            self.chest = torch.empty(B, S, o.K, 2, **f32)
+            self.snr_db = torch.empty(B, 1, **f32)
+            self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=dev)
+            self.tx_power = torch.zeros(1, **f32)
+            self.nws = tr.lib.dccn_eq_workspace_size(C.byref(self.shape), 1)
+            self.ws = torch.empty(self.nws, dtype=torch.uint8, device=dev)
+        self.buffers = self._buffers()
+        self.graphs: Dict[object, C.c_void_p] = {}
+
+    def _buffers(self, x_next=None, pre: int = 0, slot: int = 0) -> EqBuffers:
+        tr = self.tr
         p = lambda t: t.data_ptr()          # noqa: E731
-        self.buffers = EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
-                                 p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
-                                 p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
-                                 p(self.ws), nws, 1, p(tr.rx_folded(self.shape)))        # reg_uniform: _flatten() fills one value per dense tensor
-        self.graphs: Dict[int, C.c_void_p] = {}
+        return EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
+                         p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
+                         p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
+                         p(self.ws), self.nws, 1, p(tr.rx_folded(self.shape)),        # reg_uniform: _flatten() fills one value per dense tensor
+                         None if x_next is None else p(x_next), int(pre), int(slot))
+
+    def pipe_with(self, other: "_FusedPlan", slot: int):
+        """Training steps of this plan normalise `other`'s input on their optimizer launch (include/dccn.h
+        dccn_eq_buffers.x_next); run(True, pipe=0) starts a chain (own normalisation), pipe=1 continues one."""
+        assert other.ws is self.ws
+        for key in [k for k in self.graphs if isinstance(k, tuple)]:      # captured with the previous partner's pointers
+            self.tr.lib.dccn_rx_graph_destroy(self.graphs.pop(key))
+        self.pipe_buffers = {0: self._buffers(other.x, 0, slot), 1: self._buffers(other.x, 1, slot)}
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.tr.device).cuda_stream)
@@ -68,24 +90,27 @@ class _FusedPlan:
         self.x.copy_(torch.as_tensor(x, dtype=torch.float32).reshape(self.x.shape), non_blocking=True)
         self.bits.copy_(torch.as_tensor(bits).to(torch.int32).reshape(self.bits.shape), non_blocking=True)
 
-    def run(self, train: bool, graph: bool = True):
+    def run(self, train: bool, graph: bool = True, pipe: Optional[int] = None):
         lib, tr = self.tr.lib, self.tr
+        bufs = self.buffers if pipe is None else self.pipe_buffers[pipe]
+        assert pipe is None or train
         if not graph:
             if train:
-                check(lib.dccn_eq_train_step(C.byref(self.shape), C.byref(self.buffers), tr.hp, self._stream()),
+                check(lib.dccn_eq_train_step(C.byref(self.shape), C.byref(bufs), tr.hp, self._stream()),
                       "dccn_eq_train_step")
             else:
-                check(lib.dccn_eq_eval_step(C.byref(self.shape), C.byref(self.buffers), self._stream()),
+                check(lib.dccn_eq_eval_step(C.byref(self.shape), C.byref(bufs), self._stream()),
                       "dccn_eq_eval_step")
             return
         mode = 1 if train else 0
-        if mode not in self.graphs:
+        key = mode if pipe is None else (mode, pipe)
+        if key not in self.graphs:
             g = C.c_void_p(0)
             torch.cuda.synchronize(tr.device)
-            check(lib.dccn_eq_graph_create(C.byref(self.shape), C.byref(self.buffers), mode, tr.hp, self._stream(),
+            check(lib.dccn_eq_graph_create(C.byref(self.shape), C.byref(bufs), mode, tr.hp, self._stream(),
                                            C.byref(g)), "dccn_eq_graph_create")
-            self.graphs[mode] = g
-        check(lib.dccn_rx_graph_launch(self.graphs[mode], self._stream()), "dccn_rx_graph_launch")
+            self.graphs[key] = g
+        check(lib.dccn_rx_graph_launch(self.graphs[key], self._stream()), "dccn_rx_graph_launch")
 
     def close(self):
         for g in self.graphs.values():

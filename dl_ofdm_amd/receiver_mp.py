@@ -24,7 +24,7 @@ import copy
 import os
 import time
 from dataclasses import asdict, dataclass
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -74,6 +74,7 @@ class Flags:
     snr_step: int = 5               # :81
     device_data: bool = False       # generate bits/frames/channel/noise on the GPU (datagen.py)
     align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
+    pipeline_norm: Optional[bool] = None  # device_data: step i normalises batch i+1 on its optimizer launch (None: when the library can)
     overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
@@ -269,9 +270,14 @@ class DeviceEpochLoop:
     noise power, step workspace) and the generator on its own HIP stream -- batch i+1 is produced into the other set while
     step i runs; two events per set order producer and consumer.  Same batches, same step: the trained model is bit-identical
     to the one-stream loop (tests/test_gpu_equalizer.py) -- but not faster: 0.2222 vs 0.2172 ms per step (tools/eqloop.py);
-    the two cross-stream edges per step cost what hiding the generator's 26 us gains."""
+    the two cross-stream edges per step cost what hiding the generator's 26 us gains.
 
-    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int, overlap: bool = False):
+    ``pipeline`` (default: on when the library honours ``dccn_eq_buffers.x_next`` for this shape): two twin plans (own input
+    and labels, shared workspace and outputs) hold consecutive batches; batch i+1 is generated BEFORE step i is issued, and
+    step i normalises it on leading workgroups of its optimizer launch, so every step but the first of an epoch starts at
+    the layer norm -- one launch (6 us) off a 21-launch chain.  Same kernels on the same data: bit-identical training."""
+
+    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int, overlap: bool = False, pipeline: Optional[bool] = None):
         import ctypes as C
         import torch
         from .equalizer import _FusedPlan
@@ -279,7 +285,15 @@ class DeviceEpochLoop:
         self.F, self.o, self.tr, self.gen, self.steps = FLAGS, ofdmobj, trainer, gen, int(steps)
         dev, B = trainer.device, pl.batch
         self.overlap = bool(overlap)
-        self.pls = [pl, _FusedPlan(trainer, B)] if self.overlap else [pl]
+        if pipeline is None:
+            pipeline = not self.overlap and bool(trainer.lib.dccn_eq_norm_rides(C.byref(pl.shape)))
+        self.pipeline = bool(pipeline) and not self.overlap
+        if self.pipeline:
+            self.pls = [pl, _FusedPlan(trainer, B, twin_of=pl)]
+            self.pls[0].pipe_with(self.pls[1], 0)
+            self.pls[1].pipe_with(self.pls[0], 1)
+        else:
+            self.pls = [pl, _FusedPlan(trainer, B)] if self.overlap else [pl]
         self.pl = pl
         self.per_symbol = 1 if (gen.doppler or gen.mixed) else 0
         hshape = (B, FLAGS.nsymbol, ofdmobj.K, 2) if self.per_symbol else (B, ofdmobj.K, 2)
@@ -336,7 +350,15 @@ class DeviceEpochLoop:
         tr = self.tr
         i = self.i % self.steps
         self.i += 1
-        if not self.overlap:
+        pipe = None
+        if self.pipeline:
+            q = i & 1
+            if i == 0:
+                self._generate(0, 0)
+            if i + 1 < self.steps:
+                self._generate(i + 1, q ^ 1)                         # before step i: its optimizer launch normalises it
+            pipe = 0 if i == 0 else 1
+        elif not self.overlap:
             q = 0
             self._generate(i, 0)
         else:
@@ -347,7 +369,7 @@ class DeviceEpochLoop:
                 self._produce(i + 1, q ^ 1)                          # the next batch, while this step runs
             self.torch.cuda.current_stream(tr.device).wait_event(self.ready[q])
         pl = self.pls[q]
-        pl.run(True)
+        pl.run(True, pipe=pipe)
         npow = self.npow[q] if self.gen.want_noise_power else None
         check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H[q].data_ptr(), self.per_symbol, pl.batch,
                                                 self.F.nsymbol, self.o.K, pl.metrics_buf.data_ptr(), pl.tx_power.data_ptr(),
@@ -397,9 +419,10 @@ class BestSnapshot:
         return self.path if self.written else ""
 
 
-def device_epoch_runner(FLAGS, ofdmobj, trainer, gen, pl, steps: int = 197, overlap: bool = False):
+def device_epoch_runner(FLAGS, ofdmobj, trainer, gen, pl, steps: int = 197, overlap: bool = False,
+                        pipeline: Optional[bool] = None):
     """tools/eqloop.py: one step of the loop below as a callable (SNR table drawn once)"""
-    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=overlap)
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=overlap, pipeline=pipeline)
     loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, pl.batch], p=TRAIN_SNR_PROB))
     return loop.step
 
@@ -414,7 +437,8 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     pl, ev = trainer.resident(batch_size), trainer.resident(FLAGS.eval_frames)
     loss_min, epoch_min, best_path, history = 100.0, 0, "", []
     steps = frame_cnt // batch_size
-    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=bool(getattr(FLAGS, "overlap_generator", False)))
+    loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=bool(getattr(FLAGS, "overlap_generator", False)),
+                           pipeline=getattr(FLAGS, "pipeline_norm", None))
     best = BestSnapshot(trainer, os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), FLAGS)
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))

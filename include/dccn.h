@@ -511,7 +511,21 @@ typedef struct dccn_eq_buffers {
     const float* rx_folded;       /* nullable: dccn_eq_rx_fold(rx_params) -- the frozen receiver's C-Conv and dense layer as one
                                      matrix.  When given, few-row batches (<= 96 frames) run ONE GEMM where the step ran the two
                                      layers (and one on the way back); must be rebuilt whenever rx_params change. */
+    /* Pipelined input normalisation (training, round 4; same idea as dccn_rx_buffers.x_next): the step's first launch -- the
+       batch normalisation of `input:0` -- depends on nothing but x, so the PREVIOUS step can run it for this batch on leading
+       workgroups of its optimizer launch.
+       x_next != NULL   this step also normalises x_next (same shape as x) into the workspace; honoured when
+                        dccn_eq_norm_rides(shape) is 1, otherwise ignored
+       x_prenormalised  1: the workspace already holds the normalisation of x (and its R8 partial sums in slot norm_slot),
+                        written by the previous call through x_next on the SAME workspace: the step starts at the layer norm
+       norm_slot        0/1: the R8 partial-sum slot of THIS batch; x_next's sums go to the other one, so consecutive
+                        pipelined calls alternate it.  Results are bit-identical to un-pipelined calls. */
+    const float* x_next;
+    int x_prenormalised;
+    int norm_slot;
 } dccn_eq_buffers;
+/* 1: dccn_eq_train_step honours dccn_eq_buffers.x_next for this shape */
+int dccn_eq_norm_rides(const dccn_eq_shape* shape);
 
 /* The frozen receiver's linear part folded into one matrix: out [S*2n_sc*2D + 2D] floats = Mf [S*2n_sc, 2D] then bf [2D], with
  * z = out_eq_flat . Mf + bf  ==  dense(C-Conv(out_eq)) of dev/py/model.py:1246-1275 (rows of cyclic-prefix samples are zero

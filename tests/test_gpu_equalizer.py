@@ -601,6 +601,71 @@ def test_generator_on_a_side_stream_trains_the_same_equaliser():
     assert torch.equal(out[0][1], out[1][1])
 
 
+def test_next_batch_normalised_on_the_optimizer_launch_trains_the_same_equaliser():
+    """include/dccn.h dccn_eq_buffers.x_next / x_prenormalised / norm_slot: step i normalises batch i+1 on leading workgroups
+    of its optimizer launch and step i+1 starts at the layer norm (receiver_mp.DeviceEpochLoop pipeline, twin plans sharing
+    one workspace).  (1) the C ABI directly: two pipelined steps == two plain steps, bit for bit (parameters, Adam state,
+    metrics, tx_power of both steps); (2) the harness: 3 epochs of 28 steps (an odd and an even step count both start every
+    epoch on plan 0) with and without the pipeline -> identical history and parameters."""
+    from dl_ofdm_amd import receiver as R, receiver_mp as H
+    from dl_ofdm_amd.engine import glorot_init
+    import ctypes as C
+    from dl_ofdm_amd.equalizer import _FusedPlan
+    from dl_ofdm_amd import ofdm
+    F, tx, ecfg, rcfg, pe, pr, tr = _trainer(seed=23)
+    assert tr.lib.dccn_eq_norm_rides(C.byref(tr.resident(9).shape)) == 1
+    rng = np.random.RandomState(5)
+    xs = [(rng.standard_normal((9, 7, 80, 2)) * 1.5).astype(np.float32) for _ in range(3)]
+    bs = [rng.randint(0, 2, (9, tx.frame_size, 2)).astype(np.int32) for _ in range(3)]
+    start = {n: getattr(tr, n).clone() for n in ("params", "adam_m", "adam_v", "adam_state")}
+
+    def restore():
+        for n, v in start.items():
+            getattr(tr, n).copy_(v)
+
+    def snap(pl):
+        torch.cuda.synchronize()
+        return (tr.params.clone(), tr.adam_m.clone(), tr.adam_v.clone(), tr.adam_state.clone(), pl.metrics_buf.clone(),
+                pl.tx_power.clone(), pl.chest.clone())
+
+    plain = []
+    pl = tr.resident(9)
+    for k in range(3):
+        pl.set_batch(xs[k], bs[k])
+        pl.run(True, graph=False)
+        plain.append(snap(pl))
+    for graph in (False, True):
+        restore()
+        a = _FusedPlan(tr, 9)
+        b = _FusedPlan(tr, 9, twin_of=a)
+        a.pipe_with(b, 0)
+        b.pipe_with(a, 1)
+        a.set_batch(xs[0], bs[0])
+        b.set_batch(xs[1], bs[1])
+        a.run(True, graph=graph, pipe=0)
+        got = [snap(a)]
+        a.set_batch(xs[2], bs[2])                     # (refilled only after the step that read it was issued: same stream)
+        b.run(True, graph=graph, pipe=1)
+        got.append(snap(b))
+        a.run(True, graph=graph, pipe=1)
+        got.append(snap(a))
+        for k in range(3):
+            for u, v in zip(plain[k], got[k]):
+                assert torch.equal(u, v), (graph, k)
+        a.close()
+        b.close()
+    out = []
+    for pipe in (False, True):
+        hf = H.Flags(nbits=2, nfilter=64, channel="EPA", msg_length=7 * 2048, batch_size=512, max_epoch_num=3,
+                     early_stop=100, token="PN", save_dir="/tmp/_eq_pipe_%d/" % pipe, seed=6, eval_frames=512,
+                     device_data=True, pipeline_norm=pipe)
+        o = ofdm.ofdm_tx(hf)
+        res = H.train(hf, verbose=False, run_test=False, rx_params=glorot_init(R.rx_dims(hf, o), 1))
+        out.append((res["history"], res["trainer"].params.detach().clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+
+
 def test_equalizer_harness_on_device_generated_data():
     """receiver_mp.train(device_data=True): bits, frames, fading, noise and the true channel response all come
     from the GPU generator; same learning criterion as the host-data test above."""

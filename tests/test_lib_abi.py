@@ -43,6 +43,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.RxBuffers) == 24 * 8          # ... + x_next_ready
 
 
+
 def test_host_side_queries(lib):
     from dl_ofdm_amd import _lib
     assert lib.dccn_version() >= 100

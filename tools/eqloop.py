@@ -73,7 +73,12 @@ def main():
                 ("step_eager", step_eager)]
     if hasattr(M, "device_epoch_runner"):
         variants.insert(0, ("r04_loop_generator_on_side_stream", M.device_epoch_runner(F, o, tr, gen, pl, overlap=True)))
-        variants.insert(0, ("r04_loop", M.device_epoch_runner(F, o, tr, gen, pl)))
+        try:
+            variants.insert(0, ("r04_loop_next_batch_normalised_on_the_optimizer_launch",
+                                M.device_epoch_runner(F, o, tr, gen, pl, pipeline=True)))
+            variants.insert(0, ("r04_loop", M.device_epoch_runner(F, o, tr, gen, pl, pipeline=False)))
+        except TypeError:                                             # (an older package)
+            variants.insert(0, ("r04_loop", M.device_epoch_runner(F, o, tr, gen, pl)))
     for name, fn in variants:
         for _ in range(30):
             fn()
