@@ -69,7 +69,8 @@ enum TuneKey : int {
     TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
     TUNE_ADAM_NT = 22,          // 1: large arenas: the optimizer launch loads the gradient with non-temporal hints
     TUNE_DENSE_FWD_BIG = 23,    // > 0: dense + tail variant of LARGE layers (14 / 15: 160x64 tiles, 16: 128x64) instead of 80x64
-    TUNE_COUNT = 24
+    TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
+    TUNE_COUNT = 25
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -98,7 +99,7 @@ struct TuneTable {
 //   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
 //   22 = 0  non-temporal gradient loads in the optimizer launch of large arenas: C4 step 4933 vs 4898 us -- slower, off;
 //   23 = 0  160x64 / 128x64 tiles for the fused dense + tail launch of large layers: C4 step 5012 / 5423 vs 4933 us with 80x64 -- off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -2298,8 +2299,12 @@ int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, co
     float* pw1 = pb2 + (size_t)tiles * SK2;
     float* pb1 = pw1 + (size_t)tiles * SK2 * P;
     auto kern = P == 32 ? eq_bottleneck_bwd_kernel<2> : eq_bottleneck_bwd_kernel<1>;
+    EqRideArgs no_ride;
+    memset(&no_ride, 0, sizeof(no_ride));
+    dccn_adam_hparams no_hp;
+    memset(&no_hp, 0, sizeof(no_hp));
     hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
-                       pw1, pb1, B, SK2, q);
+                       pw1, pb1, B, SK2, q, tiles, no_ride, no_hp);
     DCCN_LAUNCH_CHECK();
     // (the fused equaliser step leaves these sums to its optimizer launch)
     DCCN_TRY(launch_splitk_reduce2(pw2, tiles, (long long)P * SK2, dW2, (long long)P * SK2, pb2, (long long)SK2, db2, (long long)SK2, s));

@@ -141,8 +141,15 @@ __global__ __launch_bounds__(256) void eq_bottleneck_bwd_kernel(const float* __r
                                                                 float* __restrict__ dy_out, float* __restrict__ pW2,
                                                                 float* __restrict__ pb2, float* __restrict__ pW1,
                                                                 float* __restrict__ pb1, const int B, const int SK2,
-                                                                const int q) {
+                                                                const int q, const int row_tiles, const EqRideArgs ride,
+                                                                const dccn_adam_hparams hp) {
     constexpr int P = 16 * NP;
+    // grid rows behind the batch's row tiles: optimizer riders (eq_opt.h EqRideArgs), dispatched after every block of the
+    // launch's own work
+    if ((int)blockIdx.y >= row_tiles) {
+        eq_ride_body(ride, hp, ((int)blockIdx.y - row_tiles) * (int)gridDim.x + (int)blockIdx.x);
+        return;
+    }
     __shared__ float part[4][16][P + 1];
     __shared__ float g1[16][P + 1];                       // dd1 tile (rows past the batch are zero)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;

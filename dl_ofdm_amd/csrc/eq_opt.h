@@ -32,10 +32,12 @@ struct EqOptJob {
     int kin, F;              // CCONV_FOLD: kin, F; CONV2D_FOLD: L, W
 };
 constexpr int kEqOptJobs = 24;
-struct EqOptArgs {
+struct EqOptPtrs {
     float* param; float* grad; float* m; float* v;
     const float* reg_coef;
     const dccn_adam_state* state;
+};
+struct EqOptArgs : EqOptPtrs {
     int njobs;
     EqOptJob job[kEqOptJobs];
     TailFinalizeArgs fin;
@@ -50,7 +52,7 @@ struct EqOptArgs {
 struct AdamCoef {
     float alpha, omb1, omb2, eps;
 };
-__device__ __forceinline__ void eq_adam_one(const EqOptArgs& a, const AdamCoef& k, const long long j, const float g) {
+__device__ __forceinline__ void eq_adam_one(const EqOptPtrs& a, const AdamCoef& k, const long long j, const float g) {
     float p = a.param[j], mm = a.m[j], vv = a.v[j];
     const float ge = g + (a.reg_coef ? a.reg_coef[j] : 0.f) * p;
     mm += (ge - mm) * k.omb1;
@@ -59,7 +61,7 @@ __device__ __forceinline__ void eq_adam_one(const EqOptArgs& a, const AdamCoef& 
     a.param[j] = p; a.m[j] = mm; a.v[j] = vv;
 }
 
-__device__ __forceinline__ void eq_opt_sum(const EqOptArgs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
+__device__ __forceinline__ void eq_opt_sum(const EqOptPtrs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
     const long long stride = (long long)J.blocks * 256 * 4;
     const float creg = (J.reg_uniform && a.reg_coef) ? a.reg_coef[J.off] : 0.f;      // (uniform address: one scalar load)
     for (long long i = ((long long)bx * 256 + threadIdx.x) * 4; i < J.n; i += stride) {
@@ -236,6 +238,24 @@ __device__ __forceinline__ void eq_opt_conv2d(const EqOptArgs& a, const EqOptJob
         eq_adam_one(a, k, J.off + tap * 2, ga);
         eq_adam_one(a, k, J.off + tap * 2 + 1, gb);
     }
+}
+
+// Optimizer work riding BEHIND another launch's own workgroups (round 4): the Adam update of a dense kernel whose gradient is
+// already complete in the arena is a pure stream (7 arrays, ~22 MB for 896 x 896), and the launches of the backward chain
+// are latency-bound with the memory system idle -- so the two big kernels of the equaliser are updated by extra workgroups
+// of a LATER backward launch that neither reads nor writes them, instead of in the optimizer launch at the end of the chain
+// (which was 16 us, 9 of them these two streams).  Same arithmetic as EQJ_SUM (eq_opt_sum): bit-identical parameters.
+struct EqRideArgs {
+    EqOptPtrs p;
+    int njobs, blocks;
+    EqOptJob job[2];
+};
+__device__ __forceinline__ void eq_ride_body(const EqRideArgs& r, const dccn_adam_hparams& hp, const int bx) {
+    if (bx >= r.blocks) return;
+    const int j = (r.njobs > 1 && bx >= r.job[1].block0) ? 1 : 0;
+    AdamCoef k;
+    k.alpha = r.p.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
+    eq_opt_sum(r.p, r.job[j], k, bx - r.job[j].block0);
 }
 
 __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dccn_adam_hparams hp) {

@@ -155,8 +155,11 @@ static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, 
 
 // optimizer jobs of a dense layer (kernel variable i, bias variable i + 1)
 // (uni: the caller's reg_coef is one value over each dense kernel / bias -- dccn_eq_buffers.reg_uniform)
-static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const DeferredSlabs& ds, long long N, bool uni) {
-    if (ds.dw_slabs) ob.slabs(d.o[i], d.sz[i], ds.dw_slabs, ds.splits, d.sz[i], uni);
+// kernel_done: the kernel variable was updated by a rider of an earlier launch (EqRideArgs)
+static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const DeferredSlabs& ds, long long N, bool uni,
+                         bool kernel_done = false) {
+    if (kernel_done) {}
+    else if (ds.dw_slabs) ob.slabs(d.o[i], d.sz[i], ds.dw_slabs, ds.splits, d.sz[i], uni);
     else ob.plain(d.o[i], d.sz[i], uni);
     if (ds.dw_slabs && ds.db_slabs) ob.slabs(d.o[i + 1], d.sz[i + 1], ds.db_slabs, ds.splits, N, uni);
     else ob.plain(d.o[i + 1], d.sz[i + 1], uni);
@@ -395,6 +398,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_l[EQL_DENSE3],
                                  w.n_l[EQL_DENSE3], s, 1, nullptr, nullptr, keep_slabs ? &ds3 : nullptr));
     const float* dy_sum;
+    bool rode[2] = {false, false};                              // dense_4 / dense_3 kernels updated by riders (below)
     const int bn_tiles = ceil_div(B, 16);
     float* bn_w2 = w.bn_part;                                   // [tiles][P][SK2]
     float* bn_b2 = bn_w2 + (size_t)bn_tiles * d.Pp * SK2;       // [tiles][SK2]
@@ -405,9 +409,30 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         // four weight / bias gradients (summed by the optimizer launch)
         auto kern = d.Pp == 32 ? eq_bottleneck_bwd_kernel<2> : eq_bottleneck_bwd_kernel<1>;
         const int q = eq_bottleneck_q(B, SK2);
-        hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), bn_tiles), dim3(256), 0, s, (const float*)w.dd2, (const float*)w.d1,
-                           (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2, bn_w1, bn_b1, B,
-                           SK2, q);
+        const int nx = ceil_div(SK2 / 16, q);
+        // riders: the Adam updates of dense_3 / dense_4 (their gradients are complete in the arena, nothing from here to the
+        // end of the step touches those kernels) stream behind this launch's own blocks instead of in the optimizer launch
+        EqRideArgs ride;
+        memset(&ride, 0, sizeof(ride));
+        if (g_tune[TUNE_EQ_RIDERS]) {
+            ride.p.param = b->eq_params; ride.p.grad = G; ride.p.m = b->adam_m; ride.p.v = b->adam_v;
+            ride.p.reg_coef = b->reg_coef; ride.p.state = b->adam;
+            for (int li = 0; li < 2; ++li) {
+                const int i = li == 0 ? 10 : 8;
+                const DeferredSlabs& dsl = li == 0 ? ds4 : ds3;
+                if (dsl.dw_slabs != nullptr || (d.sz[i] % 4) != 0) continue;
+                if (g_tune[TUNE_EQ_RIDERS] == 2 + li) continue;          // 2: only dense_3 rides, 3: only dense_4
+
+                EqOptJob& J = ride.job[ride.njobs++];
+                J.kind = EQJ_SUM; J.block0 = ride.blocks; J.blocks = EqOptBuilder::stream_blocks(d.sz[i]); J.splits = 1;
+                J.off = d.o[i]; J.n = d.sz[i]; J.vec = 1; J.reg_uniform = (b->reg_uniform != 0 && b->reg_coef != nullptr) ? 1 : 0;
+                ride.blocks += J.blocks;
+                rode[li] = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3(nx, bn_tiles + ceil_div(ride.blocks, nx)), dim3(256), 0, s, (const float*)w.dd2,
+                           (const float*)w.d1, (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2,
+                           bn_w1, bn_b1, B, SK2, q, bn_tiles, ride, hp);
         DCCN_LAUNCH_CHECK();
         dy_sum = w.dflat;
     } else {
@@ -460,8 +485,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         eq_opt_dense(ob, d, 4, ds1, d.Pp, uni);
         eq_opt_dense(ob, d, 6, ds2, SK2, uni);
     }
-    eq_opt_dense(ob, d, 8, ds3, SK2, uni);
-    eq_opt_dense(ob, d, 10, ds4, SK2, uni);
+    eq_opt_dense(ob, d, 8, ds3, SK2, uni, rode[1]);
+    eq_opt_dense(ob, d, 10, ds4, SK2, uni, rode[0]);
     ob.conv2d_fold(d.o[12], d.o[13], dsT.dw_slabs ? dsT.dw_slabs : w.dT, (dsT.dw_slabs && dsT.db_slabs) ? dsT.db_slabs : w.dbe,
                    dsT.dw_slabs ? dsT.splits : 1, (long long)SK2 * SK2, SK2, d.S, K);
     for (int g = 1; g >= 0; --g) {          // arena order: conv3d_2 (corr, group 1), then conv3d_3 (eq, group 0)
