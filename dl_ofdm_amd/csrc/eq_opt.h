@@ -181,7 +181,7 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ src, const s
 
 // dev/py/complex.py:185-188 with a (S,K) kernel, 'same' padding, one filter, expanded to T[(s',k',iq)][(s,k,re/im)]
 // (equalizer.h cconv2d_same_expand_kernel); its transpose: tap (a,b) gathers its diagonal of dT
-__device__ __forceinline__ void eq_opt_conv2d(const EqOptArgs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
+__device__ __forceinline__ void eq_opt_conv2d(const EqOptPtrs& a, const EqOptJob& J, const AdamCoef& k, const int bx) {
     const int L = J.kin, W = J.F, n = L * W * 2;
     const int padL = (L - 1) / 2, padW = (W - 1) / 2;
     const int tap = bx * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -248,14 +248,16 @@ __device__ __forceinline__ void eq_opt_conv2d(const EqOptArgs& a, const EqOptJob
 struct EqRideArgs {
     EqOptPtrs p;
     int njobs, blocks;
-    EqOptJob job[2];
+    EqOptJob job[3];         // EQJ_SUM (no slabs) / EQJ_CONV2D_FOLD
 };
 __device__ __forceinline__ void eq_ride_body(const EqRideArgs& r, const dccn_adam_hparams& hp, const int bx) {
     if (bx >= r.blocks) return;
-    const int j = (r.njobs > 1 && bx >= r.job[1].block0) ? 1 : 0;
+    int j = 0;
+    while (j + 1 < r.njobs && bx >= r.job[j + 1].block0) ++j;
     AdamCoef k;
     k.alpha = r.p.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
-    eq_opt_sum(r.p, r.job[j], k, bx - r.job[j].block0);
+    if (r.job[j].kind == EQJ_CONV2D_FOLD) eq_opt_conv2d(r.p, r.job[j], k, bx - r.job[j].block0);
+    else eq_opt_sum(r.p, r.job[j], k, bx - r.job[j].block0);
 }
 
 __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dccn_adam_hparams hp) {

@@ -398,6 +398,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     DCCN_TRY(dense_bwd_full_impl(w.d2, w.dd3, P + d.o[8], w.dd2, G + d.o[8], G + d.o[9], B, SK2, SK2, w.ws_l[EQL_DENSE3],
                                  w.n_l[EQL_DENSE3], s, 1, nullptr, nullptr, keep_slabs ? &ds3 : nullptr));
     const float* dy_sum;
+    bool rode_T = false;                                        // the smoothing kernel's fold rode as well
     bool rode[2] = {false, false};                              // dense_4 / dense_3 kernels updated by riders (below)
     const int bn_tiles = ceil_div(B, 16);
     float* bn_w2 = w.bn_part;                                   // [tiles][P][SK2]
@@ -417,6 +418,15 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         if (g_tune[TUNE_EQ_RIDERS]) {
             ride.p.param = b->eq_params; ride.p.grad = G; ride.p.m = b->adam_m; ride.p.v = b->adam_v;
             ride.p.reg_coef = b->reg_coef; ride.p.state = b->adam;
+            if (dsT.dw_slabs == nullptr && g_tune[TUNE_EQ_RIDERS] != 4) {
+                // the smoothing kernel's fold (a gather over the diagonals of dT: latency, not bytes) goes first
+                EqOptJob& J = ride.job[ride.njobs++];
+                J.kind = EQJ_CONV2D_FOLD; J.block0 = ride.blocks; J.blocks = ceil_div(d.S * K + 1, 4); J.splits = 1;
+                J.off = d.o[12]; J.off_b = d.o[13]; J.src = w.dT; J.src2 = w.dbe; J.slab = (long long)SK2 * SK2; J.slab2 = SK2;
+                J.kin = d.S; J.F = K;
+                ride.blocks += J.blocks;
+                rode_T = true;
+            }
             for (int li = 0; li < 2; ++li) {
                 const int i = li == 0 ? 10 : 8;
                 const DeferredSlabs& dsl = li == 0 ? ds4 : ds3;
@@ -487,6 +497,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     }
     eq_opt_dense(ob, d, 8, ds3, SK2, uni, rode[1]);
     eq_opt_dense(ob, d, 10, ds4, SK2, uni, rode[0]);
+    if (!rode_T)
     ob.conv2d_fold(d.o[12], d.o[13], dsT.dw_slabs ? dsT.dw_slabs : w.dT, (dsT.dw_slabs && dsT.db_slabs) ? dsT.db_slabs : w.dbe,
                    dsT.dw_slabs ? dsT.splits : 1, (long long)SK2 * SK2, SK2, d.S, K);
     for (int g = 1; g >= 0; --g) {          // arena order: conv3d_2 (corr, group 1), then conv3d_3 (eq, group 0)
