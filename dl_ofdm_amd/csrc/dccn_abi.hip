@@ -69,8 +69,9 @@ enum TuneKey : int {
     TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
     TUNE_ADAM_NT = 22,          // 1: large arenas: the optimizer launch loads the gradient with non-temporal hints
     TUNE_DENSE_FWD_BIG = 23,    // > 0: dense + tail variant of LARGE layers (14 / 15: 160x64 tiles, 16: 128x64) instead of 80x64
+    TUNE_ADAM_OVERLAP = 25,     // 1: large layers: the dense kernel's Adam update runs on a second stream next to the C-Conv weight-gradient launch
     TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
-    TUNE_COUNT = 25
+    TUNE_COUNT = 26
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -99,7 +100,7 @@ struct TuneTable {
 //   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
 //   22 = 0  non-temporal gradient loads in the optimizer launch of large arenas: C4 step 4933 vs 4898 us -- slower, off;
 //   23 = 0  160x64 / 128x64 tiles for the fused dense + tail launch of large layers: C4 step 5012 / 5423 vs 4933 us with 80x64 -- off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}}};
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -1179,6 +1180,29 @@ static size_t rx_ws_bytes(const dccn_rx_shape* sh, int train) {
     return align_up(o, 256);
 }
 
+// The library's own second stream (one per device) and a pair of events per host thread: large layers run the dense kernel's
+// optimizer update -- 3.2 GB of pure HBM traffic at N = 1024 -- NEXT TO the MFMA-bound C-Conv weight-gradient launch instead
+// of behind it.  (Two kernels of one stream never overlap; blocks of two streams share the CUs.)
+struct OverlapStreams {
+    hipStream_t side;
+    hipEvent_t fork, join;
+};
+static bool overlap_streams(OverlapStreams* o) {
+    static std::mutex mu;
+    static hipStream_t sides[64];
+    thread_local hipEvent_t ev[64][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!sides[dev] && hipStreamCreateWithFlags(&sides[dev], hipStreamNonBlocking) != hipSuccess) { sides[dev] = nullptr; return false; }
+    }
+    for (int k = 0; k < 2; ++k)
+        if (!ev[dev][k] && hipEventCreateWithFlags(&ev[dev][k], hipEventDisableTiming) != hipSuccess) { ev[dev][k] = nullptr; return false; }
+    o->side = sides[dev]; o->fork = ev[dev][0]; o->join = ev[dev][1];
+    return true;
+}
+
 // side != nullptr: run the dense weight-gradient branch on `side` (fork/join by events),
 // concurrently with dX -> C-Conv weight gradient on the main stream.
 static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
@@ -1240,6 +1264,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     DeferredSlabs ds;
     FoldDefer fd;
     fd.slabs = nullptr;
+    OverlapStreams ovs{};
+    bool overlap = false;                 // the dense kernel's update runs on ovs.side (large layers)
     int fold_tilew = 0;
     const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
     // small layers: dX tiles + C-Conv weight-gradient partials in their epilogue + dW items + tail finalize: one launch
@@ -1290,6 +1316,15 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
             const long long bigx = (long long)ceil_div(sh->batch, 128) * ceil_div(L.dK, 128);
             const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
+            // round 4: the same layers, the update as a launch of its own on the library's second stream, next to the C-Conv
+            // weight-gradient launch (same precondition: alpha and the BER gate must exist before it starts)
+            if (g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
+                (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0 && overlap_streams(&ovs)) {
+                hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
+                DCCN_LAUNCH_CHECK();
+                fin.metrics = nullptr;
+                overlap = true;
+            }
             if (g_tune[TUNE_ADAM_IN_DW] && g_tune[TUNE_DENSE_BWD_BIG] && sp.splits == 1 && bigx >= 2 * kCUs && bigw >= 2 * kCUs &&
                 (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0) {
                 hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
@@ -1304,6 +1339,28 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         }
         DCCN_TRY(dense_bwd_grouped_impl(b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_w, G + L.o_dense_b,
                                         sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds, aep));
+        if (overlap && (ds.dw_slabs != nullptr || ds.adam_done)) overlap = false;
+        if (overlap) {
+            // the optimizer kernel itself, restricted to the dense kernel's segment: same arithmetic, same results
+            AdamRxArgs as;
+            memset(&as, 0, sizeof(as));
+            as.param = P; as.grad = G; as.m = b->adam_m; as.v = b->adam_v;
+            as.reg_coef = b->reg_coef; as.reg_gate = b->reg_coef ? &b->metrics->berlin : nullptr;
+            as.state = b->adam;
+            as.o_dw = L.o_dense_w; as.n_dw = (long long)L.dK * L.dN; as.o_db = L.o_dense_b; as.n_db = L.dN;
+            as.n = as.o_dw + as.n_dw;
+            as.skip_lo = 0; as.skip_hi = as.o_dw;                 // (everything in front of the dense kernel stays with the main launch)
+            as.splits = 1; as.neps = 1e-9f; as.npeak = 8.0f;
+            as.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
+            as.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
+            long long sb = ceil_div_ll(ceil_div_ll(as.n, 4), 256);
+            if (sb > 8 * kCUs) sb = 8 * kCUs;                     // (2, 4, 16 per CU measured within 0.5 % of this)
+            DCCN_HIP(hipEventRecord(ovs.fork, s));
+            DCCN_HIP(hipStreamWaitEvent(ovs.side, ovs.fork, 0));
+            hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)sb), dim3(256), 0, ovs.side, as, hp);
+            DCCN_LAUNCH_CHECK();
+            DCCN_HIP(hipEventRecord(ovs.join, ovs.side));
+        }
     }
     // C-Conv dW/db from dX (the C-Conv input is data: no dX of its own)
     // (its fold launch also carries the tail's slab reduction: metrics, tail gradients, tx_power)
@@ -1312,6 +1369,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    if (overlap) DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
@@ -1330,7 +1388,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
     // large arenas (N = 1024: 0.47 GB of gradient, far beyond the 256 MB Infinity Cache) are pure streams
     aa.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
-    if (ds.adam_done) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
+    if (ds.adam_done || overlap) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
     aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, fold_tilew > 0 ? kFoldLanesTiled : kRedLanes) : 0;
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
     if (blocks > 8 * kCUs) blocks = 8 * kCUs;
