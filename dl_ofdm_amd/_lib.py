@@ -51,8 +51,7 @@ class RxBuffers(C.Structure):
                 ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
-                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p),
-                ("fwd_prefetch", c_int)]
+                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p)]
 
 
 class EqShape(C.Structure):
@@ -151,7 +150,6 @@ SIGNATURES = {
     "dccn_stream_synchronize": (_i, [_vp]),
     "dccn_eq_rx_folded_floats": (_sz, [POINTER(EqShape)]),
     "dccn_eq_norm_rides": (_i, [POINTER(EqShape)]),
-    "dccn_rx_prefetches_forward": (_i, [POINTER(RxShape)]),
     "dccn_eq_rx_fold": (_i, [POINTER(EqShape), _vp, _vp, _vp]),
     "dccn_eq_monitor_workspace_size": (_sz, [_i, _i, _i]),
     "dccn_eq_monitor_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1203,16 +1203,6 @@ static bool overlap_streams(OverlapStreams* o) {
     return true;
 }
 
-// which shapes take the large-layer plan of round 4 (dense kernel's update on the second stream, optional forward prefetch)
-static bool can_defer_of(const RxLayout& L) { return L.o_conv_w == 0 && (L.o_dense_w % 4) == 0; }
-static bool rx_big_layer_plan(const dccn_rx_shape* sh, const RxLayout& L, bool can_defer) {
-    const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
-    const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
-    return g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && g_tune[TUNE_DENSE_BWD_BIG] && sp.splits == 1 && bigw >= 2 * kCUs &&
-           can_defer && (((long long)L.dK * L.dN) % 4) == 0 &&
-           !rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, nullptr, nullptr, nullptr, nullptr);
-}
-
 // side != nullptr: run the dense weight-gradient branch on `side` (fork/join by events),
 // concurrently with dX -> C-Conv weight gradient on the main stream.
 static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
@@ -1276,7 +1266,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     fd.slabs = nullptr;
     OverlapStreams ovs{};
     bool overlap = false;                 // the dense kernel's update runs on ovs.side (large layers)
-    const bool big_plan = rx_big_layer_plan(sh, L, can_defer_of(L));
     int fold_tilew = 0;
     const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
     // small layers: dX tiles + C-Conv weight-gradient partials in their epilogue + dW items + tail finalize: one launch
@@ -1329,7 +1318,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
             // round 4: the same layers, the update as a launch of its own on the library's second stream, next to the C-Conv
             // weight-gradient launch (same precondition: alpha and the BER gate must exist before it starts)
-            if (big_plan && overlap_streams(&ovs)) {
+            if (g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
+                (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0 && overlap_streams(&ovs)) {
                 hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
                 DCCN_LAUNCH_CHECK();
                 fin.metrics = nullptr;
@@ -1379,6 +1369,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    if (overlap) DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0));
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
@@ -1441,12 +1432,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(norm_impl(b->x_next, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &np, sh->batch, L.cols, 1e-9f,
                            8.0f, nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
-    // large layers: the next batch's C-Conv forward (its normalisation is in x_norm, the C-Conv kernel has just been updated,
-    // fft_out was last read by the dense weight gradient) -- more MFMA-bound work for the dense kernel's optimizer stream on
-    // the second stream to hide behind; the following call starts at R2 (x_prenormalised = 2)
-    if (big_plan && !fuse_bw && !side && b->fwd_prefetch != 0 && b->x_next != nullptr && !ride_bw)
-        DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
-    if (overlap) DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0));       // the step is complete on `s` only with the dense kernel's update
     return DCCN_OK;
 }
 
@@ -1691,11 +1676,6 @@ int dccn_rx_dense_tail_fused(const dccn_rx_shape* sh, int train) {
     if (!shape_ok(sh)) return 0;
     return dense_tail_planned(sh->nbits, train != 0, sh->batch, 2 * sh->D) &&
            dense_tail_shape_ok(sh->batch, sh->S * 2 * sh->F, 2 * sh->D, sh->nbits) ? 1 : 0;
-}
-int dccn_rx_prefetches_forward(const dccn_rx_shape* sh) {
-    if (!shape_ok(sh)) return 0;
-    const RxLayout L = rx_layout(sh);
-    return rx_big_layer_plan(sh, L, can_defer_of(L)) ? 1 : 0;
 }
 int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {
     if (!shape_ok(sh)) return 0;

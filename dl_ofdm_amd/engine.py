@@ -139,8 +139,7 @@ class RxEngine:
                                  p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
                                  p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0, 0, 0, 1 if want_grads else 0,
                                  1,       # reg_uniform_dense: self.reg_coef is one value over the dense kernel (above)
-                                 0,       # x_next_ready
-                                 0)       # fwd_prefetch
+                                 0)       # x_next_ready
         # pipelined training, double-buffered: the next batch is normalised into the OTHER x_norm buffer by leading blocks of
         # the backward launch (dccn.h: x_norm_next / norm_slot); `x_norm` stays the buffer plain steps use (parity 0)
         self._norm_bufs = [self.x_norm, None]
@@ -149,8 +148,6 @@ class RxEngine:
         self._ride = int(self.lib.dccn_rx_norm_rides_backward(C.byref(self.shape))) if train else 0
         if self._ride:
             self._norm_bufs[1] = torch.empty_like(self.x_norm)
-        # large layers (dccn.h fwd_prefetch): a pipelined step also runs the next batch's C-Conv forward as its last launch
-        self._pf_single = bool(self.lib.dccn_rx_prefetches_forward(C.byref(self.shape))) if train else False
         # the same buffers in the pipelined mode (dccn.h: x_next / x_prenormalised), built on demand per (label slot, last)
         self._pipe_bufs = {}
         self.bits_alt = None                 # second label buffer: the generator fills it while a step reads the first
@@ -240,7 +237,6 @@ class RxEngine:
             vals["norm_slot"] = parity
             vals["x_norm_next"] = self._norm_bufs[parity ^ 1].data_ptr() if (double and not last) else 0
             vals["x_next_ready"] = 0 if last else ready
-            vals["fwd_prefetch"] = 1 if (self._pf_single and not last) else 0
             self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
         return self._pipe_bufs[key]
 
@@ -284,8 +280,6 @@ class RxEngine:
             if double and not last:
                 self._norm_parity ^= 1           # the prefetched batch sits in the other buffer ...
                 self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out
-            elif self._pf_single and not last:
-                self._fwd_prefetched = True      # large layers: the step's last launch was that batch's C-Conv forward
         self._prefetch_pending = not last
         if last:
             self._norm_ready = False

@@ -353,15 +353,7 @@ typedef struct dccn_rx_buffers {
        stream while the forward and backward launches of this step run (the device-side generator: dl_ofdm_amd/datagen.py
        SideStreamFeeder).  Eager launches only (not inside dccn_rx_graph_create). */
     void* x_next_ready;
-    /* Large layers (round 4; honoured when dccn_rx_prefetches_forward(shape) is 1): a training step given x_next also runs
-       the C-Conv forward of that batch into fft_out as its last launch, and the following call is told so with
-       x_prenormalised = 2.  Why: the dense kernel's optimizer update of such layers (3.2 GB of HBM traffic at N = 1024) runs
-       on the library's second stream next to the MFMA-bound launches at the end of the step -- the C-Conv weight gradient,
-       and with this flag the next batch's C-Conv forward as well -- instead of behind them. */
-    int fwd_prefetch;
 } dccn_rx_buffers;
-/* 1: dccn_rx_train_step honours dccn_rx_buffers.fwd_prefetch for this shape */
-int dccn_rx_prefetches_forward(const dccn_rx_shape* shape);
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
 int dccn_rx_bwd_fused_supported(const dccn_rx_shape* shape);
