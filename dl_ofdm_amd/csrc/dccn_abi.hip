@@ -70,6 +70,7 @@ enum TuneKey : int {
     TUNE_ADAM_NT = 22,          // 1: large arenas: the optimizer launch loads the gradient with non-temporal hints
     TUNE_DENSE_FWD_BIG = 23,    // > 0: dense + tail variant of LARGE layers (14 / 15: 160x64 tiles, 16: 128x64) instead of 80x64
     TUNE_ADAM_OVERLAP = 25,     // 1: large layers: the dense kernel's Adam update runs on a second stream next to the C-Conv weight-gradient launch
+                                //    2: ... with non-temporal loads and stores (it must not displace the GEMM's operand panels)
     TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
     TUNE_COUNT = 26
 };
@@ -100,7 +101,11 @@ struct TuneTable {
 //   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
 //   22 = 0  non-temporal gradient loads in the optimizer launch of large arenas: C4 step 4933 vs 4898 us -- slower, off;
 //   23 = 0  160x64 / 128x64 tiles for the fused dense + tail launch of large layers: C4 step 5012 / 5423 vs 4933 us with 80x64 -- off.
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {1}}};
+//   24 = 1  equaliser step: Adam updates of dense_3 / dense_4 and the smoothing kernel's fold as riders of the bottleneck backward
+//           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
+//   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
+//           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
+static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -1195,7 +1200,14 @@ static bool overlap_streams(OverlapStreams* o) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!sides[dev] && hipStreamCreateWithFlags(&sides[dev], hipStreamNonBlocking) != hipSuccess) { sides[dev] = nullptr; return false; }
+        if (!sides[dev]) {
+            // lowest priority: its own hardware queue (streams of one priority share a small pool of queues round-robin, and a
+            // stream that lands on the main stream's queue does not overlap with it at all), and the MFMA-bound launch it
+            // runs next to is served first whenever a CU has room
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            if (hipStreamCreateWithPriority(&sides[dev], hipStreamNonBlocking, least) != hipSuccess) { sides[dev] = nullptr; return false; }
+        }
     }
     for (int k = 0; k < 2; ++k)
         if (!ev[dev][k] && hipEventCreateWithFlags(&ev[dev][k], hipEventDisableTiming) != hipSuccess) { ev[dev][k] = nullptr; return false; }
@@ -1352,7 +1364,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             as.skip_lo = 0; as.skip_hi = as.o_dw;                 // (everything in front of the dense kernel stays with the main launch)
             as.splits = 1; as.neps = 1e-9f; as.npeak = 8.0f;
             as.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
-            as.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
+            as.nt = g_tune[TUNE_ADAM_OVERLAP] >= 2 ? 2 : ((g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0);
             long long sb = ceil_div_ll(ceil_div_ll(as.n, 4), 256);
             if (sb > 8 * kCUs) sb = 8 * kCUs;                     // (2, 4, 16 per CU measured within 0.5 % of this)
             DCCN_HIP(hipEventRecord(ovs.fork, s));

@@ -569,7 +569,18 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
         const bool full = cnt == 4;
         // everything this element needs is requested up front (independent loads), summed afterwards
         float4 p4, m4, v4, c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (full) {
+        if (full && a.nt >= 2) {
+            // (nt = 2: the launch shares the chip with an MFMA-bound GEMM on another stream -- nothing it touches should
+            // displace that kernel's operand panels from the caches)
+            const nt_f32x4 tp = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.param + i));
+            const nt_f32x4 tm = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.m + i));
+            const nt_f32x4 tv = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.v + i));
+            p4 = make_float4(tp[0], tp[1], tp[2], tp[3]);
+            m4 = make_float4(tm[0], tm[1], tm[2], tm[3]);
+            v4 = make_float4(tv[0], tv[1], tv[2], tv[3]);
+            if (uni && i >= a.o_dw && i < a.o_dw + a.n_dw) c4 = make_float4(cdw, cdw, cdw, cdw);
+            else if (a.reg_coef) c4 = *reinterpret_cast<const float4*>(a.reg_coef + i);
+        } else if (full) {
             p4 = *reinterpret_cast<const float4*>(a.param + i);
             m4 = *reinterpret_cast<const float4*>(a.m + i);
             v4 = *reinterpret_cast<const float4*>(a.v + i);
@@ -642,7 +653,12 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
             vv[e] += (ge * ge - vv[e]) * omb2;
             p[e] -= (mm[e] * alpha) / (sqrtf(vv[e]) + hp.eps);
         }
-        if (full) {
+        if (full && a.nt >= 2) {
+            nt_f32x4 sp = {p[0], p[1], p[2], p[3]}, sm = {mm[0], mm[1], mm[2], mm[3]}, sv = {vv[0], vv[1], vv[2], vv[3]};
+            __builtin_nontemporal_store(sp, reinterpret_cast<nt_f32x4*>(a.param + i));
+            __builtin_nontemporal_store(sm, reinterpret_cast<nt_f32x4*>(a.m + i));
+            __builtin_nontemporal_store(sv, reinterpret_cast<nt_f32x4*>(a.v + i));
+        } else if (full) {
             *reinterpret_cast<float4*>(a.param + i) = make_float4(p[0], p[1], p[2], p[3]);
             *reinterpret_cast<float4*>(a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
             *reinterpret_cast<float4*>(a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
