@@ -379,7 +379,12 @@ int dccn_rx_backward(const float* x_norm, const float* fft_out, const float* dz,
                      float* dw_dense, float* db_dense, float* dw_conv, float* db_conv, int batch, int S, int kin, int F,
                      int D, int reduce, void* workspace, size_t workspace_bytes, dccn_stream_t stream);
 size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train);
-/* eager launch sequences */
+/* eager launch sequences.
+ * Large layers (an unsplit dense weight gradient of >= 512 tiles of 128x128, e.g. N = 1024: a 459 MB dense kernel): the training
+ * step forks the dense kernel's optimizer update onto a stream the LIBRARY owns (one per device, lowest priority, created on
+ * first use) and joins it before its last launch, so that this 3.2 GB stream runs next to the MFMA-bound C-Conv
+ * weight-gradient launch.  Nothing changes for the caller: every effect of the step is ordered on `stream` when the call
+ * returns, results are bit-identical, and dccn_rx_graph_create captures the fork and the join with the rest. */
 int dccn_rx_eval_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf, dccn_stream_t stream);
 int dccn_rx_train_step(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
                        dccn_adam_hparams hp, dccn_stream_t stream);
