@@ -26,8 +26,14 @@ SNRS = tuple(range(-10, 30))
 
 def init_distributed(backend: Optional[str] = None):
     """(rank, world, local device index); joins the torch.distributed job described by the environment, if any.
-    backend: ``nccl`` (= RCCL over xGMI, one rank per GPU; default) or ``gloo`` (control-flow tests with ranks sharing a
-    device); also taken from ``DCCN_DIST_BACKEND``."""
+    backend: ``nccl`` (= RCCL over xGMI, one rank per GPU; default) or ``gloo`` (ranks may share a device: rank r works on
+    GPU ``LOCAL_RANK % n_gpus``); also taken from ``DCCN_DIST_BACKEND``.
+
+    Ranks sharing a GPU are not only a test device: config 5's training chains are latency-bound sequences of 73-frame steps
+    that keep a few percent of an MI355X busy each, and independent processes own independent hardware queues, so
+    ``torchrun --nproc-per-node 4 ... tools/config5_sweep.py --backend gloo`` on ONE GPU trains the four modulations next to
+    each other (profiles/r04_config5_4ranks_1gpu).  Every model is still trained by exactly one rank with its own seeds: the
+    result does not depend on the sharing."""
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
