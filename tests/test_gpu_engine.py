@@ -358,6 +358,50 @@ def test_double_buffered_normalisation_on_the_backward_launch_is_bitwise(placeme
         lib.dccn_set_tuning(18, default)
 
 
+def test_large_layer_optimizer_stream_overlap_is_bitwise_neutral():
+    """Tuning knob 25 (include/dccn.h "eager launch sequences"): large layers run the dense kernel's Adam update on the
+    library's own low-priority stream next to the C-Conv weight-gradient launch, with non-temporal loads and stores (2) or
+    plain ones (1).  Same kernel on the same operands: three steps (plain and pipelined) must leave parameters, both Adam
+    moments, probabilities and metrics bit-identical to the one-stream order (0) -- a missing fork / join edge shows up as a
+    half-updated kernel, a stale BER gate or a wrong alpha.  N = 512 / CP = 40 / D = 2000 with 48 frames: 1792 dW tiles of
+    128x128, one k range."""
+    from dl_ofdm_amd import _lib
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    lib = _lib.load()
+    dims = RxDims(S=7, kin=552, F=512, D=2000, nbits=2)
+    frames = 48
+    rng = np.random.RandomState(5)
+    xs = [rng.standard_normal((frames, 7, 552, 2)).astype(np.float32) for _ in range(3)]
+    bs = [rng.randint(0, 2, (frames, 2000, 2)).astype(np.int32) for _ in range(3)]
+
+    def run(pipelined):
+        e = RxEngine(dims, frames, train=True, seed=4, want_prob=True)
+        if pipelined:
+            e.prime(xs[0])
+            for k in range(3):
+                e.train_step_pipelined(next_x=xs[(k + 1) % 3], bits=bs[k], last=(k == 2))
+        else:
+            for k in range(3):
+                e.train_step(xs[k], bs[k])
+        torch.cuda.synchronize()
+        return e.params.clone(), e.adam_m.clone(), e.adam_v.clone(), e.prob.clone(), e.metrics()
+    default = lib.dccn_get_tuning(25)
+    try:
+        out = {}
+        for v in (0, 1, 2):
+            assert lib.dccn_set_tuning(25, v) == 0
+            out[v] = (run(False), run(True))
+    finally:
+        lib.dccn_set_tuning(25, default)
+    for v in (1, 2):
+        for mode in (0, 1):
+            for a, b in zip(out[0][mode][:4], out[v][mode][:4]):
+                assert torch.equal(a, b), (v, mode)
+            assert out[0][mode][4] == out[v][mode][4]
+    for a, b in zip(out[0][0][:3], out[0][1][:3]):          # and the pipelined order equals the plain one
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("key,value", [(0, 2), (0, 1), (0, 0), (1, 0), (1, 3), (2, 1), (3, 0), (3, 1), (4, 3), (5, 32), (7, 0), (8, 0),
                                        (9, 0), (10, 0), (11, 0), (12, 0), (14, 0), (14, 3)])
 def test_every_tuning_setting_computes_the_same_step(key, value):
