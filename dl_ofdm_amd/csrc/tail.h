@@ -283,13 +283,19 @@ __device__ __forceinline__ void tail_block_reduce(TailLaneAcc<NB, BWD>& A, float
     if constexpr (BWD) {
         // gradients: sum over the 4 lanes of a quad on the DPP crossbar (2 adds per value instead of a full wave
         // reduction per value), park the quad sums per parameter in LDS ...
+        // (the stores stand in ONE exec-mask region behind the sums: written inside the loop above, each of the P conditional
+        // stores was its own s_and_saveexec / s_or pair -- 92 of them for 8-QAM)
         const int quad = threadIdx.x >> 2;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             float v = A.g[i];
             v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 0));
             v += __builtin_bit_cast(float, dpp_mov_i32(__builtin_bit_cast(int, v), 1));
-            if ((lane & 3) == 0) smat[quad * PS + i] = v;
+            A.g[i] = v;
+        }
+        if ((lane & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) smat[quad * PS + i] = A.g[i];
         }
     }
     __syncthreads();
