@@ -248,7 +248,12 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
  * (default 0: measured slower), 17 few-row dense backward as one grid (default 1), 18 R0 of the next batch on the
  * backward launch of double-buffered pipelined steps (default 0), 19 equaliser step: element-wise stages in GEMM
  * stores (1 few-row tiles, 2 = default: also larger batches), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
- * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2, 3 = the re-plan without the fused pilot bottleneck).
+ * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2, 3 = the re-plan without the fused pilot bottleneck),
+ * 21 few-row GEMMs (<= 96 rows) on one-latency 16x16 tiles (default 1), 22 non-temporal gradient loads in the optimizer launch of large
+ * arenas (default 0), 23 tile shape of the fused dense + tail launch of large layers (default 0 = 80x64), 24 equaliser step: the Adam
+ * updates of dense_3 / dense_4 and the smoothing kernel's gradient fold ride behind the pilot bottleneck's backward launch (default 1),
+ * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream next to the C-Conv weight-gradient launch
+ * (0 off, 1 on, 2 = default: with non-temporal loads and stores).
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
