@@ -514,6 +514,18 @@ def main():
                                                           if pipeline else ", 6 launches per step"),
                    "parallelism": "independent batch per GPU, final all-reduce of the BER/loss table"},
     }
+    # what the N > 1 line rests on: backend, library version, the one collective of the timed region
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:
+        rccl = None
+    result["distributed"] = {
+        "world": world, "backend": backend if world > 1 else "none (1 rank)", "rccl_version": rccl,
+        "devices_visible": ndev, "rank_device": "cuda:%d" % local,
+        "collective": ("one all-reduce of the [6] float64 BER/loss table per timed region (+ one MAX all-reduce of the clock, "
+                       "outside it)") if world > 1 else "none (1 rank)",
+        "units_per_rank": {"steps": args.steps, "frames_per_step": c["frames"]},
+        "points_per_rank": None}
     if rank == 0:
         fl = step_flops(c)
         result["step"] = {"algorithmic_gflop": fl / 1e9, "achieved_tflops": fl / (ms_per_step * 1e-3) / 1e12,
@@ -589,6 +601,7 @@ def main():
     if rank == 0:
         if sweep_res is not None:
             result["sweep"] = sweep_res
+            result["distributed"]["points_per_rank"] = sweep_res.get("points_per_rank")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()

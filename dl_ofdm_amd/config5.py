@@ -177,20 +177,33 @@ def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str
 CLASSICAL_METHODS = ("LMMSE", "LS-Spline", "Perfect")
 
 
+def classical_workers(nbits_list: Sequence[int], world: int) -> list:
+    """the ranks that compute the classical units: those WITHOUT a training chain when there are any (8 GPUs: ranks 4-7 --
+    they do it while ranks 0-3 train, so the stage leaves the critical path), every rank otherwise"""
+    owners = set(job_owners(nbits_list, world).values())
+    free = [r for r in range(max(world, 1)) if r not in owners]
+    return free if free else list(range(max(world, 1)))
+
+
 def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: Sequence[int], n_frames: int,
                      rank: int = 0, world: int = 1, group=None, seed: int = 5, methods: Sequence[str] = CLASSICAL_METHODS,
-                     device=None):
+                     device=None, workers: Optional[Sequence[int]] = None, reduce: bool = True, table=None):
     """The LMMSE / LS baseline curves (dev/m/OFDM_Benchmark_dev.m:339-456 via dl_ofdm_amd.benchmark), one unit per
-    (modulation, channel, estimator, SNR) -- each with its own seeded draws -- dealt round-robin to the ranks; ONE
-    all-reduce of the [units, 2] table {bit errors, bits}.  ``device``: run them on that GPU (benchmark_gpu: device-side
-    generator + libdccn receivers) instead of the host NumPy restatement.  Returns {(nbits, channel, method): BER per csnr}."""
+    (modulation, channel, estimator, SNR) -- each with its own seeded draws -- dealt round-robin to the ``workers`` (default:
+    every rank); ONE all-reduce of the [units, 2] table {bit errors, bits}.  ``device``: run them on that GPU (benchmark_gpu:
+    device-side generator + libdccn receivers) instead of the host NumPy restatement.  Returns {(nbits, channel, method):
+    BER per csnr} -- or, with reduce=False, this rank's un-reduced table (pass it back as ``table`` with reduce=True later:
+    the two halves of the stage may lie on either side of the training stage)."""
     import torch
     from . import benchmark, receiver as R, sweep
     units = [(b, ch, m, i) for b in nbits_list for ch in channels for m in methods for i in range(len(csnr))]
-    table = torch.zeros(len(units), 2, dtype=torch.float64)
+    workers = list(workers) if workers is not None else list(range(max(world, 1)))
+    have = table is not None
+    if not have:
+        table = torch.zeros(len(units), 2, dtype=torch.float64)
     cache = {}
     for u, (b, ch, m, i) in enumerate(units):
-        if u % max(world, 1) != rank:
+        if have or rank not in workers or workers[u % len(workers)] != rank:
             continue
         key = (b, ch, m)
         if key not in cache:
@@ -201,6 +214,8 @@ def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: S
                 cache[key] = benchmark.CurvePoints(R.Flags(nbits=b, channel=ch), m, n_frames=n_frames, seed=seed)
         e, n = cache[key].point(i, float(csnr[i]))
         table[u, 0], table[u, 1] = e, n
+    if not reduce:
+        return table
     if world > 1:
         import torch.distributed as dist
         if dist.get_backend(group) != "gloo":
@@ -226,6 +241,18 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     os.makedirs(out_dir, exist_ok=True)
     t0 = time.time()
     timing = {}
+    # The classical units need no trained model: ranks that own no training chain (job_owners: at most one chain per
+    # modulation, so ranks 4.. of an 8-GPU job) compute ALL of them first, while the owners train; the table meets in its
+    # all-reduce after the sweep.  The units carry their own seeds, so who computes them does not change a digit.
+    csnr = list(snrs)[::classical_every]
+    workers = classical_workers(nbits_list, world)
+    early = len(workers) < max(world, 1)
+    ctab = None
+    if early:
+        tc = time.time()
+        ctab = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device, workers=workers,
+                                reduce=False)
+        timing["classical_early"] = time.time() - tc
     trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
                             timing=timing, ckpt_dir=ckpt_dir)
     t1 = time.time()
@@ -235,10 +262,15 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     if verbose and rank == 0:
         print("DCCN sweep done: %d points, %.0f s since start" % (len(pts), time.time() - t0), flush=True)
     t2 = time.time()
-    csnr = list(snrs)[::classical_every]
-    classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device)
+    classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device, workers=workers,
+                                 table=ctab)
     timing["classical"] = time.time() - t2
     timing["total"] = time.time() - t0
+    # seconds this rank spent neither training, sweeping nor on classical units: waiting for the longest chain (the
+    # `broadcast` entry is that wait plus 9 MB per modulation over xGMI) -- the config's scaling cap, stated per rank
+    busy = sum(v for k, v in timing.items() if k.startswith(("train_rx_", "train_eq_"))) + timing["sweep"] + \
+        timing["classical"] + timing.get("classical_early", 0.0)
+    timing["idle"] = max(0.0, timing["total"] - busy)
     all_t = [timing]
     if world > 1:
         import torch.distributed as dist
@@ -259,7 +291,9 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
         # what every rank spent where: nothing is replicated (training chains, sweep points and classical units are all
         # dealt to ranks); `broadcast` + the table reductions are the only joint steps
         with open(os.path.join(out_dir, "config5_timing.json"), "w") as f:
-            json.dump({"world": world, "frames": frames, "eq_epochs": eq_epochs, "rx_epoch_scale": rx_epoch_scale,
+            import torch.distributed as dist
+            json.dump({"world": world, "backend": dist.get_backend() if world > 1 else "none (1 rank)",
+                       "classical_workers": workers, "frames": frames, "eq_epochs": eq_epochs, "rx_epoch_scale": rx_epoch_scale,
                        "classical_frames": classical_frames, "points": len(pts), "job_owners": job_owners(nbits_list, world),
                        "per_rank_seconds": all_t}, f, indent=1)
         if verbose:

@@ -1278,6 +1278,17 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     fd.slabs = nullptr;
     OverlapStreams ovs{};
     bool overlap = false;                 // the dense kernel's update runs on ovs.side (large layers)
+    // every return between the fork and the join below (a failed launch, a DCCN_TRY) still joins: the side stream never
+    // keeps running behind a call that has returned, and a capture of `s` is never left with an un-joined branch
+    struct OverlapJoin {
+        OverlapStreams* o; hipStream_t s; bool forked = false, joined = false;
+        ~OverlapJoin() {
+            if (forked && !joined) {
+                (void)hipEventRecord(o->join, o->side);
+                (void)hipStreamWaitEvent(s, o->join, 0);
+            }
+        }
+    } ojoin{&ovs, s};
     int fold_tilew = 0;
     const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;     // optimizer kernel takes over the fold
     // small layers: dX tiles + C-Conv weight-gradient partials in their epilogue + dW items + tail finalize: one launch
@@ -1369,6 +1380,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             if (sb > 8 * kCUs) sb = 8 * kCUs;                     // (2, 4, 16 per CU measured within 0.5 % of this)
             DCCN_HIP(hipEventRecord(ovs.fork, s));
             DCCN_HIP(hipStreamWaitEvent(ovs.side, ovs.fork, 0));
+            ojoin.forked = true;
             hipLaunchKernelGGL(adam_rx_kernel<0>, dim3((unsigned)sb), dim3(256), 0, ovs.side, as, hp);
             DCCN_LAUNCH_CHECK();
             DCCN_HIP(hipEventRecord(ovs.join, ovs.side));
@@ -1381,7 +1393,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    if (overlap) DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0));
+    if (overlap) { ojoin.joined = true; DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0)); }
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
@@ -1754,6 +1766,9 @@ int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]) {
     return DCCN_OK;
 }
 size_t dccn_rx_workspace_size(const dccn_rx_shape* shape, int train) {
+    // the library's second stream and the calling thread's event pair are created here, i.e. before any step and outside
+    // any stream capture (every caller sizes its workspace first); rx_step_impl only looks them up
+    if (train && shape_ok(shape) && g_tune[TUNE_ADAM_OVERLAP]) { OverlapStreams o; (void)overlap_streams(&o); }
     if (!shape_ok(shape)) return 0;
     return rx_ws_bytes(shape, train);
 }

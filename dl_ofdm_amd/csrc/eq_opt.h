@@ -131,7 +131,10 @@ __device__ __forceinline__ void eq_opt_sum(const EqOptPtrs& a, const EqOptJob& J
             *reinterpret_cast<float4*>(a.m + j) = make_float4(mm[0], mm[1], mm[2], mm[3]);
             *reinterpret_cast<float4*>(a.v + j) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
-            for (long long e = i; e < J.n; ++e) {
+            // (a thread's own quad only: the grid stride hands [i, i+4) to exactly one thread -- unaligned / odd-sized
+            // segments take this path for every quad, not just the last one)
+            const long long e1 = (i + 4 < J.n) ? i + 4 : J.n;
+            for (long long e = i; e < e1; ++e) {
                 float g;
                 if (J.src) {
                     float run[kRedGroups];

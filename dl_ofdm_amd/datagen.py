@@ -265,6 +265,12 @@ class SideStreamFeeder:
         self._step = torch.cuda.Event()
         self._have_step = False
 
+    def rebind(self, make):
+        """a new epoch on the same engine: new producer, same stream and events; the first next() waits for everything the
+        main stream has issued (the end-of-epoch evaluation included)"""
+        self.make = make
+        self._have_step = False
+
     def first(self, slot: int = 0):
         self.make(slot)
         self.eng.prime()

@@ -64,6 +64,7 @@ class _FusedPlan:
             self.nws = tr.lib.dccn_eq_workspace_size(C.byref(self.shape), 1)
             self.ws = torch.empty(self.nws, dtype=torch.uint8, device=dev)
         self.buffers = self._buffers()
+        self._partner = None
         self.graphs: Dict[object, C.c_void_p] = {}
 
     def _buffers(self, x_next=None, pre: int = 0, slot: int = 0) -> EqBuffers:
@@ -81,7 +82,16 @@ class _FusedPlan:
         assert other.ws is self.ws
         for key in [k for k in self.graphs if isinstance(k, tuple)]:      # captured with the previous partner's pointers
             self.tr.lib.dccn_rx_graph_destroy(self.graphs.pop(key))
-        self.pipe_buffers = {0: self._buffers(other.x, 0, slot), 1: self._buffers(other.x, 1, slot)}
+        # 0 starts a chain, 1 continues it, 2 ends it (consumes the batch normalised ahead, normalises nothing: the last
+        # step of an epoch), 3 = a one-step chain is the plain step
+        self.pipe_buffers = {0: self._buffers(other.x, 0, slot), 1: self._buffers(other.x, 1, slot),
+                             2: self._buffers(None, 1, slot), 3: self._buffers(None, 0, slot)}
+        self._partner = other
+
+    def _ahead(self) -> dict:
+        """which plan's input the shared workspace currently holds normalised (twins share one workspace): any run that is
+        not a link of the chain clears it, and a link that does not find its own batch there starts a new chain instead"""
+        return self.tr.__dict__.setdefault("_normalised_ahead", {})
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.tr.device).cuda_stream)
@@ -92,8 +102,12 @@ class _FusedPlan:
 
     def run(self, train: bool, graph: bool = True, pipe: Optional[int] = None):
         lib, tr = self.tr.lib, self.tr
-        bufs = self.buffers if pipe is None else self.pipe_buffers[pipe]
         assert pipe is None or train
+        ahead, wskey = self._ahead(), self.ws.data_ptr()
+        if pipe in (1, 2) and ahead.get(wskey) is not self:      # an eval / plain run used the workspace in between
+            pipe = 0 if pipe == 1 else 3
+        bufs = self.buffers if pipe is None else self.pipe_buffers[pipe]
+        ahead[wskey] = self._partner if pipe in (0, 1) else None
         if not graph:
             if train:
                 check(lib.dccn_eq_train_step(C.byref(self.shape), C.byref(bufs), tr.hp, self._stream()),

@@ -268,6 +268,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
     loss_min, epoch_min, best_path = 100.0, 0, ""
     history = []
     gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
+    feed = None
     import torch
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))           # reference: int(time.time()) + epoch
@@ -286,10 +287,20 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             # and backward launches of step i run; the step's last launch waits for it
             from .datagen import SideStreamFeeder
 
+            # the generator's noise-power monitor is reused per batch: each batch's value goes to one of two preallocated
+            # slots (allocated on the main stream, never handed back to the caching allocator while a step may read them)
+            noise_slots = torch.zeros(2, 1, dtype=torch.float32, device=eng.device)
+
             def make(slot, eng=eng, bs=batch_size):
                 npow = _gen_into(gen, eng, FLAGS, ofdmobj, bs, FLAGS.SNR, slot=slot)
-                return None if npow is None else npow.clone()       # (the generator's monitor buffer is reused per batch)
-            feed = SideStreamFeeder(eng, make)
+                if npow is None:
+                    return None
+                noise_slots[slot].copy_(npow.reshape(1))
+                return noise_slots[slot]
+            if feed is None or feed.eng is not eng:                  # one side stream + event pair per engine, not per epoch
+                feed = SideStreamFeeder(eng, make)
+            else:
+                feed.rebind(make)
             noise_t = None
             if steps:
                 noise_t = make(0)
@@ -298,10 +309,10 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
                 last = i + 1 == steps
                 noise_next = None if last else feed.next((i + 1) & 1)
                 eng.train_step_pipelined(slot=i & 1, last=last, x_ready=None if last else feed.ready)
-                feed.step_issued()
                 acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power)
                 if noise_t is not None:
                     acc[2:3].add_(noise_t)
+                feed.step_issued()            # (after the monitor reads: the generator may now overwrite slot i & 1's values)
                 noise_t = noise_next
             a = acc.cpu().numpy() / max(steps, 1)
             losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])

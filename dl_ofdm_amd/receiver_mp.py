@@ -357,7 +357,8 @@ class DeviceEpochLoop:
                 self._generate(0, 0)
             if i + 1 < self.steps:
                 self._generate(i + 1, q ^ 1)                         # before step i: its optimizer launch normalises it
-            pipe = 0 if i == 0 else 1
+            last = i + 1 == self.steps                               # the epoch's last step normalises nothing ahead
+            pipe = (3 if last else 0) if i == 0 else (2 if last else 1)
         elif not self.overlap:
             q = 0
             self._generate(i, 0)
@@ -386,7 +387,8 @@ class DeviceEpochLoop:
 class BestSnapshot:
     """The best-train-loss model of :456-459, kept on the DEVICE: the reference calls ``saver.save`` every time the epoch loss
     improves; here that is a 28 MB device-to-device copy of the four arenas (microseconds) and the file is written when
-    training ends -- and every ``interval`` seconds in between, so a killed run loses at most that much.  Writing the
+    training ends (also when it ends with an exception or Ctrl-C: the epoch loop flushes in a ``finally``) -- and, checked
+    once per epoch, every ``interval`` seconds in between, so a killed run loses at most that much plus one epoch.  Writing the
     checkpoint file on every improvement (60 small device-to-host copies + a 21 MB archive) cost as much as half an epoch
     of training steps."""
     NAMES = ("params", "adam_m", "adam_v", "adam_state")
@@ -401,7 +403,12 @@ class BestSnapshot:
         for n, b in self.bufs.items():
             b.copy_(getattr(self.tr, n))
         self.dirty = True
-        if time.time() - self.t_last > self.interval:
+        self.maybe_flush()
+
+    def maybe_flush(self):
+        """call once per epoch, improved or not: a snapshot taken less than ``interval`` seconds after the last write is
+        written by the first later epoch that finds the interval over"""
+        if self.dirty and time.time() - self.t_last > self.interval:
             self.flush()
 
     def flush(self) -> str:
@@ -440,31 +447,35 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     loop = DeviceEpochLoop(FLAGS, ofdmobj, trainer, gen, pl, steps, overlap=bool(getattr(FLAGS, "overlap_generator", False)),
                            pipeline=getattr(FLAGS, "pipeline_norm", None))
     best = BestSnapshot(trainer, os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), FLAGS)
-    for epoch in range(FLAGS.max_epoch_num):
-        np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))
-        # :407 one draw for the epoch's frames (the same stream of values as `steps` draws of one batch each)
-        loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, batch_size], p=TRAIN_SNR_PROB))
-        for i in range(steps):
-            loop.step()
-        a = loop.epoch_means()
-        train_loss_epoch = float(a[0])
-        snr = np.random.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)       # :438
-        tx, _ = gen.transmit(FLAGS.eval_frames, out_bits=ev.bits)
-        gen.channel(tx, snr, out_x=ev.x)
-        gen.offset += 1
-        ev.run(False)
-        em = trainer._metrics(ev.metrics_buf, ev.tx_power)
-        history.append(dict(epoch=epoch, train_loss=train_loss_epoch, train_ber=float(a[1]), chan_rms=float(a[4]),
-                            test_loss=em["ce_mean"], test_ber=em["berlin"]))
-        if verbose:
-            print("Epoch: %d  Train Loss: %f  Tx Power: %f  Noise Power: %f  SNR MSE: %f | Test Loss: %f  Test BER: %.8f"
-                  % (epoch, train_loss_epoch, a[2], a[3], a[4], em["ce_mean"], em["berlin"]))
-        if train_loss_epoch < loss_min:
-            epoch_min, loss_min = epoch, train_loss_epoch
-            best.take()                                                  # :456-459 (device snapshot; file written below)
-        if epoch - FLAGS.early_stop > epoch_min:
-            break
-    best_path = best.flush()
+    try:
+        for epoch in range(FLAGS.max_epoch_num):
+            np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))
+            # :407 one draw for the epoch's frames (the same stream of values as `steps` draws of one batch each)
+            loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, batch_size], p=TRAIN_SNR_PROB))
+            for i in range(steps):
+                loop.step()
+            a = loop.epoch_means()
+            train_loss_epoch = float(a[0])
+            snr = np.random.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)       # :438
+            tx, _ = gen.transmit(FLAGS.eval_frames, out_bits=ev.bits)
+            gen.channel(tx, snr, out_x=ev.x)
+            gen.offset += 1
+            ev.run(False)
+            em = trainer._metrics(ev.metrics_buf, ev.tx_power)
+            history.append(dict(epoch=epoch, train_loss=train_loss_epoch, train_ber=float(a[1]), chan_rms=float(a[4]),
+                                test_loss=em["ce_mean"], test_ber=em["berlin"]))
+            if verbose:
+                print("Epoch: %d  Train Loss: %f  Tx Power: %f  Noise Power: %f  SNR MSE: %f | Test Loss: %f  Test BER: %.8f"
+                      % (epoch, train_loss_epoch, a[2], a[3], a[4], em["ce_mean"], em["berlin"]))
+            if train_loss_epoch < loss_min:
+                epoch_min, loss_min = epoch, train_loss_epoch
+                best.take()                                              # :456-459 (device snapshot; file written below)
+            else:
+                best.maybe_flush()                                       # an older snapshot whose interval has run out
+            if epoch - FLAGS.early_stop > epoch_min:
+                break
+    finally:
+        best_path = best.flush()                                         # also on exceptions / KeyboardInterrupt
     if verbose:
         print("Training Done!, Best model saved to\n%s" % best_path)
     result = dict(history=history, best_path=best_path, trainer=trainer)

@@ -152,6 +152,57 @@ def test_bench_two_ranks_over_gloo_one_json_line():
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 * 8190 / (out["ms_per_step"] * 6e-3)) <= 1e-6 * out["value"]
 
 
+def _two_gpus():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs >= 2 GPUs: the RCCL (nccl backend) branch, one rank per GPU")
+def test_bench_two_ranks_over_rccl_one_json_line():
+    """the driver's N = 2 launch exactly as it issues it (backend nccl = RCCL over xGMI, one rank per GPU): one JSON line,
+    whole-job value, the `distributed` object names backend / RCCL version / collective / points per rank, and the reduced
+    tables hold both ranks' bits.  Skipped on 1-GPU boxes (the gloo twin above covers the control flow there)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DCCN_BENCH_BACKEND", "DCCN_DIST_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--no-kernel-times", "--sweep-frames", "1000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    d = out["distributed"]
+    assert out["n_gpus"] == 2 and d["world"] == 2 and d["backend"] == "nccl" and d["rccl_version"]
+    assert d["points_per_rank"] == [20, 20] and "all-reduce" in d["collective"]
+    bits_per_rank = 1170 * 320 * 2
+    t = out["step"]["ber_table"]
+    assert t[5] == 2 * bits_per_rank and sum(t[:4]) == 2 * bits_per_rank
+    assert out["sweep"]["bits_counted"] == 40 * 1000 * 320 * 4 and "all-reduce" in out["sweep"]["collective"]
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs >= 2 GPUs: the RCCL (nccl backend) branch, one rank per GPU")
+def test_config5_sweep_tool_over_rccl(tmp_path):
+    """tools/config5_sweep.py --backend nccl on 2 ranks (scaled down): chains dealt to ranks, arenas broadcast over RCCL,
+    one all-reduce of the table; the CSV equals the 1-rank run byte for byte."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DCCN_BENCH_BACKEND", "DCCN_DIST_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--frames", "2000", "--eq_epochs", "4", "--rx_epoch_scale", "0.01", "--classical_frames", "40",
+              "--snrs=-5,5,15,29", "--classical_every", "2"]
+    tool = os.path.join(ROOT, "tools", "config5_sweep.py")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), tool, "--out", str(tmp_path / "two"), "--backend", "nccl"]
+                         + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert two.returncode == 0, two.stderr[-3000:]
+    one = subprocess.run([sys.executable, tool, "--out", str(tmp_path / "one")] + common, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1500)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = open(str(tmp_path / "one" / "config5_ber.csv")).read()
+    b_ = open(str(tmp_path / "two" / "config5_ber.csv")).read()
+    assert a == b_ and a.count("\n") >= 2
+    tj = json.load(open(str(tmp_path / "two" / "config5_timing.json")))
+    assert tj["world"] == 2 and tj.get("backend") == "nccl"
+
+
 def _c5_worker(rank, world, port, out_dir, q, kw, classical_every=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

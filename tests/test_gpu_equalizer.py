@@ -231,20 +231,22 @@ def test_equalizer_without_cp():
 
 
 # ---- the transfer-learning step (ofdmreceiver_np_mp.py:319-330) -----------------------------------------
-def _trainer(nbits=2, seed=21, cp=True):
+def _trainer(nbits=2, seed=21, cp=True, nfft=64, longcp=True):
     from dl_ofdm_amd.equalizer import EqualizerTrainer
     from dl_ofdm_amd.ofdm import ofdm_tx
     F = _Flags()
     F.nbits, F.opt, F.init_learning, F.cp = nbits, 0, 1e-3, cp
+    F.nfft, F.nfilter, F.longcp = nfft, nfft, longcp
     tx = ofdm_tx(F)
     ecfg = E.EqConfig(S=7, K=tx.K, CP=tx.CP, cp=cp, pilot_size=tx.pilot_size,
                       pilot_carriers=tuple(int(v) for v in tx.pilotCarriers))
-    rcfg = O.RxConfig(S=7, kin=80 if cp else 64, F=64, D=tx.frame_size, nbits=nbits)
+    rcfg = O.RxConfig(S=7, kin=tx.K + tx.CP if cp else tx.K, F=nfft, D=tx.frame_size, nbits=nbits)
     pe = E.init_params(ecfg, seed=seed, bias_scale=0.05)
     pr = O.init_params(rcfg, seed=seed + 1)
     tr = EqualizerTrainer(F, tx, pr, seed=3)
     assert tr.names == list(E.param_shapes(ecfg).keys())
-    assert tr.n_params == (1_753_282 if cp else 1_753_282 - 32 * 128)
+    if nfft == 64 and longcp:
+        assert tr.n_params == (1_753_282 if cp else 1_753_282 - 32 * 128)
     tr.load_params(pe)
     return F, tx, ecfg, rcfg, pe, pr, tr
 
@@ -443,6 +445,44 @@ def test_round3_launch_plan_equals_round2_plan(B, cp, plan):
         lib.dccn_set_tuning(20, 0)
         eb = tr_b.eval_step(x, bits, fused=True)
         assert ea["conf"] == eb["conf"]
+    finally:
+        lib.dccn_set_tuning(20, 1)
+
+
+@pytest.mark.parametrize("B", [12, 200])
+def test_launch_plan_with_unaligned_gradient_slabs(B):
+    """nfft=128 with the short prefix (CP = 9: rows of 2(K+CP) = 274 floats, 274 % 4 = 2): split-K bias / kernel slabs that
+    are not 16 bytes apart take the optimizer launch's element-wise branch (eq_opt.h eq_opt_sum, J.vec == 0).  Every element
+    must be summed and Adam-updated exactly once: the re-planned step against the launch-per-stage plan, three steps, and the
+    step must repeat bit for bit (a quad walked by more than one thread would race)."""
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    F, tx, ecfg, rcfg, pe, pr, tr_a = _trainer(seed=43, nfft=128, longcp=False)
+    _, _, _, _, _, _, tr_b = _trainer(seed=43, nfft=128, longcp=False)
+    _, _, _, _, _, _, tr_c = _trainer(seed=43, nfft=128, longcp=False)
+    assert tx.CP == 9 and (2 * (tx.K + tx.CP)) % 4 == 2
+    rng = np.random.RandomState(23)
+    try:
+        for step in range(3):
+            x = (rng.standard_normal((B, 7, tx.K + tx.CP, 2)) * 2).astype(np.float32)
+            bits = rng.randint(0, 2, (B, tx.frame_size, 2)).astype(np.int32)
+            with torch.no_grad():
+                for name in ("params", "adam_m", "adam_v", "adam_state"):
+                    getattr(tr_b, name).copy_(getattr(tr_a, name))
+                    getattr(tr_c, name).copy_(getattr(tr_a, name))
+            lib.dccn_set_tuning(20, 3)
+            tr_a.train_step(x, bits, fused=True, graph=False)
+            tr_c.train_step(x, bits, fused=True, graph=False)
+            lib.dccn_set_tuning(20, 0)
+            tr_b.train_step(x, bits, fused=True, graph=False)
+            ga, gb, gc = tr_a.get_grads(), tr_b.get_grads(), tr_c.get_grads()
+            pa, pb, pc = tr_a.get_params(), tr_b.get_params(), tr_c.get_params()
+            for n in tr_a.names:
+                assert np.array_equal(ga[n], gc[n]) and np.array_equal(pa[n], pc[n]), (step, n, "not repeatable")
+                assert np.array_equal(ga[n], gb[n]), (step, n, float(np.abs(ga[n] - gb[n]).max()))
+                assert float(np.abs(pa[n] - pb[n]).max()) <= 2e-6, (step, n, float(np.abs(pa[n] - pb[n]).max()))   # (lr = 1e-3)
+            dm = (tr_a.adam_m - tr_b.adam_m).abs().max() / tr_b.adam_m.abs().max()
+            assert float(dm) <= 1e-6, float(dm)
     finally:
         lib.dccn_set_tuning(20, 1)
 

@@ -143,3 +143,24 @@ def test_csv_and_harness_helpers(tmp_path):
     f0 = cfgs[0][0]
     assert (f0.nbits, f0.SNR, f0.max_epoch_num, f0.cp, f0.longcp, f0.token) == (4, 20.0, 4800, False, False,
                                                                                     "OFDM_Dense3_4mod_snr20_cpFalse")
+
+
+def test_config5_unit_ownership_over_ranks():
+    """who does what in BASELINE config[4] as the rank count grows (dl_ofdm_amd/config5.py): one training chain per
+    modulation, longest first to the least-loaded rank; the classical units go to the ranks WITHOUT a chain when there are
+    any (they run while the chains train), to every rank otherwise.  Every unit has exactly one owner."""
+    from dl_ofdm_amd import config5
+    nb = (1, 2, 3, 4)
+    assert config5.job_owners(nb, 1) == {4: 0, 3: 0, 2: 0, 1: 0}
+    assert config5.job_owners(nb, 2) == {4: 0, 3: 1, 2: 1, 1: 0}
+    assert config5.job_owners(nb, 4) == {4: 0, 3: 1, 2: 2, 1: 3}
+    assert config5.job_owners(nb, 8) == {4: 0, 3: 1, 2: 2, 1: 3}
+    assert config5.classical_workers(nb, 1) == [0]
+    assert config5.classical_workers(nb, 2) == [0, 1]
+    assert config5.classical_workers(nb, 4) == [0, 1, 2, 3]
+    assert config5.classical_workers(nb, 8) == [4, 5, 6, 7]
+    assert config5.classical_workers((2,), 2) == [1]
+    for world in (1, 2, 4, 8):
+        w = config5.classical_workers(nb, world)
+        owners = [w[u % len(w)] for u in range(4 * 3 * 3 * 14)]
+        assert set(owners) == set(w) and all(0 <= r < world for r in owners)

@@ -21,11 +21,18 @@ def main():
     ap.add_argument("--ckpt_dir", default="", help="where the best-model checkpoints go (default: a temporary directory; they are "
                                                    "~90 MB per rank and would push a gpurun_out/ result directory over its 64 MiB limit)")
     ap.add_argument("--backend", default=None, help="nccl (default; RCCL over xGMI) or gloo; also DCCN_DIST_BACKEND")
+    ap.add_argument("--nbits", default="1,2,3,4", help="modulations (bits per symbol), comma separated")
+    ap.add_argument("--channels", default=",".join(config5.CHANNELS))
+    ap.add_argument("--snrs", default="", help="comma separated SNRs in dB (default: -10..29)")
+    ap.add_argument("--classical_every", type=int, default=3)
     a = ap.parse_args()
     import torch
     rank, world, local = config5.init_distributed(a.backend)
     import tempfile
-    config5.run(a.out, a.frames, a.eq_epochs, a.classical_frames, a.rx_epoch_scale, rank=rank, world=world,
+    snrs = tuple(int(v) for v in a.snrs.split(",")) if a.snrs else config5.SNRS
+    config5.run(a.out, a.frames, a.eq_epochs, a.classical_frames, a.rx_epoch_scale,
+                nbits_list=tuple(int(v) for v in a.nbits.split(",")), channels=tuple(a.channels.split(",")), snrs=snrs,
+                classical_every=a.classical_every, rank=rank, world=world,
                 device="cuda:%d" % local, ckpt_dir=a.ckpt_dir or tempfile.mkdtemp(prefix="dccn_c5_"))
     if world > 1:
         torch.distributed.barrier()
