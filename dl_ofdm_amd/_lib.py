@@ -169,6 +169,7 @@ SIGNATURES = {
     "dccn_cconv2d_same_reduce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dccn_eq_param_offsets": (_i, [POINTER(EqShape), POINTER(c_longlong)]),
     "dccn_eq_workspace_size": (_sz, [POINTER(EqShape), _i]),
+    "dccn_eq_workspace_tensor": (_i, [POINTER(EqShape), _i, C.c_char_p, POINTER(C.c_size_t), POINTER(C.c_size_t)]),
     "dccn_eq_eval_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), _vp]),
     "dccn_eq_train_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), AdamHParams, _vp]),
     "dccn_eq_graph_create": (_i, [POINTER(EqShape), POINTER(EqBuffers), _i, AdamHParams, _vp, POINTER(c_void_p)]),

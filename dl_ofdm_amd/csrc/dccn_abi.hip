@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "gemm_f32_mfma.h"
+#include "cconv_fwd.h"
 #include "norm_adam.h"
 #include "tail.h"
 #include "gemm16.h"
@@ -565,6 +566,14 @@ static int cconv_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);      // float2 loads of [Wa|Wb] rows
     const int variant = g_tune[TUNE_CCONV_FWD];
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    // 7-9 (default 7): the staged whole-k tile of cconv_fwd.h (K = 160 / 128, i.e. N = 64 with / without the cyclic
+    // prefix): bit-identical to the whole-k tile of gemm_f32_mfma.h it replaces; 8 / 9 = other LDS-store slots
+    if (variant >= 7 && variant <= 9 && big < 2 * kCUs && cconv_fwd_staged_ok(p)) {
+        if (variant == 7) return launch_cconv_fwd_staged<8>(p, s);
+        if (variant == 8) return launch_cconv_fwd_staged<4>(p, s);
+        return launch_cconv_fwd_staged<10>(p, s);
+    }
+    if (variant >= 7) return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
     if (variant > 0 && p.vecA && p.vecB && big < 2 * kCUs && kin % 2 == 0) {
         const size_t sm = tune_smem_min();
         switch (variant) {
@@ -832,7 +841,7 @@ static int rx_bwd_fused_tiles(int batch, int S, int F) { return ceil_div(batch, 
 static size_t rx_bwd_fused_ws_bytes(int batch, int S, int kin, int F) {
     const size_t tiles = (size_t)rx_bwd_fused_tiles(batch, S, F);
     size_t o = 0;
-    o = carve_size(o, tiles * 2 * kin * 64 * sizeof(float));
+    o = carve_size(o, tiles * kin * 64 * sizeof(float));        // folded per tile: [kin][32][{a, b}] (rx_bwd.h)
     o = carve_size(o, tiles * 64 * sizeof(float));
     return align_up(o, 256);
 }
@@ -883,7 +892,7 @@ static int rx_bwd_fused_impl(const float* x_norm, const float* fft_out, const fl
     Carver cc(ws_conv, ws_conv_bytes);
     DweffArgs de;
     de.xn = x_norm;
-    de.partial = cc.take<float>((size_t)tiles * 2 * kin * 64);
+    de.partial = cc.take<float>((size_t)tiles * kin * 64);
     de.colsum = cc.take<float>((size_t)tiles * 64);
     de.batch = batch; de.ldx = S * 2 * kin; de.two_kin = 2 * kin; de.two_F = 2 * F;
     de.prio = g_tune[TUNE_BWD_PRIO];
@@ -892,7 +901,7 @@ static int rx_bwd_fused_impl(const float* x_norm, const float* fft_out, const fl
     ds->dw_slabs = slabs; ds->db_slabs = dbias_dense ? cs : nullptr; ds->splits = nsplit;
     fd->slabs = de.partial; fd->colsum = de.colsum;
     fd->splits = ceil_div(batch, 64) * S;                       // terms per element: (row tile, symbol)
-    fd->slab = (long long)((2 * F) / 64) * 2 * kin * 64;        // distance between consecutive terms
+    fd->slab = (long long)((2 * F) / 64) * kin * 64;            // distance between consecutive terms (tiles folded: [kin][32][2])
     *fold_tilew = 64;
     return DCCN_OK;
 }
@@ -1846,6 +1855,38 @@ int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets) {
 size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train) {
     if (!eq_shape_ok(shape)) return 0;
     return eq_ws_bytes(shape, train);
+}
+int dccn_eq_workspace_tensor(const dccn_eq_shape* shape, int train, const char* name, size_t* byte_offset, size_t* count) {
+    if (!eq_shape_ok(shape) || !name || !byte_offset || !count) return DCCN_ERR_INVALID_ARG;
+    const EqDims d = eq_dims(shape);
+    // carve a dummy base so that every pointer is base + offset (the Carver hands out nullptr for a null base)
+    char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 40);
+    Carver c(base, ~static_cast<size_t>(0) >> 2);
+    EqWs w;
+    memset(&w, 0, sizeof(w));
+    eq_carve(c, shape, d, train != 0, w);
+    const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
+    struct Ent { const char* n; const float* p; size_t cnt; bool tr; };
+    const Ent tab[] = {
+        {"x_norm", w.x_norm, R * N2, false}, {"ln", w.ln, R * N2, false}, {"t1", w.t1, R * K2, false}, {"y", w.y, R * K2, false},
+        {"d1", w.d1, B * d.Pp, false}, {"d2", w.d2, B * SK2, false}, {"d3", w.d3, B * SK2, false}, {"d4", w.d4, B * SK2, false},
+        {"T", w.T, SK2 * SK2, false}, {"be", w.be, SK2, false}, {"eq", w.eq, B * SK2, false}, {"corr", w.corr, B * SK2, false},
+        {"eqc", w.eqc, R * K2, false}, {"corc", w.corc, R * K2, false}, {"cat", w.cat, R * 2 * K2, false},
+        {"fft", w.fft, R * 2 * (size_t)d.F, false}, {"z", w.z, B * 2 * (size_t)d.D, false},
+        {"dz", w.dz, B * 2 * (size_t)d.D, true}, {"dfft", w.dfft, R * 2 * (size_t)d.F, true}, {"dout", w.dout, R * N2, true},
+        {"dcat", w.dcat, R * 2 * K2, true}, {"deqc", w.deqc, R * K2, true}, {"dcorc", w.dcorc, R * K2, true},
+        {"deq", w.deq, B * SK2, true}, {"dcorr", w.dcorr, B * SK2, true}, {"dy", w.dy, B * SK2, true}, {"dh", w.dh, B * SK2, true},
+        {"dT", w.dT, SK2 * SK2, true}, {"dbe", w.dbe, SK2, true}, {"dd4", w.dd4, B * SK2, true}, {"dd3", w.dd3, B * SK2, true},
+        {"dd2", w.dd2, B * SK2, true}, {"dd1", w.dd1, B * d.Pp, true}, {"dflat", w.dflat, B * SK2, true}, {"dt1", w.dt1, R * K2, true},
+    };
+    for (const Ent& e : tab) {
+        if (strcmp(e.n, name) != 0) continue;
+        if (e.tr && !train) return DCCN_ERR_INVALID_ARG;
+        *byte_offset = (size_t)(reinterpret_cast<const char*>(e.p) - base);
+        *count = e.cnt;
+        return DCCN_OK;
+    }
+    return DCCN_ERR_INVALID_ARG;
 }
 size_t dccn_eq_rx_folded_floats(const dccn_eq_shape* shape) {
     if (!eq_shape_ok(shape)) return 0;

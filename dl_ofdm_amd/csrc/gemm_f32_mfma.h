@@ -821,9 +821,10 @@ static int launch_splitk_reduce2(const float* pa, int splits, long long slab_a, 
 // element index e in [0, kin*F) -> (n,f); e in [kin*F, kin*F+F) -> bias f
 // out2/gout (optional, per thread): the two element offsets (relative to dw; the bias follows the kernel) and
 // gradient values this thread produced, -1 when none -- lets a caller apply the optimizer update in the same pass
-// tilew > 0: the slabs are stored as column tiles of width tilew (the dX-epilogue partials of rx_bwd.h: term z, column
-// tile h at partial + (z*nh + h)*2kin*tilew, rows of tilew floats; colsum [z*nh + h][tilew]); `slab` is then the
-// distance between consecutive terms (nh tiles).  tilew == 0: full-width [2kin, 2F] slabs (split-K GEMM output).
+// tilew > 0: the dX-epilogue partials of rx_bwd.h: term z, column tile h (tilew columns = tilew/2 filters) at
+// partial + (z*nh + h)*kin*tilew, ALREADY FOLDED per tile: [kin][tilew/2][{a, b}] with a = dWeff[2n,2f] - dWeff[2n+1,2f+1],
+// b = dWeff[2n,2f+1] - dWeff[2n+1,2f] (one float2 per (n, f): half the bytes of the raw tile); colsum [z*nh + h][tilew];
+// `slab` is the distance between consecutive terms (nh tiles).  tilew == 0: full-width [2kin, 2F] slabs (split-K GEMM output).
 // LANES element-lanes x 256/LANES term groups per block: 64 x 4 for the split-K slabs (<= 128 terms of a few MB each:
 // few, long rows), 16 x 16 for the dX-epilogue partials (133 short terms per element: with four groups a thread walked
 // five dependent batches of loads and the fold was the long pole of the optimizer launch, 10 us; with sixteen it is one
@@ -845,13 +846,31 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     float a = 0.f, b = 0.f;
     // element (row, col = 2f) of term z: partial + z*slab + eoff + row*ld
     const int ld = tilew > 0 ? tilew : N2;
-    const size_t eoff = tilew > 0 ? (size_t)((2 * f) / tilew) * (size_t)(2 * kin) * tilew + (2 * f) % tilew : (size_t)(2 * f);
+    const size_t eoff = tilew > 0 ? (size_t)((2 * f) / tilew) * (size_t)kin * tilew + (size_t)n * tilew + (2 * f) % tilew
+                                  : (size_t)(2 * f);
     const size_t coff = tilew > 0 ? (size_t)((2 * f) / tilew) * tilew + (2 * f) % tilew : (size_t)(2 * f);
     const size_t cstride = tilew > 0 ? (size_t)(N2 / tilew) * tilew : (size_t)N2;
     // terms per batch of independent loads: 133 terms over 16 groups = 9 per thread -> ONE batch (with 8 the five groups that
     // own a ninth term walked a second, dependent batch: one more memory latency on the optimizer launch's long pole)
     constexpr int UB = LANES == kFoldLanesTiled ? 9 : 8;
-    if (is_w) {
+    if (is_w && tilew > 0) {
+        // folded tiles: one float2 {a, b} per term; the sums below add the same values in the same order as the raw form
+        // (there: a += top.x - bot.y with the difference rounded first)
+        for (int zb = grp; zb < splits; zb += UB * GROUPS) {
+            float2 ab[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                ab[u] = *reinterpret_cast<const float2*>(partial + (size_t)min(zb + u * GROUPS, splits - 1) * slab + eoff);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (zb + u * GROUPS < splits) {
+                    a += ab[u].x;
+                    b += ab[u].y;
+                }
+            }
+        }
+    } else if (is_w) {
         for (int zb = grp; zb < splits; zb += UB * GROUPS) {
             float2 top[UB], bot[UB];
 #pragma unroll

@@ -18,7 +18,12 @@
 //   2kin = 32 NU rows: NU/2 chunks of 64 rows (4 MFMAs per wave and k-step each) and, for odd NU, one unit of 32 rows of
 //   which a wave takes the row class s = hA (2 MFMAs): 10 MFMAs per wave and k-step at 2kin = 160, nothing idle.
 //   Column sums of the tile (C-Conv bias gradient) come from the accumulators before they are written.
-// The partials are folded (fixed order => deterministic) onto [Wa|Wb] by the optimizer launch (norm_adam.h).
+// The partials are summed (fixed order => deterministic) onto [Wa|Wb] by the optimizer launch (norm_adam.h).
+//   Round 5: a tile holds all four dWeff entries of each (n, f) pair it touches -- rows 2n, 2n+1 x columns 2f, 2f+1 sit in
+//   ONE lane's accumulators -- so the fold of Appendix A.2, dWa = dWeff[2n,2f] - dWeff[2n+1,2f+1], dWb = dWeff[2n,2f+1] -
+//   dWeff[2n+1,2f], is taken per tile BEFORE the store: the partial is [kin][32][{a, b}] = half the bytes (266 x 20 KB
+//   instead of 266 x 40 KB written here and read back by the optimizer launch).  The optimizer summed fl(top - bot) per
+//   term before; it now sums the stored fl(top - bot): the same additions of the same values => bit-identical gradients.
 #pragma once
 #include "gemm_kmajor.h"
 #include "norm_adam.h"
@@ -28,7 +33,7 @@ namespace dccn {
 
 struct DweffArgs {
     const float* xn;      // x_norm [batch][S][2kin]
-    float* partial;       // [dX tiles][2kin][64]
+    float* partial;       // [dX tiles][kin][32][2]: folded per tile (a = dWa term, b = dWb term)
     float* colsum;        // [dX tiles][64]
     int batch, ldx;       // ldx = S * 2kin
     int two_kin, two_F;
@@ -113,13 +118,16 @@ __device__ __forceinline__ void dweff_epilogue(const DweffArgs& d, const int ntn
     }
     const float* xr = sX + kq * RA;
     const float* dr = sD + kq * 64 + ((unsigned)(32 * hB + 2 * c) ^ sw);
-    float2 fb[2], fa[2][NCH > 0 ? NCH : 1], fo[2];
+    float2 fb[2], fa[2][NCH > 0 ? NCH : 1];
+    float fo[2];
     auto frag = [&](const int ks, const int buf) {
         fb[buf] = *reinterpret_cast<const float2*>(dr + 4 * ks * 64);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
             fa[buf][ch] = *reinterpret_cast<const float2*>(xr + 4 * ks * RA + ((unsigned)(64 * ch + 32 * hA + 2 * c) ^ sw));
-        if constexpr (ODD) fo[buf] = *reinterpret_cast<const float2*>(xr + 4 * ks * RA + ((unsigned)(32 * (NU - 1) + 2 * c) ^ sw));
+        // odd unit (32 rows): wave hA takes the row pairs (2n, 2n+1) with n = hA (mod 2): MFMA row i = c is dWeff row
+        // 32 (NU-1) + 4 (c/2) + 2 hA + c%2, so that both rows of a pair end up in one lane (r = 0,1 and r = 2,3)
+        if constexpr (ODD) fo[buf] = xr[4 * ks * RA + ((unsigned)(32 * (NU - 1) + 4 * (c >> 1) + 2 * hA + (c & 1)) ^ sw)];
     };
     frag(0, 0);
 #pragma unroll
@@ -136,26 +144,28 @@ __device__ __forceinline__ void dweff_epilogue(const DweffArgs& d, const int ntn
             aw[ch][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, aw[ch][1][1], 0, 0, 0);
         }
         if constexpr (ODD) {
-            const float av = hA ? fo[ks & 1].y : fo[ks & 1].x;
+            const float av = fo[ks & 1];
             ao[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, ao[0], 0, 0, 0);
             ao[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, ao[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // 4. the tile's partial slab [2kin][64]: a lane's two columns are one float2, 16 lanes one 128-byte segment
-    float* P = d.partial + (size_t)q * (32 * NU * 64) + 32 * hB + 2 * c;
+    // 4. the tile's FOLDED partial [kin][32][{a, b}]: lane (c, kq) of wave (hA, hB) holds, per chunk and r, the 2x2 block
+    //    rows 2n, 2n+1 (s = 0, 1) x columns 2f, 2f+1 (t = 0, 1) with n = 32 ch + 16 hA + 4 kq + r, f = 16 hB + c:
+    //    a = [2n][2f] - [2n+1][2f+1], b = [2n][2f+1] - [2n+1][2f] (complex.py:185-188 backward); 16 lanes = 128 contiguous bytes
+    float* P = d.partial + (size_t)q * (16 * NU * 64) + 2 * (16 * hB + c);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                *reinterpret_cast<float2*>(P + (size_t)(64 * ch + 32 * hA + 8 * kq + 2 * r + s) * 64) =
-                    make_float2(aw[ch][s][0][r], aw[ch][s][1][r]);
+            *reinterpret_cast<float2*>(P + (size_t)(32 * ch + 16 * hA + 4 * kq + r) * 64) =
+                make_float2(aw[ch][0][0][r] - aw[ch][1][1][r], aw[ch][0][1][r] - aw[ch][1][0][r]);
     if constexpr (ODD) {
+        // odd unit: accumulator row i = 4 kq + r is dWeff row 32 (NU-1) + 8 kq + 4 (r/2) + 2 hA + r%2: n = 16 (NU-1) + 4 kq + 2 (r/2) + hA
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float2*>(P + (size_t)(32 * (NU - 1) + 8 * kq + 2 * r + hA) * 64) = make_float2(ao[0][r], ao[1][r]);
+        for (int rp = 0; rp < 2; ++rp)
+            *reinterpret_cast<float2*>(P + (size_t)(16 * (NU - 1) + 4 * kq + 2 * rp + hA) * 64) =
+                make_float2(ao[0][2 * rp] - ao[1][2 * rp + 1], ao[1][2 * rp] - ao[0][2 * rp + 1]);
     }
 }
 

@@ -551,6 +551,19 @@ int dccn_eq_rx_fold(const dccn_eq_shape* shape, const float* rx_params, float* o
  * over whole arena segments, padding included. */
 int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets /* [21] */);
 size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train);
+/* Where a named intermediate of the fused step lives inside the caller's workspace (the step never reuses a buffer within a
+ * call, so every one of them holds what its stage left there when the call returns -- the counterpart of fetching a named
+ * tensor of the reference's graph, dev/py/model.py:349-478 by line):
+ *   forward   "x_norm" input:0 [B,S,n_sc,2] | "ln" :363 | "t1" :371 dense [B*S,2K] | "y" :378-386 [B,S,K,2] | "d1" :394 [B,2P] |
+ *             "d2" :402 | "d3" :408 | "d4" :421 (after tanh) [B,S*K*2] | "T" / "be" the :428 kernel expanded to a dense layer
+ *             [SK2,SK2] / [SK2] | "eq" :435 | "corr" :438 | "cat" :456 [B*S,K,4] | "fft" / "z" receiver (unless folded) | "dz"
+ *   backward  "dout" d loss / d equalized [B,S,n_sc,2] | "deqc" / "dcorc" gradients of the two :439-449 C-Conv outputs |
+ *             "deq" / "dcorr" | "dy" (from the equalise stage only) | "dh" | "dd4" (through the tanh) | "dd3" | "dd2" |
+ *             "dflat" (total gradient of y: "dy" + the pilot branch) | "dt1" | "dT" / "dbe"
+ * Returns DCCN_OK and (*byte_offset, *count floats), or DCCN_ERR_INVALID_ARG for an unknown name / a training-only tensor of
+ * an evaluation workspace.  Which buffers a given launch plan leaves un-written (e.g. "dcat" when the concat's gradient is
+ * split in the GEMM's store) is the plan's business: compare only what the plan's description says it materialises. */
+int dccn_eq_workspace_tensor(const dccn_eq_shape* shape, int train, const char* name, size_t* byte_offset, size_t* count);
 int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream);
 int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_adam_hparams hp,
                        dccn_stream_t stream);

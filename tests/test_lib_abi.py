@@ -63,6 +63,28 @@ def test_host_side_queries(lib):
     assert lib.dccn_cconv_gemm_fwd(None, None, None, None, 0, 80, 64, None) == -1
 
 
+def test_eq_workspace_tensor_lookup(lib):
+    """dccn_eq_workspace_tensor: a host-side query (no device work): named intermediates of the fused equaliser step lie
+    inside the sized workspace on 256-byte boundaries; unknown names and training-only tensors of an evaluation workspace
+    are refused."""
+    from dl_ofdm_amd import _lib
+    sh = _lib.EqShape(12, 7, 64, 16, 1, 64, 320, 2, 16, 8)
+    off, cnt = C.c_size_t(), C.c_size_t()
+    assert lib.dccn_eq_workspace_tensor(C.byref(sh), 1, b"y", C.byref(off), C.byref(cnt)) == 0 and cnt.value == 12 * 7 * 128
+    total = lib.dccn_eq_workspace_size(C.byref(sh), 1)
+    assert off.value % 256 == 0 and off.value + 4 * cnt.value <= total
+    seen = set()
+    for name in (b"x_norm", b"ln", b"t1", b"d1", b"d2", b"d3", b"d4", b"eq", b"corr", b"cat", b"dz", b"dout", b"deqc", b"dcorc",
+                 b"deq", b"dcorr", b"dy", b"dh", b"dd4", b"dd3", b"dd2", b"dflat", b"dt1"):
+        assert lib.dccn_eq_workspace_tensor(C.byref(sh), 1, name, C.byref(off), C.byref(cnt)) == 0, name
+        assert off.value % 256 == 0 and cnt.value > 0 and off.value + 4 * cnt.value <= total and off.value not in seen
+        seen.add(off.value)
+    assert lib.dccn_eq_workspace_tensor(C.byref(sh), 0, b"dh", C.byref(off), C.byref(cnt)) == -1          # training only
+    assert lib.dccn_eq_workspace_tensor(C.byref(sh), 0, b"y", C.byref(off), C.byref(cnt)) == 0
+    assert lib.dccn_eq_workspace_tensor(C.byref(sh), 1, b"nope", C.byref(off), C.byref(cnt)) == -1
+    assert lib.dccn_eq_workspace_tensor(C.byref(sh), 1, None, C.byref(off), C.byref(cnt)) == -1
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from dl_ofdm_amd import _lib, ops
