@@ -454,8 +454,7 @@ def main():
     def reduce_table():
         """final BER/loss reduction over xGMI (the only collective of the path): the last step's metrics record goes
         into the float64 table row by one stream-ordered launch (no host round trip), then ONE all-reduce"""
-        table.zero_()
-        _lib.check(lib.dccn_metrics_table_add(eng.metrics_buf.data_ptr(), table.data_ptr(), eng._stream()), "table_add")
+        _lib.check(lib.dccn_metrics_table_set(eng.metrics_buf.data_ptr(), table.data_ptr(), eng._stream()), "table_set")
         if world > 1:
             dist.all_reduce(table)
 
@@ -463,14 +462,18 @@ def main():
     reduce_table()          # first use loads torch's element-wise code objects / RCCL channels (tens of ms of GPU idleness, once)
     if world > 1:
         dist.barrier()
+    pci = hip_device_pci(dev)
+    # (read BEFORE the pre-warm: the sysfs DPM files are answered by the SMU and take tens of milliseconds for a node's
+    # cards -- read between the pre-warm and the timed regions, as round 4 did, they left the GPU idle long enough to restart
+    # it at its post-idle clock, and with the driver's K = 20 the seven 1.5-ms regions then measured the recovery:
+    # 0.0767, 0.0764, 0.0763, 0.0759, 0.0754, 0.0759, 0.0753 ms in gpurun_out/r05c)
+    clocks_before = gpu_clock_state(pci) if rank == 0 else None
+    timer = HipTimer()
+    regions, ev_regions, enq_regions = [], [], []
     # untimed pre-warm AFTER everything that leaves the GPU idle: continuous load until the clocks are where they stay
     prewarm(step, dev, 0.5)
     for _ in range(args.warmup):
         step()
-    pci = hip_device_pci(dev)
-    clocks_before = gpu_clock_state(pci) if rank == 0 else None
-    timer = HipTimer()
-    regions, ev_regions, enq_regions = [], [], []
     # The timed region = EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  It is run `--regions` times
     # back to back and `value` is the median region: with the driver's K = 20 one region lasts 1.6 ms, and a single sample
     # of that length cannot tell a slow box from a slow moment (0.101 vs 0.079 ms on another box of the pool).

@@ -117,6 +117,7 @@ SIGNATURES = {
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
+    "dccn_metrics_table_set": (_i, [_vp, _vp, _vp]),
     "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),
     "dccn_ingraph_awgn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_ulonglong, C.c_uint, _vp, _sz, _vp]),
     "dccn_classical_workspace_size": (_sz, []),

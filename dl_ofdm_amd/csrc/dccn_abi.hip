@@ -83,11 +83,17 @@ struct TuneTable {
 };
 // defaults = the fastest measured (A/B runs of tools/ab.py inside one process on one box, medians of 4-6 rounds of 300 steps;
 // boxes of the pool differ by up to 9 % in absolute time, so only same-process comparisons decide):
+//    2 = 7  round 5: the staged whole-k C-Conv forward of cconv_fwd.h (stages of 32 k consumed as they land): 7.15 -> 5.04 us in
+//           situ, C2 step 76.36 -> 74.67 us, bit-identical (gpurun_out/r05a; 8 / 9 = other LDS-store slots: 74.59 / 74.76);
 //   12 = 3  dX tiles at wave priority 3: -0.4 us per C2 step;
 //   13 = 1  8-QAM training 86.7 -> 84.4 us with the tail in the dense launch; the quad-lane form of 16-QAM training is
 //           built and parity-tested but slower than its own launch (104.8 vs 98.8 us: one wave per SIMD cannot hide the
 //           transcendental / DPP latencies of 24 cells per quad), so bit 1 stays off;
-//   14 = 1  graded dense-dW ranges {8,6,3,2}/19 of the batch: 80.2 -> 77.4 us per C2 step over three uniform ranges;
+//   14 = 14 graded dense-dW ranges {9,5,2,2,1}/19 of the batch (k-tiles of 64 frames; round 4: {8,6,3,2}, 80.2 -> 77.4 us per C2
+//           step over three uniform ranges).  Round 5 re-scanned 24 presets on the lighter launch (folded dWeff partials):
+//           steeper grading packs the grid's tail better although a fifth slab is written and summed -- backward launch
+//           33.1 -> 31.0 us in situ, optimizer 6.9 -> 7.2, step 74.4 -> 73.5 us ({8,5,3,2,1} 73.6, {9,5,3,2} 73.8, {10,5,3,1}
+//           73.7, six ranges 74.3-74.8, three ranges 76.3-77.4, two 80.8: gpurun_out/r05a, r05c-r05e);
 //   15 = 0  the optimizer launch that also runs the next batch's C-Conv forward (in-launch hand-off of the updated kernel,
 //           3 launches per step) is built and bitwise-tested but measured +1.4 us: poll + acquire + the serial fold -> tile
 //           chain (19.6 us) cost what the saved launch boundary gave (10.0 + 8.0 us as two launches);
@@ -106,7 +112,7 @@ struct TuneTable {
 //           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
 //   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
 //           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
-static TuneTable g_tune = {{{9}, {7}, {0}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {1}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}}};
+static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -334,9 +340,12 @@ constexpr int kFusedBwdRangeRows = 448;
 // graded k ranges (in 64-row k-tiles, as shares of the total): the items are dispatched range by range, so the last ones
 // handed out are the short ones
 static int graded_ranges(int preset, int M, int off[9]) {
-    static const int shares[][6] = {{0}, {8, 6, 3, 2, 0}, {9, 6, 4, 0}, {7, 5, 4, 3, 0}, {10, 9, 0}, {8, 7, 4, 0}, {6, 5, 4, 3, 1, 0},
-                                    {9, 7, 3, 0}};
-    if (preset < 1 || preset > 7) return 0;
+    static const int shares[][8] = {{0}, {8, 6, 3, 2, 0}, {9, 6, 4, 0}, {7, 5, 4, 3, 0}, {10, 9, 0}, {8, 7, 4, 0}, {6, 5, 4, 3, 1, 0},
+                                    {9, 7, 3, 0}, {9, 6, 3, 1, 0}, {8, 5, 3, 2, 1, 0}, {10, 5, 3, 1, 0}, {7, 6, 4, 2, 0},
+                                    {8, 6, 4, 1, 0}, {9, 5, 3, 2, 0}, {9, 5, 2, 2, 1, 0}, {8, 4, 3, 2, 2, 0}, {10, 4, 2, 2, 1, 0},
+                                    {7, 5, 3, 2, 2, 0}, {9, 4, 3, 2, 1, 0}, {8, 5, 3, 1, 2, 0}, {7, 5, 4, 2, 1, 0},
+                                    {8, 4, 3, 2, 1, 1, 0}, {9, 4, 2, 2, 1, 1, 0}, {9, 5, 2, 1, 1, 1, 0}, {10, 4, 2, 1, 1, 1, 0}};
+    if (preset < 1 || preset > 24) return 0;
     const int nt = ceil_div(M, 64);
     int tot = 0, n = 0;
     while (shares[preset][n]) tot += shares[preset][n++];
@@ -566,12 +575,15 @@ static int cconv_fwd_impl(const float* x, const float* w, const float* bias, flo
     p.vecB = (F % 2 == 0) && aligned16(w) && small_enough(kin, 2LL * F);      // float2 loads of [Wa|Wb] rows
     const int variant = g_tune[TUNE_CCONV_FWD];
     const long long big = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    // 7-9 (default 7): the staged whole-k tile of cconv_fwd.h (K = 160 / 128, i.e. N = 64 with / without the cyclic
+    // 7-11 (default 7): the staged whole-k tile of cconv_fwd.h (K = 160 / 128, i.e. N = 64 with / without the cyclic
     // prefix): bit-identical to the whole-k tile of gemm_f32_mfma.h it replaces; 8 / 9 = other LDS-store slots
-    if (variant >= 7 && variant <= 9 && big < 2 * kCUs && cconv_fwd_staged_ok(p)) {
+    // 10 / 11: 32 x 128 tiles (every x row read by one block)
+    if (variant >= 7 && variant <= 11 && big < 2 * kCUs && cconv_fwd_staged_ok(p)) {
         if (variant == 7) return launch_cconv_fwd_staged<8>(p, s);
         if (variant == 8) return launch_cconv_fwd_staged<4>(p, s);
-        return launch_cconv_fwd_staged<10>(p, s);
+        if (variant == 9) return launch_cconv_fwd_staged<10>(p, s);
+        if (variant == 10) return launch_cconv_fwd_staged<8, 32, 128>(p, s);
+        return launch_cconv_fwd_staged<4, 32, 128>(p, s);
     }
     if (variant >= 7) return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
     if (variant > 0 && p.vecA && p.vecB && big < 2 * kCUs && kin % 2 == 0) {
@@ -1365,7 +1377,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                 ae.p = P + L.o_dense_w; ae.m = b->adam_m + L.o_dense_w; ae.v = b->adam_v + L.o_dense_w;
                 ae.reg = b->reg_coef ? b->reg_coef + L.o_dense_w : nullptr;
                 ae.gate = b->reg_coef ? &b->metrics->berlin : nullptr;
-                ae.state = b->adam; ae.hp = hp; ae.keep_grad = b->keep_dense_grad != 0;
+                ae.state = b->adam; ae.hp = hp; ae.keep_grad = b->keep_dense_grad > 0;
                 aep = &ae;
             }
         }
@@ -1419,6 +1431,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.n_conv = L.o_dense_w;                      // C-Conv kernel + bias come first in the arena
     aa.skip_lo = aa.skip_hi = 0;
     aa.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
+    aa.skip_dw_grad = b->keep_dense_grad < 0 ? 1 : 0;          // the caller never reads the summed dense gradient
     // large arenas (N = 1024: 0.47 GB of gradient, far beyond the 256 MB Infinity Cache) are pure streams
     aa.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
     if (ds.adam_done || overlap) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
@@ -1618,6 +1631,20 @@ __global__ void metrics_table_add_kernel(const dccn_metrics* __restrict__ m, dou
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream) {
     if (!metrics || !row6) return DCCN_ERR_INVALID_ARG;
     hipLaunchKernelGGL(metrics_table_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, metrics, row6);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+// row = the record (a one-point table: no clearing launch in front of it)
+__global__ void metrics_table_set_kernel(const dccn_metrics* __restrict__ m, double* __restrict__ row) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) row[k] = (double)m->conf[k];
+        row[4] = m->ce_sum;
+        row[5] = (double)m->count;
+    }
+}
+int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_stream_t stream) {
+    if (!metrics || !row6) return DCCN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(metrics_table_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, metrics, row6);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

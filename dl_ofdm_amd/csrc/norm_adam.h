@@ -473,6 +473,9 @@ struct AdamRxArgs {
     unsigned long long* stamp;             // step timeline stamps (common.h stamp_mark), nullptr = none
     int reg_uniform_dw;                    // reg_coef is one value over [o_dw, o_dw + n_dw): read once, not streamed
     int nt;                                // streaming hints: the gradient is loaded non-temporal (read exactly once)
+    int skip_dw_grad;                      // 1: the sum of the dense kernel's split-K slabs feeds the update only and is not
+                                           //    written to the gradient arena (dccn_rx_buffers.keep_dense_grad < 0: 2.3 MB of
+                                           //    the launch's 14 MB of stores at C2)
 };
 
 // C-Conv parameters: fold the dWeff slabs (Appendix A.2) and apply the update right here.
@@ -605,7 +608,7 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
                 }
             }
             g[0] = s.x; g[1] = s.y; g[2] = s.z; g[3] = s.w;
-            *reinterpret_cast<float4*>(a.grad + i) = s;
+            if (!a.skip_dw_grad) *reinterpret_cast<float4*>(a.grad + i) = s;
         } else if (full && !(a.dw_slabs && i < a.o_dw + a.n_dw && i + 4 > a.o_dw) &&
                    !(a.db_slabs && i < a.o_db + a.n_db && i + 4 > a.o_db)) {
             float4 s;

@@ -137,7 +137,7 @@ class RxEngine:
         self.buffers = RxBuffers(p(self.x), p(self.bits), p(self.params), p(self.grads), p(self.adam_m),
                                  p(self.adam_v), p(self.reg_coef), p(self.adam_state), p(self.x_norm),
                                  p(self.fft_out), p(self.z), p(self.prob), p(self.dz), p(self.dfft),
-                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0, 0, 0, 1 if want_grads else 0,
+                                 p(self.metrics_buf), p(self.tx_power), p(self.ws), nws, 0, 0, 0, 0, 1 if want_grads else -1,
                                  1,       # reg_uniform_dense: self.reg_coef is one value over the dense kernel (above)
                                  0)       # x_next_ready
         # pipelined training, double-buffered: the next batch is normalised into the OTHER x_norm buffer by leading blocks of

@@ -234,6 +234,8 @@ int dccn_classical_detect(const float* Y, const float* G, const int* dat, const 
 /* One row of the sweep table {c00,c01,c10,c11,ce_sum,count} (float64, device): row6 += the metrics record of the
  * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
+/* row6 = the record (the one-point table of a single evaluation: no clearing launch needed in front of it) */
+int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
 
 /* Kernel-configuration knobs for experiments and profiling (process-wide; individually atomic, but a change
  * while another thread plans a launch may be seen half-way through that plan): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
@@ -348,7 +350,9 @@ typedef struct dccn_rx_buffers {
     float* x_norm_next;
     int norm_slot;
     /* Large layers (dccn_get_tuning(16), N = 1024): the dense kernel's optimizer update runs in the epilogue of its
-       weight-gradient tiles and its gradient is not written to `grads` unless keep_dense_grad != 0. */
+       weight-gradient tiles and its gradient is not written to `grads` unless keep_dense_grad > 0.
+       keep_dense_grad < 0 (round 5): the caller never reads the dense kernel's gradient (a training loop): the optimizer
+       launch that sums its split-K slabs does not store the sum either (the other gradients are still written). */
     int keep_dense_grad;
     /* reg_coef holds ONE value over the whole dense-kernel segment (what the reference's keras l2(0.01) regulariser gives:
        dev/py/model.py:1271-1272): the optimizer then reads that value once instead of streaming a parameter-sized array

@@ -76,7 +76,7 @@ def oracle_values(B=5, nbits=2, seed=3):
 def test_stage_checker_agrees_with_the_whole_graph_oracle():
     v, pe, G, c, lit_rx, bits, ce, conf = oracle_values()
     st = Stage()
-    ce2, conf2 = check_stages(v, pe, G, c, lit_rx, bits, st)
+    ce2, conf2, _ = check_stages(v, pe, G, c, lit_rx, bits, st)
     worst = max(e for _, e, _ in st.rows)
     assert worst <= 1e-11, sorted(st.rows, key=lambda r: -r[1])[:3]
     assert len(st.rows) >= 45 and abs(ce - ce2) <= 1e-14 and np.array_equal(conf, conf2)

@@ -37,7 +37,7 @@ def test_c4_full_size_qpsk_n1024_585_frames():
     eng.train_step(x, bits)
     torch.cuda.synchronize()
     m, g = eng.metrics(), eng.get_grads()
-    tol = 2e-5                                                     # K up to 14336: a little more fp32 rounding
+    tol = 1e-5                                                     # north_star's figure, also at K = 14336
     rng = np.random.RandomState(1)
     fr = np.sort(rng.choice(batch, 16, replace=False))
     p64 = {k: v.astype(np.float64) for k, v in p.items()}

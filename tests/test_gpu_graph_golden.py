@@ -112,7 +112,7 @@ def test_hip_operators_match_tensorflows_graph(path):
         if n in scales:
             gr = gr - ber32 * float(np.float32(1e-4)) * scales[n] * vars_[n]
         return gr
-    tol = 2e-5
+    tol = 1e-5
     assert rel(wc.grad.cpu().numpy(), tfgrad("fft_like/conv3d/kernel")[0, t0, 0]) <= tol
     assert rel(bc.grad.cpu().numpy(), tfgrad("fft_like/conv3d/bias")) <= tol
     assert rel(Wd.grad.cpu().numpy(), tfgrad("demodulation/dense/kernel")) <= tol

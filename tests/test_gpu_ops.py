@@ -108,7 +108,7 @@ def test_cconv_gemm_no_bias_and_determinism(ops):
                                         (300, 80, 33)])
 def test_cconv_fwd_staged_is_bitwise_the_whole_k_tile(ops, rows, kin, F):
     """csrc/cconv_fwd.h: the N = 64 C-Conv forward with its k range cut into stages of 32 that are consumed as they land
-    (tuning key 2 = 7 / 8 / 9) writes the same values to the same LDS positions and issues the same MFMA chain as the
+    (tuning key 2 = 7 .. 11: 64 x 64 and 32 x 128 tiles, three LDS-store slots) writes the same values to the same LDS positions and issues the same MFMA chain as the
     whole-k tile of gemm_f32_mfma.h (key 2 = 0): every output bit is the same -- ragged last row tile, K = 128 (no
     cyclic prefix), column counts that are not a multiple of 64 and an odd F (which must fall back) included."""
     import ctypes as C
@@ -122,7 +122,7 @@ def test_cconv_fwd_staged_is_bitwise_the_whole_k_tile(ops, rows, kin, F):
     default = lib.dccn_get_tuning(2)
     outs = {}
     try:
-        for v in (0, 7, 8, 9):
+        for v in (0, 7, 8, 9, 10, 11):
             assert lib.dccn_set_tuning(2, v) == 0
             o = torch.full((rows, F, 2), float("nan"), device="cuda")
             _lib.check(lib.dccn_cconv_gemm_fwd(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
@@ -133,7 +133,7 @@ def test_cconv_fwd_staged_is_bitwise_the_whole_k_tile(ops, rows, kin, F):
         lib.dccn_set_tuning(2, default)
     ref = O.cconv_gemm_fwd(xv.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64))
     assert_close(outs[0].cpu().numpy(), ref, "whole-k tile vs oracle")
-    for v in (7, 8, 9):
+    for v in (7, 8, 9, 10, 11):
         assert torch.equal(outs[v], outs[0]), (v, float((outs[v] - outs[0]).abs().max()))
 
 

@@ -17,6 +17,7 @@
 #   eq | eqkt | eqab:<k=v0,v1>     equaliser step bench (73 / 1170 frames) | its kernel-trace summaries | A/B of a tuning key
 #   eqloop | e2e | conv            equaliser epoch loop | generate-and-train loop | general-k C-Conv bench
 #   config5[:args]                 tools/config5_sweep.py at full size -> config5/
+#   sh:<command>                   any shell command (output -> sh_<n>.txt)
 #   smoke                          __graft_entry__.smoke()
 TAG=${1:-r05}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -86,6 +87,7 @@ for ln in sys.stdin:
     conv)   timeout 600 python tools/convbench.py 2>&1 | grep -v amdgpu.ids | tee $O/convbench.jsonl | cut -c1-220 ;;
     config5)
       timeout 2400 python tools/config5_sweep.py --out $O/config5 --eq_epochs 0 $(echo $arg | tr ',' ' ') > $O/config5_run.log 2>&1; tail -3 $O/config5_run.log; cat $O/config5/config5_timing.json | head -40 ;;
+    sh)     timeout 900 bash -c "$arg" 2>&1 | grep -v amdgpu.ids | tee -a $O/sh_$n.txt | tail -12 ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt ;;
     *) echo "unknown section $name" ;;
   esac

@@ -21,6 +21,7 @@ OP_OF_KERNEL = [  # kernel-name substring -> bench.py operator key (C2 shapes)
     ("cconv_bwd_w_km_finalize_kernel", "cconv_bwd_w"),
     ("gemm_f32_mfma_kernel<1, 0,", "dense_fwd"),
     ("gemm_f32_mfma_kernel<1, 2,", "cconv_fwd"),        # any tile configuration of the C-Conv forward
+    ("cconv_fwd_staged_kernel", "cconv_fwd"),           # round 5: the staged whole-k tile (cconv_fwd.h)
     ("gemm_f32_mfma_kernel<0, 0,", "cconv_bwd_w"),
     ("cconv_bwd_w_finalize_kernel", "cconv_bwd_w"),
 ]
