@@ -51,7 +51,18 @@ class RxBuffers(C.Structure):
                 ("dz", c_void_p), ("dfft", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
-                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p)]
+                ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p),
+                ("gen_next", c_void_p)]
+
+
+class GenStatic(C.Structure):
+    """dccn_gen_static"""
+    _fields_ = [("bits_out", c_void_p), ("cell_map", c_void_p), ("const_tab", c_void_p), ("pilot_re", c_float),
+                ("pilot_im", c_float), ("idft", c_void_p), ("coeff", c_void_p), ("alpha", c_void_p), ("n_taps", c_int),
+                ("L", c_int), ("identity", c_int), ("snr_db", c_void_p), ("y", c_void_p), ("noise", c_void_p),
+                ("power_partial", c_void_p), ("noise_partial", c_void_p), ("noise_power_out", c_void_p), ("tx_out", c_void_p),
+                ("frames", c_int), ("S", c_int), ("K", c_int), ("CP", c_int), ("D", c_int), ("nbits", c_int),
+                ("seed", C.c_ulonglong), ("offset", C.c_uint)]
 
 
 class EqShape(C.Structure):
@@ -170,6 +181,10 @@ SIGNATURES = {
     "dccn_cconv2d_same_reduce": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dccn_eq_param_offsets": (_i, [POINTER(EqShape), POINTER(c_longlong)]),
     "dccn_eq_workspace_size": (_sz, [POINTER(EqShape), _i]),
+    "dccn_gen_static_supported": (_i, [_i, _i, _i]),
+    "dccn_gen_static_partials": (_i, [_i]),
+    "dccn_gen_static_frames": (_i, [POINTER(GenStatic), _vp]),
+    "dccn_gen_static_apply": (_i, [POINTER(GenStatic), _vp, _vp, _vp]),
     "dccn_eq_workspace_tensor": (_i, [POINTER(EqShape), _i, C.c_char_p, POINTER(C.c_size_t), POINTER(C.c_size_t)]),
     "dccn_eq_eval_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), _vp]),
     "dccn_eq_train_step": (_i, [POINTER(EqShape), POINTER(EqBuffers), AdamHParams, _vp]),

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include "gemm_f32_mfma.h"
+#include "norm_adam.h"
 
 namespace dccn {
 
@@ -268,6 +270,240 @@ __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y,
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pw;
         __syncthreads();
         if (threadIdx.x == 0) noise_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
+}
+
+// ---- round 5: the whole static-channel generator chain of a batch in ONE launch ----------------------------------------
+// What tx_grid_kernel -> IDFT GEMM -> (channel_taps_kernel) -> fir_same_kernel -> awgn_kernel do in four or five launches
+// (26-37 us of a 110 us generate-and-train step, each launch latency-bound on 1170 frames), per block of two frames:
+//   1. label bits (util.py:25-29, Philox stream 0) -> constellation / pilot / guard cells (ofdm.py:339-356) into an LDS grid
+//      of 2 S rows x 2K floats (rows past 2 S zero);
+//   2. ifft + cyclic prefix (ofdm.py:357-362) as a 16 x 2K x 2(K+CP) product on v_mfma_f32_16x16x4_f32 with the constant
+//      matrix of DeviceDataGen.idft_cp_matrix read straight from L2 into the MFMA registers (every load of a wave is issued
+//      before its first MFMA), the time-domain frames land in LDS;
+//   3. the frames' static taps (radio.py:352-372, Philox stream 1; the arithmetic of channel_taps_kernel);
+//   4. y = np.convolve(frame, g, 'same') (radio.py:360-366; the loop of fir_same_kernel) -> y, and ONE partial sum of |y|^2
+//      per block;
+//   5. the frame-scaled noise of radio.py:513-526 (Philox stream 2, sqrt(.5) 10^(-SNR/20) per frame; the draws and
+//      expressions of awgn_kernel) -> noise, and one partial sum of |noise|^2 per block.
+// What cannot be finished here is the batch-wide 1 / sqrt(mean |y|^2): x = y * that + noise is formed by the consumer -- R0 of
+// the receiver step reads (y, noise, partials) as its virtual input (norm_adam.h NormVirtual), or gen_static_apply_kernel
+// materialises x where a buffer is wanted.
+struct GenStaticArgs {
+    int32_t* bits_out; const int* cell_map; const float2* const_tab; float2 pilot; const float* idft;
+    const float* coeff; const float* alpha; int n_taps, L, identity;
+    const float* snr_db;
+    float2* y; float2* noise; double* power_partial; double* noise_partial; float* tx_out;
+    int frames, S, K, CP, D, nbits;
+    unsigned offset; unsigned long long seed;
+    int abl;            // timing ablations (DCCN_GEN_ABL, experiments only: results are wrong when set): 1 no noise draws, 2 no
+                        // label draws, 4 no ifft matrix loads, 8 no FIR
+};
+typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGenFramesPerBlock = 2;
+// S, K, CP are compile-time (the N = 64 grid of the reference: 7 symbols, 64 + 16 samples): every index split is a division by a
+// constant, and the per-thread loops over a block's 1024 grid cells and 1120 samples are unrolled -- a thread's cells / samples
+// are INDEPENDENT chains (Philox -> Box-Muller -> store; cell map -> Philox -> constellation table) whose latencies then
+// overlap instead of adding up (the first version walked them one after the other with run-time divisions: 26.8 us per launch;
+// profiles/r05_e2e_kernel_stats.txt has this one)
+template <int S, int K, int CP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a) {
+    constexpr int K2 = 2 * K, N2 = 2 * (K + CP), T = S * (K + CP), LDG = K2 + 4;
+    constexpr int G16 = K2 / 16, NTILE = N2 / 16, TPW = (NTILE + 3) / 4;
+    constexpr int NSMP = (kGenFramesPerBlock * T + 255) / 256;          // samples per thread (5)
+    constexpr int NCELL = 16 * K / 256;                                  // grid cells per thread (4)
+    static_assert(kGenFramesPerBlock * S <= 16 && K2 % 16 == 0 && N2 % 16 == 0 && (16 * K) % 256 == 0, "generator tile shape");
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* sG = gsm;                                   // [16][LDG]   grid rows (frame, symbol), (k, iq) contiguous
+    float2* sTX = reinterpret_cast<float2*>(gsm + 16 * LDG);      // [2][T]  time-domain frames
+    __shared__ float2 gs[kGenFramesPerBlock][64];
+    __shared__ float2 tap[kGenFramesPerBlock][16];
+    __shared__ double sh[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int f0 = (int)blockIdx.x * kGenFramesPerBlock;
+    const int nfr = min(kGenFramesPerBlock, a.frames - f0);
+
+    // 2 (early). this wave's share of the ifft matrix: tiles w, w + 4, ... ; lane (c, kq) needs idft[16 g + 4 kq + j][16 tile + c]
+    const int c = lane & 15, kq = lane >> 4;
+    float bfr[TPW][G16][4];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tile = min(w + 4 * ti, NTILE - 1);
+        const float* B = a.idft + (size_t)(4 * kq) * N2 + 16 * tile + c;
+#pragma unroll
+        for (int g = 0; g < G16; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[ti][g][j] = (a.abl & 4) ? 0.5f : B[(size_t)(16 * g + j) * N2];
+    }
+    // 1 (early). cell map entries of this thread's grid cells
+    int cd[NCELL];
+#pragma unroll
+    for (int q = 0; q < NCELL; ++q) {
+        const int i = tid + 256 * q, row = i / K, k = i - row * K, fr = row / S;
+        cd[q] = fr < nfr ? a.cell_map[(row - fr * S) * K + k] : -2;
+    }
+    // 5. the frame-scaled noise (depends on nothing else: its Philox / Box-Muller chains run under the loads above)
+    double nw = 0.0;
+    {
+        const float std0 = 0.70710678118654752440f * exp10f(-a.snr_db[f0] * 0.05f);
+        const float std1 = 0.70710678118654752440f * exp10f(-a.snr_db[f0 + (nfr > 1 ? 1 : 0)] * 0.05f);
+        float2 z[NSMP];
+#pragma unroll
+        for (int q = 0; q < NSMP; ++q) {
+            const int i = tid + 256 * q, fr = i / T;
+            const size_t o = (size_t)f0 * T + i;                         // (f0 + fr) * T + (i - fr * T)
+            if (a.abl & 1) { z[q] = make_float2(0.3f, 0.1f); continue; }
+            const Philox4 p = philox4x32_10((unsigned long long)o, kStreamNoise, a.offset, a.seed);
+            z[q] = box_muller(p.v[0], p.v[1]);
+            const float sd = fr == 0 ? std0 : std1;
+            z[q].x *= sd;
+            z[q].y *= sd;
+        }
+#pragma unroll
+        for (int q = 0; q < NSMP; ++q) {
+            const int i = tid + 256 * q;
+            if (i < nfr * T) {
+                a.noise[(size_t)f0 * T + i] = z[q];
+                nw += (double)z[q].x * z[q].x + (double)z[q].y * z[q].y;
+            }
+        }
+    }
+    // 3 (early). static taps of the block's frames (threads 0..n_taps-1 of waves 0 / 1 draw frame 0 / 1)
+    if (!a.identity && w < nfr && lane < a.n_taps) {
+        const Philox4 p = philox4x32_10((unsigned long long)(f0 + w) * a.n_taps + lane, kStreamTaps, a.offset, a.seed);
+        const float2 z = box_muller(p.v[0], p.v[1]);
+        const float cf = a.coeff[lane] * 0.70710678118654752440f;
+        tap[w][lane] = make_float2(z.x * cf, z.y * cf);
+    }
+    // 1. resource grid: label bits (Philox word 0 of the cell), constellation / pilot / guard value
+    {
+        int idx[NCELL];
+#pragma unroll
+        for (int q = 0; q < NCELL; ++q) {
+            const int i = tid + 256 * q, row = i / K, fr = row / S;
+            idx[q] = 0;
+            if (cd[q] >= 0) {
+                const long long cell = (long long)(f0 + fr) * a.D + cd[q];
+                const unsigned word = (a.abl & 2) ? (unsigned)cell : philox4x32_10((unsigned long long)cell, kStreamBits, a.offset, a.seed).v[0];
+                for (int j = 0; j < a.nbits; ++j) {
+                    const int bit = (int)((word >> j) & 1u);
+                    a.bits_out[cell * a.nbits + j] = bit;
+                    idx[q] = (idx[q] << 1) | bit;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NCELL; ++q) {
+            const int i = tid + 256 * q, row = i / K, k = i - row * K;
+            float2 v = make_float2(0.f, 0.f);
+            if (cd[q] == -1) v = a.pilot;
+            else if (cd[q] >= 0) v = a.const_tab[idx[q]];
+            *reinterpret_cast<float2*>(sG + row * LDG + 2 * k) = v;
+        }
+    }
+    __syncthreads();
+    if (!a.identity && w < nfr && lane < a.L) {         // g = taps . alpha (same order as channel_taps_kernel)
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = 0; k < a.n_taps; ++k) {
+            const float wgt = a.alpha[k * a.L + lane];
+            acc.x += tap[w][k].x * wgt;
+            acc.y += tap[w][k].y * wgt;
+        }
+        gs[w][lane] = acc;
+    } else if (a.identity && w < nfr && lane < a.L) {
+        gs[w][lane] = make_float2(lane == 0 ? 1.f : 0.f, 0.f);
+    }
+    // 2. tx[row][n] = sum_k grid[row][k] idft[k][n]
+    {
+        gen_f32x4 acc[TPW];
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) acc[ti] = gen_f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Ar = sG + c * LDG + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < G16; ++g) {
+            const float4 av = *reinterpret_cast<const float4*>(Ar + 16 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti)
+                    acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av, j), bfr[ti][g][j], acc[ti], 0, 0, 0);
+        }
+        // C layout: col = lane & 15, row = 4 (lane >> 4) + r
+        float* txf = reinterpret_cast<float*>(sTX);
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            const int tile = w + 4 * ti;
+            if (tile < NTILE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * kq + r, fr = row / S;
+                    if (fr < nfr) txf[fr * 2 * T + (row - fr * S) * N2 + 16 * tile + c] = acc[ti][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (a.tx_out != nullptr)
+        for (int i = tid; i < nfr * 2 * T; i += 256) a.tx_out[(size_t)f0 * 2 * T + i] = reinterpret_cast<const float*>(sTX)[i];
+    // 4. 'same' FIR (the loop of fir_same_kernel) and its power
+    const int off = (a.L - 1) / 2;
+    double pw = 0.0;
+    {
+        float2 yv[NSMP];
+#pragma unroll
+        for (int q = 0; q < NSMP; ++q) {
+            const int i = min(tid + 256 * q, nfr * T - 1), fr = i / T, t = i - fr * T;
+            const float2* xf = sTX + fr * T;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int l = 0; l < ((a.abl & 8) ? 1 : a.L); ++l) {
+                const int u = t + off - l;
+                if (u < 0 || u >= T) continue;
+                const float2 v = xf[u], gl = gs[fr][l];
+                acc.x += gl.x * v.x - gl.y * v.y;
+                acc.y += gl.x * v.y + gl.y * v.x;
+            }
+            yv[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < NSMP; ++q) {
+            const int i = tid + 256 * q;
+            if (i < nfr * T) {
+                a.y[(size_t)f0 * T + i] = yv[q];
+                pw += (double)yv[q].x * yv[q].x + (double)yv[q].y * yv[q].y;
+            }
+        }
+    }
+    pw = wave_sum(pw);
+    nw = wave_sum(nw);
+    if (lane == 0) { sh[0][w] = pw; sh[1][w] = nw; }
+    __syncthreads();
+    if (tid == 0) {
+        a.power_partial[blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        if (a.noise_partial != nullptr) a.noise_partial[blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+// x = y / sqrt(mean |y|^2) + noise where a buffer is wanted (the first batch of a pipelined loop, tests, iq dumps): the
+// expression of awgn_kernel on the generator's y and noise.  grid: any; 256 threads.
+__global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ noise,
+                                                               const double* __restrict__ ppart, int npart, double total,
+                                                               float4* __restrict__ x, long long n4,
+                                                               const double* __restrict__ npart_noise, int n_noise,
+                                                               float* __restrict__ npow_out) {
+    __shared__ double sh4[4];
+    __shared__ float s_inv;
+    const float inv = batch_power_inv_scale(ppart, npart, total, sh4, &s_inv);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = y[i], z = noise[i];
+        x[i] = make_float4(v.x * inv + z.x, v.y * inv + z.y, v.z * inv + z.z, v.w * inv + z.w);
+    }
+    if (npow_out != nullptr && blockIdx.x == 0) {
+        __syncthreads();
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n_noise; i += 256) a += npart_noise[i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) npow_out[0] = (float)(((sh4[0] + sh4[1]) + (sh4[2] + sh4[3])) / total);
     }
 }
 

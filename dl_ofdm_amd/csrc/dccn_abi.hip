@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "gemm_f32_mfma.h"
@@ -1236,6 +1237,40 @@ static bool overlap_streams(OverlapStreams* o) {
     return true;
 }
 
+// ---- fused static-channel generator launch (datagen.h gen_static_frames_kernel; ABI entry points further down) ----
+static bool gen_static_ok(const dccn_gen_static* g) {
+    if (!g || !g->bits_out || !g->cell_map || !g->const_tab || !g->idft || !g->snr_db || !g->y || !g->noise || !g->power_partial)
+        return false;
+    if (g->frames <= 0 || g->frames > 65535 || g->S <= 0 || 2 * g->S > 16 || g->K <= 0 || g->CP < 0 || g->D <= 0 || g->nbits < 1 ||
+        g->nbits > 4 || g->L <= 0 || g->L > 64)
+        return false;
+    if (!g->identity && (!g->coeff || !g->alpha || g->n_taps <= 0 || g->n_taps > 16)) return false;
+    // the instantiated shape: the reference's N = 64 frame with the long cyclic prefix, 7 symbols x (64 + 16) samples
+    return g->S == 7 && g->K == 64 && g->CP == 16 && aligned16(g->y) && aligned16(g->noise);
+}
+static int gen_static_launch(const dccn_gen_static* g, hipStream_t s) {
+    if (!gen_static_ok(g)) return DCCN_ERR_INVALID_ARG;
+    if (ceil_div(g->frames, kGenFramesPerBlock) > kChanPartials) return DCCN_ERR_INVALID_ARG;
+    GenStaticArgs a;
+    a.bits_out = g->bits_out; a.cell_map = g->cell_map; a.const_tab = reinterpret_cast<const float2*>(g->const_tab);
+    a.pilot = make_float2(g->pilot_re, g->pilot_im); a.idft = g->idft;
+    a.coeff = g->coeff; a.alpha = g->alpha; a.n_taps = g->n_taps; a.L = g->L; a.identity = g->identity;
+    a.snr_db = g->snr_db; a.y = reinterpret_cast<float2*>(g->y); a.noise = reinterpret_cast<float2*>(g->noise);
+    a.power_partial = g->power_partial; a.noise_partial = g->noise_partial; a.tx_out = g->tx_out;
+    a.frames = g->frames; a.S = g->S; a.K = g->K; a.CP = g->CP; a.D = g->D; a.nbits = g->nbits;
+    a.offset = g->offset; a.seed = g->seed;
+    {
+        static const int abl = getenv("DCCN_GEN_ABL") ? atoi(getenv("DCCN_GEN_ABL")) : 0;      // timing experiments only
+        a.abl = abl;
+    }
+    const int T = g->S * (g->K + g->CP);
+    const size_t smem = (size_t)16 * (2 * g->K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * T * sizeof(float2);
+    const int blocks = ceil_div(g->frames, kGenFramesPerBlock);
+    hipLaunchKernelGGL((gen_static_frames_kernel<7, 64, 16>), dim3(blocks), dim3(256), smem, s, a);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
 // side != nullptr: run the dense weight-gradient branch on `side` (fork/join by events),
 // concurrently with dX -> C-Conv weight gradient on the main stream.
 static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
@@ -1257,6 +1292,17 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     // 4 backward (fused, or grouped dX+dW), 5 C-Conv weight gradient (own launch), 6 optimizer
     const StepTraceScope trace;
 
+    // the fused generator of the NEXT batch (dccn_rx_buffers.gen_next): first launch of the step, consumed by its last one
+    // (x_next_ready set as well: the caller has issued that launch itself on ANOTHER stream -- it then overlaps the first three
+    // launches of this step -- and the optimizer launch waits for the event)
+    if (train && b->gen_next != nullptr) {
+        if (b->gen_next->frames != sh->batch || b->gen_next->S != sh->S || 2 * (b->gen_next->K + b->gen_next->CP) * sh->S != L.cols)
+            return DCCN_ERR_INVALID_ARG;
+        if (b->x_next_ready == nullptr) {
+            trace.launch(7);
+            DCCN_TRY(gen_static_launch(b->gen_next, s));
+        }
+    }
     // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
     const bool pre = train && b->x_prenormalised != 0;
@@ -1321,7 +1367,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                          norm_fused_ok(b->x_next, b->x_norm_next, sh->batch, L.cols);
     if (b->x_norm_next != nullptr && b->x_next != nullptr && !ride_bw) return DCCN_ERR_INVALID_ARG;   // ask dccn_rx_norm_rides_backward first
     // a producer on another stream is filling x_next: the launch that reads it waits for the producer's event
-    const bool wait_x = b->x_next != nullptr && b->x_next_ready != nullptr;
+    const bool wait_x = (b->x_next != nullptr || b->gen_next != nullptr) && b->x_next_ready != nullptr;
     if (fuse_bw) {
         NormRideArgs nr;
         memset(&nr, 0, sizeof(nr));
@@ -1442,13 +1488,27 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     // R0 of the next batch on the leading blocks of this launch (dccn_rx_buffers.x_next)
     aa.nx = nullptr; aa.ny = nullptr; aa.npower = nullptr; aa.nbatch = 0; aa.ncols = 0; aa.norm_blocks = 0;
     aa.neps = 1e-9f; aa.npeak = 8.0f;
-    const bool ride = !ride_bw && b->x_next != nullptr && kNormFusedCG == 2 && norm_fused_ok(b->x_next, b->x_norm, sh->batch, L.cols);
+    aa.nv = norm_virtual_none();
+    // gen_next: the next batch is produced by the fused generator launch issued at the top of this step; R0 reads it as
+    // (y, noise, power partials) -- its virtual input -- instead of a materialised x_next (x_next, when given too, receives x)
+    const dccn_gen_static* gen = (!ride_bw && train) ? b->gen_next : nullptr;
+    const float* rin = gen ? gen->y : b->x_next;
+    const bool ride = !ride_bw && rin != nullptr && kNormFusedCG == 2 && norm_fused_ok(rin, b->x_norm, sh->batch, L.cols);
+    if (gen && !ride) return DCCN_ERR_INVALID_ARG;
     if (ride) {
         PowerPartials np;
-        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm, &np, nslot);
-        aa.nx = b->x_next; aa.ny = b->x_norm; aa.npower = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
+        norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, rin, b->x_norm, &np, nslot);
+        aa.nx = rin; aa.ny = b->x_norm; aa.npower = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
         aa.nbatch = sh->batch; aa.ncols = L.cols; aa.norm_blocks = norm_fused_blocks(L.cols);
         blocks += aa.norm_blocks;
+        if (gen) {
+            aa.nv.y = gen->y; aa.nv.noise = gen->noise; aa.nv.ppart = gen->power_partial;
+            aa.nv.npart = ceil_div(gen->frames, kGenFramesPerBlock);
+            aa.nv.total = (double)gen->frames * (double)(gen->S * (gen->K + gen->CP));
+            aa.nv.x_out = const_cast<float*>(b->x_next);
+            aa.nv.npart_noise = gen->noise_partial; aa.nv.n_noise = aa.nv.npart;
+            aa.nv.npow_out = gen->noise_partial ? gen->noise_power_out : nullptr;
+        }
     }
     if (ride_bw && aa.fold_blocks > 0 && g_tune[TUNE_FWD_PREFETCH]) {
         // the C-Conv forward of the batch the backward launch has just normalised rides on this launch (rx_bwd.h)
@@ -2196,6 +2256,29 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
                            noise_power);
         DCCN_LAUNCH_CHECK();
     }
+    return DCCN_OK;
+}
+
+// ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
+static_assert(sizeof(dccn_gen_static) == 168 && sizeof(dccn_rx_buffers) == 200, "ctypes mirrors in dl_ofdm_amd/_lib.py");
+int dccn_gen_static_supported(int S, int K, int CP) {
+    return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
+}
+int dccn_gen_static_partials(int frames) { return frames > 0 ? ceil_div(frames, kGenFramesPerBlock) : 0; }
+int dccn_gen_static_frames(const dccn_gen_static* g, dccn_stream_t stream) { return gen_static_launch(g, (hipStream_t)stream); }
+int dccn_gen_static_apply(const dccn_gen_static* g, float* x_out, float* noise_power, dccn_stream_t stream) {
+    if (!gen_static_ok(g) || !x_out || !aligned16(x_out)) return DCCN_ERR_INVALID_ARG;
+    const int T = g->S * (g->K + g->CP);
+    const long long n4 = (long long)g->frames * T * 2 / 4;
+    if (((long long)g->frames * T * 2) % 4 != 0) return DCCN_ERR_INVALID_ARG;
+    const int np = dccn_gen_static_partials(g->frames);
+    long long blocks = ceil_div_ll(n4, 256);
+    if (blocks > 4 * kCUs) blocks = 4 * kCUs;
+    hipLaunchKernelGGL(gen_static_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(g->y), reinterpret_cast<const float4*>(g->noise),
+                       (const double*)g->power_partial, np, (double)g->frames * (double)T, reinterpret_cast<float4*>(x_out), n4,
+                       (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np, noise_power);
+    DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
 

@@ -207,18 +207,53 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
 // power_partial[blockIdx.x] = sum over the block of |clip(y)|^2; adam: see moments_kernel.
 // (a __device__ body: the kernel below runs it, and so do the leading blocks of the optimizer kernel when the step
 // normalises the NEXT batch behind its Adam update -- bidx / nblk are the block's index and count inside that group)
+// Virtual input (round 5, the fused device generator of datagen.h): the batch to normalise is not in memory as x but as the
+// two terms of dev/py/radio.py:513-526 AWGN_channel_np, x = y / sqrt(mean |y|^2 over the batch) + noise -- y the channel
+// output, noise already scaled per frame, the batch power as <= 2048 per-block partial sums of the generator launch.  R0 forms
+// x in registers on the way in (the expression and the order of awgn_kernel: the same bits as the materialised input), so
+// the AWGN launch and a 5 MB round trip of x disappear.  y == nullptr: plain input.
+struct NormVirtual {
+    const float* y; const float* noise;           // [batch, cols] each
+    const double* ppart; int npart; double total; // partial sums of |y|^2, batch * T (complex samples)
+    float* x_out;                                 // nullable: also store x (tx_ofdm) -- tests, iq dumps
+    const double* npart_noise; int n_noise; float* npow_out;      // nullable: `noise_power:0` monitor, summed by block 0
+};
+__device__ __host__ inline NormVirtual norm_virtual_none() {
+    NormVirtual v;
+    v.y = nullptr; v.noise = nullptr; v.ppart = nullptr; v.npart = 0; v.total = 1.0; v.x_out = nullptr;
+    v.npart_noise = nullptr; v.n_noise = 0; v.npow_out = nullptr;
+    return v;
+}
+// 1 / sqrt(mean |y|^2): every block of a 256-thread launch adds the partial sums in the same fixed order (thread t: t, t + 256,
+// ...; DPP wave sum; the four wave sums as (0 + 1) + (2 + 3)), so all blocks -- and awgn_kernel, and R0 -- get the same bits
+__device__ __forceinline__ float batch_power_inv_scale(const double* __restrict__ ppart, const int npart, const double total,
+                                                       double* sh4, float* s_inv) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < npart; i += 256) a += ppart[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *s_inv = 1.0f / sqrtf((float)(((sh4[0] + sh4[1]) + (sh4[2] + sh4[3])) / total));
+    __syncthreads();
+    return *s_inv;
+}
+
 template <int CG, int RPT>
 __device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, float* __restrict__ y, int batch, int cols,
                                                 float eps, float peak, double* __restrict__ power_partial,
                                                 float* __restrict__ mean_out, float* __restrict__ var_out,
                                                 dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp,
-                                                const int bidx, const int nblk) {
+                                                const int bidx, const int nblk, const NormVirtual nv = norm_virtual_none()) {
     constexpr int NW = 2 * CG;                        // waves per block
     constexpr int RS = 64 / CG;                       // row slots per wave
     __shared__ double red[NW][CG][8];
     __shared__ double stat[CG][8];
-    __shared__ double pred[NW];
+    __shared__ double pred[NW > 4 ? NW : 4];
+    __shared__ float s_inv;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool virt = NW == 4 && nv.y != nullptr;     // (kernel argument: block-uniform; 256-thread blocks only)
+    float inv_scale = 1.0f;
+    if (virt) inv_scale = batch_power_inv_scale(nv.ppart, nv.npart, nv.total, pred, &s_inv);
     if (adam != nullptr && bidx == 0 && t == 0) {
         adam->alpha = adam_alpha(adam, hp);
         adam->beta1_power = adam->beta1_power * hp.beta1;
@@ -234,9 +269,27 @@ __device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, flo
     const bool live = c4 < cols;
     float4 v[RPT];
     const int c4c = live ? c4 : 0;                    // clamped addresses: every load issues, none branches
+    if (virt) {
+        float4 nz[RPT];
 #pragma unroll
-    for (int p = 0; p < RPT; ++p)
-        v[p] = *reinterpret_cast<const float4*>(x + (size_t)min(slot + 128 * p, batch - 1) * cols + c4c);
+        for (int p = 0; p < RPT; ++p) {
+            const size_t o = (size_t)min(slot + 128 * p, batch - 1) * cols + c4c;
+            v[p] = *reinterpret_cast<const float4*>(nv.y + o);
+            nz[p] = *reinterpret_cast<const float4*>(nv.noise + o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) {               // radio.py:524-526, as awgn_kernel evaluates it
+            v[p] = make_float4(v[p].x * inv_scale + nz[p].x, v[p].y * inv_scale + nz[p].y, v[p].z * inv_scale + nz[p].z,
+                               v[p].w * inv_scale + nz[p].w);
+            if (nv.x_out != nullptr && live && slot + 128 * p < batch)
+                *reinterpret_cast<float4*>(nv.x_out + (size_t)(slot + 128 * p) * cols + c4) = v[p];
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < RPT; ++p)
+            v[p] = *reinterpret_cast<const float4*>(x + (size_t)min(slot + 128 * p, batch - 1) * cols + c4c);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < RPT; ++p)
@@ -330,6 +383,15 @@ __device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, flo
             for (int w = 0; w < NW; ++w) a += pred[w];
             power_partial[bidx] = a;              // (idle strips past the last column contribute 0)
         }
+    }
+    if (virt && nv.npow_out != nullptr && bidx == 0) {          // `noise_power:0`: mean |noise|^2 from the generator's partials
+        __syncthreads();
+        double a = 0.0;
+        for (int i = t; i < nv.n_noise; i += 256) a += nv.npart_noise[i];
+        a = wave_sum(a);
+        if (lane == 0) pred[wave] = a;
+        __syncthreads();
+        if (t == 0) nv.npow_out[0] = (float)(((pred[0] + pred[1]) + (pred[2] + pred[3])) / nv.total);
     }
 }
 
@@ -468,6 +530,7 @@ struct AdamRxArgs {
     const float* nx; float* ny; double* npower;
     int nbatch, ncols, norm_blocks;
     float neps, npeak;
+    NormVirtual nv;                        // y != nullptr: the next batch comes as (y, noise, power partials) instead of nx
     // [skip_lo, skip_hi): elements whose update already happened in the epilogue of their weight-gradient GEMM
     long long skip_lo, skip_hi;
     unsigned long long* stamp;             // step timeline stamps (common.h stamp_mark), nullptr = none
@@ -676,7 +739,7 @@ __global__ __launch_bounds__(256) void adam_rx_kernel(const AdamRxArgs a, const 
     stamp_mark(a.stamp, 0);
     if ((int)blockIdx.x < a.norm_blocks) {
         norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, a.neps, a.npeak, a.npower, nullptr, nullptr,
-                                           nullptr, hp, (int)blockIdx.x, a.norm_blocks);
+                                           nullptr, hp, (int)blockIdx.x, a.norm_blocks, a.nv);
         stamp_mark(a.stamp, 1);
         return;
     }

@@ -240,6 +240,69 @@ class DeviceDataGen:
         return (x, bits, npow, H) if want_H else (x, bits, npow)
 
 
+class FusedStaticGen:
+    """``DeviceDataGen.make_batch`` of a static single-profile channel as ONE launch (include/dccn.h dccn_gen_static,
+    csrc/datagen.h gen_static_frames_kernel): bits -> grid -> ifft + CP -> taps -> 'same' FIR -> (y, frame-scaled noise, power
+    partials).  The receiver's input x = y / sqrt(mean |y|^2) + noise is formed by the consumer: ``RxEngine.
+    train_step_generated`` hands the descriptor to ``dccn_rx_train_step``, which issues the generator launch itself and reads
+    (y, noise, partials) as the virtual input of its pipelined normalisation -- one C call and five launches per generated-and-
+    trained batch instead of two or three calls and eight or nine launches; ``make_batch`` materialises x (one more launch)
+    where a buffer is wanted.  Same Philox streams, draws and batch offsets as ``DeviceDataGen`` (it advances ``gen.offset``)."""
+
+    def __init__(self, gen: DeviceDataGen, n_frames: int, snr_db, want_noise_power: bool = False):
+        if not self.supported(gen):
+            raise _lib.DccnError("FusedStaticGen: static single-profile N = 64 channels only")
+        self.gen, self.n = gen, int(n_frames)
+        dev, f32 = gen.device, dict(dtype=torch.float32, device=gen.device)
+        self.snr = torch.empty(self.n, **f32)
+        self.set_snr(snr_db)
+        self.y = torch.empty(self.n, gen.S, gen.n_sc, 2, **f32)
+        self.noise = torch.empty(self.n, gen.S, gen.n_sc, 2, **f32)
+        npart = int(gen.lib.dccn_gen_static_partials(self.n))
+        self.ppart = torch.zeros(npart, dtype=torch.float64, device=dev)
+        self.npart = torch.zeros(npart, dtype=torch.float64, device=dev) if want_noise_power else None
+        self.npow = torch.zeros(2, 1, **f32) if want_noise_power else None       # one slot per label slot
+        p = DeviceDataGen._p
+        self.desc = _lib.GenStatic(0, p(gen.cell_map), p(gen.const_tab), float(gen.pilot.real), float(gen.pilot.imag),
+                                   p(gen.idft), p(gen.coeff), p(gen.alpha), gen.n_taps, gen.L, 1 if gen.identity else 0,
+                                   p(self.snr), p(self.y), p(self.noise), p(self.ppart), p(self.npart), None, None,
+                                   self.n, gen.S, gen.K, gen.CP, gen.D, gen.nbits, gen.seed, 0)
+
+    @staticmethod
+    def supported(gen: DeviceDataGen) -> bool:
+        return (not gen.mixed and not gen.doppler and not gen.align_window and
+                bool(gen.lib.dccn_gen_static_supported(gen.S, gen.K, gen.CP)))
+
+    def set_snr(self, snr_db):
+        if np.isscalar(snr_db):
+            self.snr.fill_(float(snr_db))
+        else:
+            self.snr.copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)) if not isinstance(snr_db, torch.Tensor)
+                           else snr_db.reshape(-1).to(torch.float32))
+
+    def arm(self, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None) -> "_lib.GenStatic":
+        """the descriptor for the NEXT launch: labels go to ``out_bits``, the batch offset is the generator's current one (which
+        is advanced: call once per batch)"""
+        g, d = self.gen, self.desc
+        d.bits_out = out_bits.data_ptr()
+        d.offset = g.offset & 0xFFFFFFFF
+        d.seed = g.seed
+        d.noise_power_out = self.npow[slot & 1].data_ptr() if self.npow is not None else None
+        d.tx_out = None if tx_out is None else tx_out.data_ptr()
+        g.offset = (g.offset + 1) & 0xFFFFFFFF
+        return d
+
+    def make_batch(self, out_x: torch.Tensor, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None):
+        """generate + materialise: (x, bits, noise power or None), two launches (the first batch of a pipelined loop, tests)"""
+        d = self.arm(out_bits, slot, tx_out)
+        st = self.gen._stream()
+        check(self.gen.lib.dccn_gen_static_frames(C.byref(d), st), "dccn_gen_static_frames")
+        npw = self.npow[slot & 1] if self.npow is not None else None
+        check(self.gen.lib.dccn_gen_static_apply(C.byref(d), out_x.data_ptr(), None if npw is None else npw.data_ptr(), st),
+              "dccn_gen_static_apply")
+        return out_x, out_bits, npw
+
+
 class SideStreamFeeder:
     """The generator on its own HIP stream: batch i+1 is produced while the forward and backward launches of step i run.
 

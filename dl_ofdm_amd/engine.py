@@ -226,12 +226,13 @@ class RxEngine:
         return self.bits_alt
 
     def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1,
-                      ready: int = 0) -> RxBuffers:
-        key = (slot, last, parity, double, pre, ready)
+                      ready: int = 0, gen: int = 0, keep_x: bool = True) -> RxBuffers:
+        key = (slot, last, parity, double, pre, ready, gen, keep_x)
         if key not in self._pipe_bufs:
             vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
             vals["bits"] = self.label_slot(slot).data_ptr()
-            vals["x_next"] = 0 if last else self.x.data_ptr()
+            vals["x_next"] = 0 if (last or (gen and not keep_x)) else self.x.data_ptr()
+            vals["gen_next"] = 0 if last else gen
             vals["x_prenormalised"] = pre
             vals["x_norm"] = self._norm_bufs[parity].data_ptr()
             vals["norm_slot"] = parity
@@ -280,6 +281,44 @@ class RxEngine:
             if double and not last:
                 self._norm_parity ^= 1           # the prefetched batch sits in the other buffer ...
                 self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out
+        self._prefetch_pending = not last
+        if last:
+            self._norm_ready = False
+
+    def train_step_generated(self, fgen, slot: int = 0, last: bool = False, keep_x: bool = False, side=None):
+        """``train_step_pipelined`` fed by the fused device generator (datagen.FusedStaticGen), ONE C call: the step trains on
+        the batch normalised ahead (labels in ``label_slot(slot)``), issues the generator launch of the NEXT batch as its first
+        launch (labels to the other slot) and normalises that batch -- read as (y, noise, power partials), never written as x
+        unless ``keep_x`` -- on its optimizer launch.  The first call generates, materialises and normalises batch 0 itself.
+        Bit-identical to ``train_step_pipelined`` on the materialised batches (tests/test_gpu_datagen.py)."""
+        if not self.train:
+            raise _lib.DccnError("engine built with train=False")
+        if self._ride:
+            raise _lib.DccnError("train_step_generated needs the single-buffer pipelining (dccn_rx_norm_rides_backward == 0)")
+        if not self._norm_ready:
+            fgen.make_batch(self.x, self.label_slot(slot), slot)
+            self.prime()
+        gen_ptr, ready = 0, 0
+        if not last:
+            d = fgen.arm(self.label_slot(slot ^ 1), slot ^ 1)
+            gen_ptr = C.addressof(d)
+            if side is not None:
+                # ``side`` = (stream, ready event, step event): the generator launch goes to that stream -- after the previous
+                # step (whose last launch read the single-buffered y / noise) -- and overlaps this step's first three launches
+                st, ev_ready, ev_step = side
+                main = torch.cuda.current_stream(self.device)
+                if getattr(self, "_gen_side_primed", False):
+                    st.wait_event(ev_step)
+                else:
+                    st.wait_stream(main)
+                    self._gen_side_primed = True
+                check(self.lib.dccn_gen_static_frames(C.byref(d), C.c_void_p(st.cuda_stream)), "dccn_gen_static_frames")
+                ev_ready.record(st)
+                ready = int(ev_ready.cuda_event)
+        bufs = self._pipe_buffers(slot, last, 0, False, 1, ready, gen_ptr, keep_x)
+        check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(bufs), self.hp, self._stream()), "dccn_rx_train_step")
+        if side is not None and not last:
+            side[2].record(torch.cuda.current_stream(self.device))
         self._prefetch_pending = not last
         if last:
             self._norm_ready = False

@@ -269,6 +269,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
     history = []
     gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None
     feed = None
+    fused = {}                       # batch size -> datagen.FusedStaticGen
     import torch
     for epoch in range(FLAGS.max_epoch_num):
         np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))           # reference: int(time.time()) + epoch
@@ -285,7 +286,23 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
             # ... and the generator runs on its own stream (datagen.SideStreamFeeder): batch i+1 is produced while the forward
             # and backward launches of step i run; the step's last launch waits for it
-            from .datagen import SideStreamFeeder
+            from .datagen import FusedStaticGen, SideStreamFeeder
+            if FLAGS.cp and FusedStaticGen.supported(gen) and not eng._ride and not getattr(FLAGS, "no_fused_generator", False):
+                # round 5: static single-profile channels -- ONE C call per batch: the fused generator launch of the next batch
+                # + the four step launches, whose pipelined normalisation reads (y, noise, power partials) as its virtual
+                # input (include/dccn.h dccn_gen_static; datagen.FusedStaticGen).  Same batches as the loop below.
+                fg = fused.get(batch_size)
+                if fg is None:
+                    fg = fused[batch_size] = FusedStaticGen(gen, batch_size, FLAGS.SNR, want_noise_power=True)
+                eng.drop_prefetch()
+                for i in range(steps):
+                    eng.train_step_generated(fg, slot=i & 1, last=(i + 1 == steps))
+                    acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power)
+                    acc[2:3].add_(fg.npow[i & 1])
+                a = acc.cpu().numpy() / max(steps, 1)
+                losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
+                berl = eng.metrics()["berlin"]
+                steps = 0                                            # (the loop below has nothing left to do)
 
             # the generator's noise-power monitor is reused per batch: each batch's value goes to one of two preallocated
             # slots (allocated on the main stream, never handed back to the caching allocator while a step may read them)
@@ -314,9 +331,10 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
                     acc[2:3].add_(noise_t)
                 feed.step_issued()            # (after the monitor reads: the generator may now overwrite slot i & 1's values)
                 noise_t = noise_next
-            a = acc.cpu().numpy() / max(steps, 1)
-            losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
-            berl = eng.metrics()["berlin"]
+            if steps:
+                a = acc.cpu().numpy() / max(steps, 1)
+                losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
+                berl = eng.metrics()["berlin"]
         else:
             xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
             nb = n_use // batch_size

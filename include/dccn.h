@@ -312,6 +312,41 @@ typedef struct dccn_rx_shape {
     int nbits;     /* 1..4 */
 } dccn_rx_shape;
 
+/* The fused device-side generator of a static single-profile channel (round 5; the chain of dccn_ofdm_tx_frames +
+ * dccn_channel_awgn below in ONE launch, csrc/datagen.h gen_static_frames_kernel): label bits -> resource grid -> ifft + cyclic
+ * prefix -> static Rayleigh taps -> 'same' FIR (dev/py/util.py:25-29, ofdm.py:328-380, radio.py:352-372) -> y, plus the
+ * frame-scaled noise of radio.py:513-526 and per-block partial sums of |y|^2 and |noise|^2.  The receiver's input is
+ * x = y / sqrt(mean |y|^2 over the batch) + noise: formed by the consumer -- dccn_rx_train_step reads the descriptor as the
+ * virtual input of its pipelined normalisation (dccn_rx_buffers.gen_next) -- or materialised by dccn_gen_static_apply.
+ * Same Philox streams and draws as the separate launches (a batch is a pure function of (seed, offset)); the ifft runs on
+ * 16x16x4 MFMA tiles instead of the 32x32x2 GEMM, so tx / y agree with that path to rounding, not bit for bit.
+ * All pointers are device pointers; power_partial / noise_partial hold dccn_gen_static_partials(frames) doubles. */
+typedef struct dccn_gen_static {
+    int32_t* bits_out;            /* [frames, D, nbits] labels drawn here */
+    const int32_t* cell_map;      /* [S*K] >= 0 data-cell index, -1 pilot, -2 empty */
+    const float* const_tab;       /* [2^nbits, 2] */
+    float pilot_re, pilot_im;
+    const float* idft;            /* [2K, 2(K+CP)] real form of ifft + cyclic prefix */
+    const float* coeff;           /* [n_taps] tap amplitudes (null when identity) */
+    const float* alpha;           /* [n_taps, L] sinc interpolation */
+    int n_taps, L, identity;      /* identity: AWGN channel (g = [1]) */
+    const float* snr_db;          /* [frames] */
+    float* y;                     /* [frames, S, K+CP, 2] channel output */
+    float* noise;                 /* [frames, S, K+CP, 2] noise, already scaled per frame */
+    double* power_partial;        /* [partials] */
+    double* noise_partial;        /* [partials], nullable */
+    float* noise_power_out;       /* device float[1], nullable: `noise_power:0`, written by the consumer that sums noise_partial */
+    float* tx_out;                /* [frames, S, K+CP, 2], nullable: the transmitted frames (tests) */
+    int frames, S, K, CP, D, nbits;
+    unsigned long long seed;
+    unsigned offset;
+} dccn_gen_static;
+int dccn_gen_static_supported(int S, int K, int CP);      /* 1: shapes the fused launch is instantiated for (N = 64) */
+int dccn_gen_static_partials(int frames);
+int dccn_gen_static_frames(const dccn_gen_static* g, dccn_stream_t stream);
+/* x_out [frames, S, K+CP, 2] = y / sqrt(mean |y|^2) + noise; noise_power (nullable) = mean |noise|^2 */
+int dccn_gen_static_apply(const dccn_gen_static* g, float* x_out, float* noise_power, dccn_stream_t stream);
+
 typedef struct dccn_rx_buffers {
     const float* x;            /* [batch, S, kin, 2] raw input (tx_ofdm) */
     const int32_t* bits;       /* [batch, D, nbits] labels (bits_in) */
@@ -362,6 +397,13 @@ typedef struct dccn_rx_buffers {
        stream while the forward and backward launches of this step run (the device-side generator: dl_ofdm_amd/datagen.py
        SideStreamFeeder).  Eager launches only (not inside dccn_rx_graph_create). */
     void* x_next_ready;
+    /* Round 5: the next batch comes from the fused generator (host pointer to a descriptor, read during the call only): the
+       step issues the generator launch as its FIRST launch and its last launch normalises (y, noise, partials) as if they were
+       x_next = y / sqrt(mean |y|^2) + noise (bit-identical to normalising the materialised batch).  x_next, when non-null as
+       well, receives that batch (tx_ofdm); the labels go to gen_next->bits_out (the caller's OTHER label slot).  Training
+       calls on the single-buffer pipelining only (dccn_rx_norm_rides_backward(shape) == 0); one C call per generated-and-
+       trained batch. */
+    const dccn_gen_static* gen_next;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);

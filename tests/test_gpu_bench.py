@@ -30,7 +30,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     diag = json.dumps({"regions_ms": st["regions_ms"], "boundaries": st.get("boundaries"),
                        "clocks": d["device"].get("clocks_before_timed_regions")})
     assert len(st["regions_ms"]) == 7 and abs(sorted(st["regions_ms"])[3] - d["ms_per_step"]) < 1e-4, diag
-    assert st["mfma_frac"] >= 0.33, "C2 step below 33 %% of the fp32 MFMA peak: %s" % diag
+    # (round 5: 0.410 with the driver's arguments, 0.415 over 500 steps; VERDICT r04 asked for >= 0.36 once the step was past 0.40)
+    assert st["mfma_frac"] >= 0.37, "C2 step below 37 %% of the fp32 MFMA peak: %s" % diag
+    assert d["distributed"]["world"] == 1 and d["distributed"]["points_per_rank"] == [40]
     bd = st["boundaries"]
     names = [l["name"] for l in bd["launches"]]
     assert names == ["cconv_fwd", "dense_fwd_tail", "backward", "optimizer"], names       # the 4-launch plan, in stream order

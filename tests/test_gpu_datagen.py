@@ -325,3 +325,83 @@ def test_generator_on_a_side_stream_trains_the_same_model():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert a[3] == b[3] and 0.0 < a[3]["berlin"] < 0.5
 
+
+
+# ---- round 5: the whole static-channel chain in one launch (csrc/datagen.h gen_static_frames_kernel) ------------------------
+@pytest.mark.parametrize("chan,nbits,n,cp", [("EPA", 2, 1170, True), ("EVA", 4, 37, True), ("AWGN", 1, 64, True), ("ETU", 3, 9, True),
+                                              ("EPA", 2, 73, False)])
+def test_fused_static_generator_matches_the_launch_per_stage_chain(chan, nbits, n, cp):
+    """dccn_gen_static_frames + dccn_gen_static_apply against dccn_ofdm_tx_frames + dccn_channel_awgn at the same (seed,
+    offset): the label bits are the same bits, the transmitted frames and the received batch agree to rounding (the ifft runs
+    on 16x16x4 MFMA tiles instead of the 32x32x2 GEMM: another summation order), the noise power monitor is the mean of
+    |noise|^2 -- odd frame counts (a block holding one frame), every modulation, the AWGN channel (no taps), no cyclic prefix
+    in the receiver's view (the generator always emits it)."""
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
+    F = flags(nbits=nbits, channel=chan, cp=cp)
+    o = ofdm.ofdm_tx(F)
+    snr = np.linspace(0.0, 20.0, n).astype(np.float32)
+    ga, gb = DeviceDataGen(F, o, seed=11), DeviceDataGen(F, o, seed=11)
+    ga.offset = gb.offset = 3
+    assert FusedStaticGen.supported(gb)
+    tx_a, bits_a = ga.transmit(n)
+    x_a, npow_a, _ = ga.channel(tx_a, snr)
+    fg = FusedStaticGen(gb, n, snr, want_noise_power=True)
+    x_b = torch.empty_like(x_a)
+    bits_b = torch.empty_like(bits_a)
+    tx_b = torch.empty_like(tx_a)
+    _, _, npow_b = fg.make_batch(x_b, bits_b, slot=0, tx_out=tx_b)
+    torch.cuda.synchronize()
+    assert gb.offset == 4
+    assert torch.equal(bits_a, bits_b)
+    sc = float(tx_a.abs().max())
+    assert float((tx_a - tx_b).abs().max()) <= 2e-6 * sc
+    assert float((x_a - x_b).abs().max()) <= 1e-5 * float(x_a.abs().max())
+    assert abs(float(npow_a) - float(npow_b)) <= 1e-6 * float(npow_a)
+    want_npow = float((fg.noise.double() ** 2).sum() / (n * gb.T))
+    assert abs(float(npow_b) - want_npow) <= 1e-6 * want_npow
+    # x = y / sqrt(mean |y|^2) + noise, in float32 with the float64 batch power
+    inv = np.float32(1.0) / np.sqrt(np.float32(float((fg.y.double() ** 2).sum()) / (n * gb.T)))
+    want_x = fg.y.cpu().numpy() * inv + fg.noise.cpu().numpy()
+    assert np.abs(x_b.cpu().numpy() - want_x).max() <= 2e-7 * np.abs(want_x).max()
+
+
+@pytest.mark.parametrize("frames,nbits", [(1170, 2), (73, 4)])
+def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frames, nbits):
+    """RxEngine.train_step_generated (ONE C call per batch: generator launch + the four step launches, R0 reading (y, noise,
+    power partials) as its virtual input) against the same generator materialising x for train_step_pipelined: the same
+    batches in the same order => the same bits in every parameter, Adam slot and metric after six steps -- and the
+    materialised copy the virtual path can leave behind (keep_x) is the batch the other path trained on."""
+    from dl_ofdm_amd import ofdm, receiver as R
+    from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
+    from dl_ofdm_amd.engine import RxEngine
+    F = flags(nbits=nbits, channel="EPA")
+    o = ofdm.ofdm_tx(F)
+    dims = R.rx_dims(F, o)
+    engs, gens, fgs = [], [], []
+    for _ in range(2):
+        engs.append(RxEngine(dims, frames, train=True, seed=5, want_prob=False, want_z=False))
+        gens.append(DeviceDataGen(F, o, seed=21))
+        fgs.append(FusedStaticGen(gens[-1], frames, 7.0, want_noise_power=True))
+    ea, eb = engs
+    n = 6
+    xs = []
+    for i in range(n):
+        ea.train_step_generated(fgs[0], slot=i & 1, last=(i + 1 == n), keep_x=True)
+        xs.append(ea.x.clone())                       # (the batch step i normalised ahead: batch i + 1)
+    # the reference loop: batch 0, then every step materialises the next batch and normalises it behind its Adam update
+    fgs[1].make_batch(eb.x, eb.label_slot(0), 0)
+    eb.prime()
+    for i in range(n):
+        last = i + 1 == n
+        if not last:
+            fgs[1].make_batch(eb.x, eb.label_slot((i + 1) & 1), (i + 1) & 1)
+            assert torch.equal(eb.x, xs[i]), i
+        eb.train_step_pipelined(slot=i & 1, last=last)
+    torch.cuda.synchronize()
+    assert gens[0].offset == gens[1].offset == n
+    for name in ("params", "adam_m", "adam_v", "adam_state"):
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+    ma, mb = ea.metrics(), eb.metrics()
+    assert ma["conf"] == mb["conf"] and ma["ce_mean"] == mb["ce_mean"] and ma["tx_power"] == mb["tx_power"]
+    assert torch.equal(fgs[0].npow, fgs[1].npow)

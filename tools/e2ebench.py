@@ -52,7 +52,30 @@ def main():
             eng.train_step_pipelined(slot=i & 1, x_ready=feed.ready)
             feed.step_issued()
 
-    for mode, fn in (("device-generated, one stream", run), ("device-generated, generator on a side stream", run_overlapped)):
+    from dl_ofdm_amd.datagen import FusedStaticGen
+    modes = [("device-generated, one stream", run), ("device-generated, generator on a side stream", run_overlapped)]
+    if FusedStaticGen.supported(gen) and not eng._ride:
+        fg = FusedStaticGen(gen, a.frames, F.SNR)
+        cnt = [0]
+
+        def run_fused(n, first):
+            if first:
+                cnt[0] = 0
+            for _ in range(n):
+                eng.train_step_generated(fg, slot=cnt[0] & 1)
+                cnt[0] += 1
+        modes.append(("device-generated, fused generator launch + virtual input of R0, one C call per batch", run_fused))
+        side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+
+        def run_fused_side(n, first):
+            if first:
+                cnt[0] = 0
+                eng._gen_side_primed = False
+            for _ in range(n):
+                eng.train_step_generated(fg, slot=cnt[0] & 1, side=side)
+                cnt[0] += 1
+        modes.append(("device-generated, fused generator launch on a side stream + virtual input of R0", run_fused_side))
+    for mode, fn in modes:
         eng.drop_prefetch()
         gen.offset = 0
         fn(20, True)
