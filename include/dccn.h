@@ -256,6 +256,8 @@ int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_strea
  * updates of dense_3 / dense_4 and the smoothing kernel's gradient fold ride behind the pilot bottleneck's backward launch (default 1),
  * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream next to the C-Conv weight-gradient launch
  * (0 off, 1 on, 2 = default: with non-temporal loads and stores).
+ * Key 2: 7 (default) = the staged whole-k C-Conv forward, 8-11 its other store slots / 32x128
+ * tiles; key 14: presets 1-24, default 14 = ranges of {9,5,2,2,1}/19 of the batch.
  * Set them before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
