@@ -1298,6 +1298,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     if (train && b->gen_next != nullptr) {
         if (b->gen_next->frames != sh->batch || b->gen_next->S != sh->S || 2 * (b->gen_next->K + b->gen_next->CP) * sh->S != L.cols)
             return DCCN_ERR_INVALID_ARG;
+        // (the double-buffered pipelining -- R0 on the backward launch, knob 18 -- has no virtual-input form: refuse rather than
+        // normalise a stale x_next)
+        if (b->x_norm_next != nullptr) return DCCN_ERR_INVALID_ARG;
         if (b->x_next_ready == nullptr) {
             trace.launch(7);
             DCCN_TRY(gen_static_launch(b->gen_next, s));
@@ -2277,7 +2280,8 @@ int dccn_gen_static_apply(const dccn_gen_static* g, float* x_out, float* noise_p
     hipLaunchKernelGGL(gen_static_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(g->y), reinterpret_cast<const float4*>(g->noise),
                        (const double*)g->power_partial, np, (double)g->frames * (double)T, reinterpret_cast<float4*>(x_out), n4,
-                       (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np, noise_power);
+                       (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np,
+                       (noise_power && g->noise_partial) ? noise_power : nullptr);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
