@@ -127,6 +127,11 @@ SIGNATURES = {
     "dccn_cconv_patch_supported": (_i, [_i] * 9),
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
+    "dccn_cconv_patch_bwd_supported": (_i, [_i] * 11),
+    "dccn_cconv_patch_bwd_w_workspace_size": (C.c_size_t, [_i] * 7),
+    "dccn_cconv_patch_bwd_w": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp, C.c_size_t, _vp]),
+    "dccn_cconv_patch_bwd_x_workspace_size": (C.c_size_t, [_i] * 4),
+    "dccn_cconv_patch_bwd_x": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp, C.c_size_t, _vp]),
     "dccn_metrics_table_add": (_i, [_vp, _vp, _vp]),
     "dccn_metrics_table_set": (_i, [_vp, _vp, _vp]),
     "dccn_ingraph_awgn_workspace_size": (_sz, [_i, _i]),

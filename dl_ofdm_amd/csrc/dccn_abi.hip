@@ -2595,6 +2595,107 @@ int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, floa
     p.pg.sL = sL; p.pg.sW = sW; p.pg.l0 = tl0 - pl0; p.pg.w0 = tw0 - pw0;
     return launch_gemm<OP_KPATCH, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, (hipStream_t)stream);
 }
+// ---- the backward of the same convolutions without the patch tensor ---------------------------------------------
+// weight gradient: dWeff[(ti,tj,c,iq), n] = sum over output positions of patch(x)^T . dout -- the k-major weight-gradient
+// GEMM (gemm_kmajor.h) with its A rows gathered from x itself (APATCH); split-K slabs folded like every C-Conv's
+int dccn_cconv_patch_bwd_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int sL, int sW, int F) {
+    if (!dccn_cconv_patch_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, F)) return 0;
+    if (sL <= 0 || sW <= 0) return 0;
+    if ((long long)B * Lo * Wo * F * 2 >= (1LL << 31)) return 0;          // 32-bit element offsets into dout
+    int mode = 1;                                                          // bit 0: weight gradient
+    if (sL == 1 && sW == 1) {
+        mode |= 2;                                                         // bit 1: input gradient qualifies
+        // bit 2: ... and is expected to beat GEMM + col2im: its GEMM multiplies ceil(2C/64) column tiles by ntl*ntw*2F deep
+        // rows where the other route multiplies ceil(2kin/64) tiles by 2F -- few channels (2C << 64) leave most of every tile
+        // empty ntl*ntw times over, which costs more than the [rows, kin, 2] round trip saves
+        const long long imp = (long long)ceil_div(2 * C, 64) * ntl * ntw, col = (long long)ceil_div(2 * ntl * ntw * C, 64);
+        if (imp <= 2 * col) mode |= 4;
+    }
+    return mode;
+}
+size_t dccn_cconv_patch_bwd_w_workspace_size(int B, int Lo, int Wo, int C, int ntl, int ntw, int F) {
+    if (B <= 0 || Lo <= 0 || Wo <= 0 || C <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
+    return cconv_bw_ws_bytes(B * Lo * Wo, ntl * ntw * C, F);
+}
+int dccn_cconv_patch_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int B, int L, int Wd, int C, int Lo,
+                           int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
+                           void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
+    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
+    if (!x || !dout || !dw || !im2col_geom_ok(g) || !aligned16(x) || !aligned16(dout) ||
+        !(dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F) & 1))
+        return DCCN_ERR_INVALID_ARG;
+    const int rows = B * Lo * Wo, kin = ntl * ntw * C;
+    if (!workspace || workspace_bytes < cconv_bw_ws_bytes(rows, kin, F)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
+    Carver c(workspace, workspace_bytes);
+    float* slabs = c.take<float>((size_t)sp.splits * 4 * kin * F);
+    float* cs = c.take<float>((size_t)sp.splits * 2 * F);
+    GemmParams p = gp_zero();                 // dWeff[2kin,2F] = patches(x)[rows,2kin]^T . dout[rows,2F]
+    p.A = x; p.B = dout; p.C = slabs; p.colsum = cs;
+    p.M = 2 * kin; p.N = 2 * F; p.K = rows;
+    p.lda = 0; p.ldb = 2 * F; p.ldc = 2 * F;
+    p.klen = sp.klen;
+    p.slab = (long long)4 * kin * F;
+    p.vecA = 1; p.vecB = 1;
+    p.pg.L = L; p.pg.Wd = Wd; p.pg.c2 = 2 * C; p.pg.Lo = Lo; p.pg.Wo = Wo; p.pg.ntl = ntl; p.pg.ntw = ntw;
+    p.pg.sL = sL; p.pg.sW = sW; p.pg.l0 = tl0 - pl0; p.pg.w0 = tw0 - pw0;
+    patch_div_magic(Lo * Wo, p.pg.per_mul, p.pg.per_shift);
+    patch_div_magic(Wo, p.pg.wo_mul, p.pg.wo_shift);
+    if (!kmajor_ok(p)) return DCCN_ERR_INVALID_ARG;
+    DCCN_TRY((launch_kmajor<1, TAG_CCONV_BWD_W, true>(p, sp.splits, s)));
+    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
+    hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, slabs, sp.splits, p.slab, cs, dw, dbias, kin, F);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+// input gradient at stride 1: dx[b,l,w,(c,iq)] = sum over taps of dout[b, l-l0-ti, w-w0-tj, :] . Weff[(ti,tj,c,iq), :] -- a
+// convolution of dout with the tap-flipped transposed weights, i.e. the SAME implicit GEMM with dout as the gathered operand
+// (geometry: rows = input positions, taps t' = nt-1-t, origin -(l0+ntl-1)) and Bt[(c,iq)][(ti',tj',n)] as a plain k-contiguous
+// operand built from w by the little kernel below (4 kin F floats).  No [rows, kin, 2] gradient-of-patches tensor, no col2im.
+__global__ __launch_bounds__(256) void cconv_flip_wt_kernel(const float* __restrict__ w, float* __restrict__ bt, int C, int ntl,
+                                                            int ntw, int F) {
+    const long long K = (long long)ntl * ntw * 2 * F, total = 2LL * C * K;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i / K);
+    const int k = (int)(i - (long long)j * K);
+    const int tp = k / (2 * F), nn = k - tp * 2 * F;
+    const int tip = tp / ntw, tjp = tp - tip * ntw;
+    const int n = (((ntl - 1 - tip) * ntw) + (ntw - 1 - tjp)) * C + (j >> 1);
+    const int iq = j & 1, f = nn >> 1, oq = nn & 1;
+    const float wa = w[(size_t)n * 2 * F + f], wb = w[(size_t)n * 2 * F + F + f];
+    // Weff[2n, 2f] = Wa, [2n, 2f+1] = Wb, [2n+1, 2f] = -Wb, [2n+1, 2f+1] = -Wa (gemm_f32_mfma.h OP_CCONV_W)
+    bt[i] = iq == 0 ? (oq == 0 ? wa : wb) : (oq == 0 ? -wb : -wa);
+}
+size_t dccn_cconv_patch_bwd_x_workspace_size(int C, int ntl, int ntw, int F) {
+    if (C <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
+    return align_up((size_t)4 * C * ntl * ntw * F * sizeof(float), 256);
+}
+int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl,
+                           int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F, void* workspace,
+                           size_t workspace_bytes, dccn_stream_t stream) {
+    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
+    if (!dout || !w || !dx || !im2col_geom_ok(g) || !aligned16(dout) || !aligned16(dx) ||
+        !(dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F) & 2))
+        return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_cconv_patch_bwd_x_workspace_size(C, ntl, ntw, F) || !aligned16(workspace))
+        return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* bt = reinterpret_cast<float*>(workspace);
+    const long long total = 4LL * C * ntl * ntw * F;
+    hipLaunchKernelGGL(cconv_flip_wt_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, w, bt, C, ntl, ntw, F);
+    DCCN_LAUNCH_CHECK();
+    GemmParams p = gp_zero();                 // dx[B*L*Wd, 2C] = patches'(dout)[., ntl*ntw*2F] . Bt^T
+    p.A = dout; p.B = bt; p.C = dx;
+    p.M = B * L * Wd; p.N = 2 * C; p.K = ntl * ntw * 2 * F;
+    p.lda = 0; p.ldb = p.K; p.ldc = 2 * C;
+    p.klen = round_k(p.K);
+    p.vecA = 1; p.vecB = 1;
+    p.pg.L = Lo; p.pg.Wd = Wo; p.pg.c2 = 2 * F; p.pg.Lo = L; p.pg.Wo = Wd; p.pg.ntl = ntl; p.pg.ntw = ntw;
+    p.pg.sL = 1; p.pg.sW = 1; p.pg.l0 = -(tl0 - pl0) - (ntl - 1); p.pg.w0 = -(tw0 - pw0) - (ntw - 1);
+    return launch_gemm<OP_KPATCH, OP_KCONTIG, 0, TAG_CCONV_BWD_X>(p, 1, s);
+}
 int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
                       int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
     const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};

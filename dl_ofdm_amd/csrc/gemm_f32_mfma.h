@@ -45,7 +45,17 @@ enum GemmTag : int { TAG_DENSE_FWD = 0, TAG_DENSE_BWD_X = 1, TAG_DENSE_BWD_W = 2
 // (l0 = first live tap - padding before, may be negative); c2 = 2C floats per cell
 struct PatchGeom {
     int L, Wd, c2, Lo, Wo, ntl, ntw, sL, sW, l0, w0;
+    unsigned per_mul, wo_mul;        // row -> (b, lo, wo) without integer division (gemm_kmajor.h patch_div): / (Lo*Wo), / Wo
+    int per_shift, wo_shift;
 };
+// floor(n / d) = (n * mul) >> shift for every 0 <= n < 2^31:  s = ceil(log2 d), mul = ceil(2^(31+s) / d) <= 2^32 - 1
+// (mul d = 2^(31+s) + e with e < d <= 2^s, so the error term n e / (d 2^(31+s)) stays below 1/d)
+static inline void patch_div_magic(int d, unsigned& mul, int& shift) {
+    int s = 0;
+    while ((1LL << s) < (long long)d) ++s;
+    shift = 31 + s;
+    mul = (unsigned)(((1ULL << shift) + (unsigned long long)d - 1) / (unsigned long long)d);
+}
 
 struct GemmParams {
     const float* A;

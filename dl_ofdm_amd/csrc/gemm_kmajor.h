@@ -27,8 +27,18 @@ typedef float kf32x4 __attribute__((ext_vector_type(4)));
 template <int BK = 64>
 constexpr size_t kmajor_smem_bytes() { return (size_t)(2 * 2 * BK * 64) * sizeof(float); }
 
+// floor(n / d) for n < 2^31 by the multiplier / shift pair of patch_div_magic (gemm_f32_mfma.h): mul_hi + mul_lo + shift
+__device__ __forceinline__ int patch_div(int n, unsigned mul, int shift) {
+    return (int)(((unsigned long long)(unsigned)n * mul) >> shift);
+}
+
 // COLSUM: also the column sums of the B rows of this k range (bias gradient), written by the m0 == 0 tiles
-template <int COLSUM, int BK = 64>
+// APATCH: operand A is the im2col patch matrix of p.pg, gathered from x = p.A (dev/py/complex.py:51-92, 140-196; the
+//         weight gradient of a general-k C-Conv with no patch tensor): row k = output position (b, lo, wo), column
+//         m = (ti, tj, c, iq).  Every piece of a thread lies in the same float4 column (tid % 16), so the tap
+//         decomposition is a thread constant; a piece decomposes its ROW per k-tile (two multiply-shift divisions),
+//         tests the padding and forms one address -- A always takes the masked form, B (dout) keeps its fast path.
+template <int COLSUM, int BK = 64, bool APATCH = false>
 __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, const int T, const int z,
                                              const long long goA = 0, const long long goB = 0, const long long goC = 0,
                                              const long long goS = 0) {
@@ -70,6 +80,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
     unsigned offA[NV], offB[NV];
     float4 ra[NV], rb[NV];
     unsigned okm = 0u;                                  // masked path: bit v = row of piece v lies inside the k range
+    unsigned okb = 0u;                                  // APATCH: okm also carries A's padding test, B rows keep their own
     const unsigned sw = ((unsigned)(tid >> 4) & 1u) << 5;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -77,10 +88,28 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
         offA[v] = (unsigned)((row * p.lda + min(m0 + 4 * c4, p.M - 4)) * 4);
         offB[v] = (unsigned)((row * p.ldb + min(n0 + 4 * c4, p.N - 4)) * 4);
     }
+    int p_tl = 0, p_tw = 0, p_cc = 0;                   // APATCH: l / w offset of this thread's tap, float offset in the cell
+    if constexpr (APATCH) {
+        const int mc = min(m0 + 4 * (tid & 15), p.M - 4);
+        const int seg = p.pg.ntw * p.pg.c2;
+        const int ti = mc / seg, r2 = mc - ti * seg, tj = r2 / p.pg.c2;
+        p_cc = r2 - tj * p.pg.c2;
+        p_tl = p.pg.l0 + ti;
+        p_tw = p.pg.w0 + tj;
+    }
     auto load = [&](auto masked_tag, int q, int k0) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int v = q % NV;
-        if constexpr (!MASKED) {
+        if (APATCH && q < NV) {
+            const int k = k0 + (tid >> 4) + 16 * v, kc = min(k, p.K - 1);
+            const int b = patch_div(kc, p.pg.per_mul, p.pg.per_shift), rem = kc - b * (p.pg.Lo * p.pg.Wo);
+            const int lo = patch_div(rem, p.pg.wo_mul, p.pg.wo_shift), wo = rem - lo * p.pg.Wo;
+            const int l = lo * p.pg.sL + p_tl, wd = wo * p.pg.sW + p_tw;
+            const bool ok = k < kend && (unsigned)l < (unsigned)p.pg.L && (unsigned)wd < (unsigned)p.pg.Wd;
+            const unsigned off = ok ? (unsigned)(((b * p.pg.L + l) * p.pg.Wd + wd) * p.pg.c2 + p_cc) : 0u;
+            ra[v] = *reinterpret_cast<const float4*>(pA + off);
+            okm = (okm & ~(1u << v)) | ((ok ? 1u : 0u) << v);
+        } else if constexpr (!MASKED) {
             const char* base = reinterpret_cast<const char*>(q < NV ? pA + (size_t)k0 * p.lda : pB + (size_t)k0 * p.ldb);
             if (q < NV) ra[v] = *reinterpret_cast<const float4*>(base + offA[v]);
             else rb[v] = *reinterpret_cast<const float4*>(base + offB[v]);
@@ -92,6 +121,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
                 okm = (okm & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
             } else {
                 rb[v] = *reinterpret_cast<const float4*>(pB + (size_t)kc * p.ldb + min(n0 + 4 * c4, p.N - 4));
+                if constexpr (APATCH) okb = (okb & ~(1u << v)) | ((k < kend ? 1u : 0u) << v);
             }
         }
     };
@@ -99,8 +129,8 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int v = q % NV;
         float4 val = q < NV ? ra[v] : rb[v];
-        if constexpr (MASKED) {
-            const bool ok = (okm >> v) & 1u;
+        if (MASKED || (APATCH && q < NV)) {
+            const bool ok = (((APATCH && q >= NV) ? okb : okm) >> v) & 1u;
             val = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
         }
         *reinterpret_cast<float4*>((q < NV ? An : Bn) + ((unsigned)(4 * (tid + 256 * v)) ^ sw)) = val;
@@ -224,14 +254,14 @@ static inline bool kmajor_ok(const GemmParams& p) {
 }
 
 // stand-alone launch: grid (tiles, 1, splits)
-template <int COLSUM, int TAG>
+template <int COLSUM, int TAG, bool APATCH = false>
 __global__ __launch_bounds__(kGemmThreads) void gemm_kmajor_kernel(const GemmParams p) {
-    kmajor_block<COLSUM>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+    kmajor_block<COLSUM, 64, APATCH>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
 }
 
-template <int COLSUM, int TAG>
+template <int COLSUM, int TAG, bool APATCH = false>
 static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
-    auto kern = gemm_kmajor_kernel<COLSUM, TAG>;
+    auto kern = gemm_kmajor_kernel<COLSUM, TAG, APATCH>;
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), kmajor_smem_bytes<64>()));
     dim3 grid(ceil_div(p.N, 64) * ceil_div(p.M, 64), 1, splits);
     hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), kmajor_smem_bytes<64>(), s, p);

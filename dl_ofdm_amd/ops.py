@@ -191,10 +191,17 @@ def cconv_im2col(x: torch.Tensor, Lo: int, Wo: int, taps_l, taps_w, strides, pad
     return _Im2col.apply(x.contiguous(), geom)
 
 
+_PATCH_BWD_IM2COL = False        # tools/convbench.py, tests: force the backward onto the im2col / col2im operators
+_PATCH_BWD_DX_ALWAYS = False     # ... or the input gradient onto the implicit GEMM wherever it qualifies (bit 1), not only
+                                 # where dccn_cconv_patch_bwd_supported expects it to be the faster route (bit 2)
+
+
 class _CConvPatch(torch.autograd.Function):
     """dccn_cconv_patch_fwd: the general-k complex convolution as an implicit GEMM (the operand loader gathers the taps;
-    no patch tensor in the forward).  The backward materialises the patches once (dccn_cconv_im2col) for the weight
-    gradient and scatters the input gradient back with dccn_cconv_col2im -- the same operators the im2col route uses."""
+    no patch tensor in the forward).  The backward is implicit too where dccn_cconv_patch_bwd_supported says so: the weight
+    gradient's GEMM gathers its patch rows from x (dccn_cconv_patch_bwd_w), the input gradient at stride 1 is the same
+    implicit GEMM over dout with the taps flipped (dccn_cconv_patch_bwd_x).  Otherwise (strided input gradient): patches
+    materialised once by dccn_cconv_im2col, input gradient scattered back by dccn_cconv_col2im."""
 
     @staticmethod
     def forward(ctx, x, w, bias, geom):
@@ -218,13 +225,28 @@ class _CConvPatch(torch.autograd.Function):
         dout = dout.contiguous()
         rows, kin, F = B * Lo * Wo, ntl * ntw * C, w.shape[1] // 2
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        mode = 0 if _PATCH_BWD_IM2COL else lib.dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F)
+        if ctx.needs_input_grad[0] and (mode & (2 if _PATCH_BWD_DX_ALWAYS else 4)):    # implicit GEMM over dout, taps flipped
+            dx = torch.empty_like(x)
+            nws = lib.dccn_cconv_patch_bwd_x_workspace_size(C, ntl, ntw, F)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_cconv_patch_bwd_x(_p(dout), _p(w), _p(dx), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0,
+                                             F, _p(ws), nws, _stream()), "dccn_cconv_patch_bwd_x")
+        elif ctx.needs_input_grad[0]:
             drows = torch.empty(rows, kin, 2, dtype=torch.float32, device=x.device)
             check(lib.dccn_cconv_gemm_bwd_x(_p(dout), _p(w), _p(drows), rows, kin, F, _stream()), "dccn_cconv_gemm_bwd_x")
             dx = torch.empty_like(x)
             check(lib.dccn_cconv_col2im(_p(drows), _p(dx), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0, _stream()),
                   "dccn_cconv_col2im")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if need_w and (mode & 1):                           # the weight-gradient GEMM gathers its patch rows from x
+            dw = torch.empty_like(w)
+            db = torch.empty(2 * F, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_cconv_patch_bwd_w_workspace_size(B, Lo, Wo, C, ntl, ntw, F)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_cconv_patch_bwd_w(_p(x), _p(dout), _p(dw), _p(db), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW,
+                                             pl0, pw0, F, _p(ws), nws, _stream()), "dccn_cconv_patch_bwd_w")
+        elif need_w:
             patches = torch.empty(rows, kin, 2, dtype=torch.float32, device=x.device)
             check(lib.dccn_cconv_im2col(_p(x), _p(patches), B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0, _stream()),
                   "dccn_cconv_im2col")

@@ -185,6 +185,23 @@ int dccn_cconv_patch_supported(int B, int L, int Wd, int C, int Lo, int Wo, int 
 int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, float* out, int B, int L, int Wd, int C, int Lo,
                          int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
                          dccn_stream_t stream);
+/* The backward of the same convolutions without patch-sized tensors either (the gradients TensorFlow derives for
+ * dev/py/complex.py:51-92, :140-196).  _bwd_supported: bit 0 = the weight gradient qualifies, bit 1 = the input gradient does
+ * (stride 1 only), bit 2 = ... and is expected to be the faster route (enough channels to fill the GEMM's column tiles);
+ * 0 -> dccn_cconv_im2col / _gemm_bwd_w / _gemm_bwd_x / _col2im as before.
+ * _bwd_w: dw [ntl*ntw*C, 2F] (+ dbias [2F], nullable) = patches(x)^T . dout, the patch rows gathered from x [B, L, Wd, C, 2]
+ *   by the weight-gradient GEMM's operand loader; dout [B*Lo*Wo, F, 2].  Deterministic (split-K slabs, fixed-order fold).
+ * _bwd_x: dx [B, L, Wd, C, 2] = the convolution of dout with the tap-flipped transposed weights, as the same implicit GEMM
+ *   gathering from dout (no [rows, kin, 2] intermediate, no scatter).  workspace: the flipped weights, 4*C*ntl*ntw*F floats. */
+int dccn_cconv_patch_bwd_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int sL, int sW, int F);
+size_t dccn_cconv_patch_bwd_w_workspace_size(int B, int Lo, int Wo, int C, int ntl, int ntw, int F);
+int dccn_cconv_patch_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int B, int L, int Wd, int C, int Lo,
+                           int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
+                           void* workspace, size_t workspace_bytes, dccn_stream_t stream);
+size_t dccn_cconv_patch_bwd_x_workspace_size(int C, int ntl, int ntw, int F);
+int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl,
+                           int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F, void* workspace,
+                           size_t workspace_bytes, dccn_stream_t stream);
 
 /* The in-graph AWGN monitor branch of the receiver graph (dev/py/radio.py:62-88 AWGN_channel, called at
  * dev/py/ofdmreceiver_np.py:136; tensors `tx_signal:0`, `iq_tx:0`, `iq_rx:0`, `noise_power:0`, :151-152,172-183):

@@ -53,6 +53,40 @@ def conv2d_complex_literal(inputs: torch.Tensor, kernel: torch.Tensor, bias: tor
     return torch.stack([re, im], dim=-1)                      # [B,L',W',F,2]  (:191-192)
 
 
+def layers_conv2d_complex_literal_t(inputs: torch.Tensor, kernel: torch.Tensor, bias, strides=(1, 1),
+                                    padding: str = "valid") -> torch.Tensor:
+    """torch twin of ``dccn_oracle.layers_conv2d_complex_literal`` (complex.py:140-196; any strides, SAME / VALID): the same
+    tap-by-tap evaluation on torch tensors, so that autograd yields the gradients TensorFlow derives for the layer --
+    the reference for the backward of the general-k convolutions.  inputs [B,L,Wd,C,2], kernel [kL,kW,1,C,2F]."""
+    B, L, Wd, C, _ = inputs.shape
+    kL, kW, _, _, F2 = kernel.shape
+    F = F2 // 2
+    sL, sW = strides
+    Lo, pl0, pl1 = O._tf_pad(L, kL, sL, padding)
+    Wo, pw0, pw1 = O._tf_pad(Wd, kW, sW, padding)
+    x = inputs.permute(0, 1, 2, 4, 3)                                           # [B,L,Wd,2,C]  (:168)
+    x = Fnn.pad(x, (0, 0, 0, 0, pw0, pw1, pl0, pl1))
+    conv = torch.zeros(B, Lo, Wo, 2, F2, dtype=inputs.dtype)
+    for a in range(kL):
+        for b in range(kW):
+            patch = x[:, a:a + (Lo - 1) * sL + 1:sL, b:b + (Wo - 1) * sW + 1:sW]
+            if patch.shape[1] != Lo or patch.shape[2] != Wo:
+                continue
+            conv = conv + patch @ kernel[a, b, 0]
+    if bias is not None:
+        conv = conv + bias
+    conv = conv.reshape(B, Lo, Wo, 4, F)                                        # (:185)
+    return torch.stack([conv[:, :, :, 0] - conv[:, :, :, 3], conv[:, :, :, 1] - conv[:, :, :, 2]], dim=-1)   # (:187-192)
+
+
+def layers_conv1d_complex_literal_t(inputs: torch.Tensor, kernel: torch.Tensor, bias, strides: int = 1,
+                                    padding: str = "valid") -> torch.Tensor:
+    """``layers_conv1d_complex`` (complex.py:51-92) on torch tensors: [B,L,C,2], kernel [k,1,C,2F] -> [B,L',F,2]
+    (the 2-D layer over a width-1 second axis: identical arithmetic, :78-85)."""
+    y = layers_conv2d_complex_literal_t(inputs[:, :, None], kernel[:, :, None], bias, (strides, 1), padding)
+    return y[:, :, 0]
+
+
 def full_kernel_from_live(w_live: np.ndarray, kin: int, seed: int = 0) -> np.ndarray:
     """Embed the live tap [kin,2F] at (K-1)//2 of a TF-shaped [1,K,1,K,2F] kernel whose
     other (dead) taps hold arbitrary values -- they must not influence anything."""

@@ -143,22 +143,26 @@ def test_conv1d_layers_vs_literal():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,F,k,stride,padding", [
     ((4, 37, 6, 2), 8, 5, 1, "same"),          # k = 5: two taps of padding at either end
-    ((3, 64, 4, 2), 6, 5, 2, "same"),          # strided
+    ((3, 64, 4, 2), 6, 5, 2, "same"),          # strided (input gradient: col2im route)
     ((2, 33, 8, 2), 4, 7, 1, "valid"),
     ((5, 9, 2, 2), 2, 3, 3, "same"),           # stride = kernel size
     ((2, 130, 64, 2), 64, 5, 1, "same"),       # several 64-deep k-tiles (K = 640), more than one row tile
+    ((16, 512, 8, 2), 16, 5, 1, "same"),       # 8192 output positions: many split-K slabs in the weight gradient
+    ((3, 20, 3, 2), 5, 3, 1, "same"),          # odd C and F: the im2col operators throughout
 ])
 def test_conv1d_implicit_gemm_vs_literal_and_im2col(shape, F, k, stride, padding):
-    """general-k layers_conv1d_complex (complex.py:51-92) as an implicit GEMM (dccn_cconv_patch_fwd): against the literal
-    fp64 restatement, and against the im2col + GEMM route it replaces (forward to 1e-5; the backward runs the same
-    operators on the same cotangent, so the gradients agree to the last bit)."""
-    from dl_ofdm_amd import complex as CX
+    """general-k layers_conv1d_complex (complex.py:51-92) as implicit GEMMs -- forward (dccn_cconv_patch_fwd), weight gradient
+    (dccn_cconv_patch_bwd_w) and, at stride 1, input gradient (dccn_cconv_patch_bwd_x): output against the literal fp64
+    restatement, gradients against the autograd of its torch twin, and the im2col + GEMM + col2im route beside them."""
+    from dl_ofdm_amd import complex as CX, ops
+    from oracle.torch_ref import layers_conv1d_complex_literal_t
     rng = np.random.RandomState(2)
     x = rng.randn(*shape).astype(np.float32)
     C = shape[2]
     res = {}
     for implicit in (True, False):
         CX.IMPLICIT_GEMM = implicit
+        ops._PATCH_BWD_DX_ALWAYS = implicit          # the implicit input gradient wherever it qualifies, not only where it pays
         try:
             st = CX.VariableStore(seed=9)
             xt = torch.as_tensor(x).cuda().requires_grad_()
@@ -176,32 +180,71 @@ def test_conv1d_implicit_gemm_vs_literal_and_im2col(shape, F, k, stride, padding
                 bias = st.tensor("conv2d/bias").detach().cpu().numpy().astype(np.float64)
                 ref = O.layers_conv1d_complex_literal(x.astype(np.float64), kern, bias, stride, padding)
                 assert relerr(res[True][0], ref) <= 1e-5
+                x64 = torch.tensor(x.astype(np.float64), requires_grad=True)
+                k64, b64 = torch.tensor(kern, requires_grad=True), torch.tensor(bias, requires_grad=True)
+                layers_conv1d_complex_literal_t(x64, k64, b64, stride, padding).backward(g.cpu().double())
+                grads = (x64.grad.numpy(), k64.grad.numpy().reshape(res[True][2].shape), b64.grad.numpy())
         finally:
             CX.IMPLICIT_GEMM = True
+            ops._PATCH_BWD_DX_ALWAYS = False
     assert relerr(res[True][0], res[False][0]) <= 1e-5
-    for a, b in zip(res[True][1:], res[False][1:]):
-        assert np.array_equal(a, b)
+    for route in (True, False):
+        for got, want in zip(res[route][1:], grads):
+            assert relerr(got, want) <= 1e-5, route
 
 
 @pytest.mark.gpu
 def test_conv2d_implicit_gemm_two_tap_axes():
-    """taps over both axes, strides (2, 1), VALID and SAME: the loader's (ti, tj) arithmetic"""
+    """taps over both axes, strides (2, 1) / (1, 2) / (1, 1), VALID and SAME: the loaders' (ti, tj) arithmetic in the forward,
+    in the weight gradient and (stride 1) in the input gradient's flipped-tap gather; dead taps get no gradient"""
     from dl_ofdm_amd import complex as CX, ops
+    from oracle.torch_ref import layers_conv2d_complex_literal_t
     rng = np.random.RandomState(6)
     for shape, F, kern, strides, padding in (((2, 9, 10, 4, 2), 6, (3, 2), (2, 1), "valid"),
-                                             ((3, 8, 12, 2, 2), 4, (3, 5), (1, 2), "same")):
+                                             ((3, 8, 12, 2, 2), 4, (3, 5), (1, 2), "same"),
+                                             ((2, 9, 10, 4, 2), 6, (3, 2), (1, 1), "same"),
+                                             ((2, 7, 64, 2, 2), 2, (7, 64), (1, 1), "same"),      # the equaliser's 2-D smoothing shape
+                                             ((4, 21, 17, 6, 2), 10, (5, 3), (1, 1), "valid")):
         x = rng.randn(*shape).astype(np.float32)
         st = CX.VariableStore(seed=3)
-        xt = torch.as_tensor(x).cuda()
+        xt = torch.as_tensor(x).cuda().requires_grad_()
         assert ops.cconv_patch_supported(xt, 1, 1, kern[0], kern[1], F)
         CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
         st.set("conv3d/bias", rng.randn(2 * F))
         st.begin()
         y = CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
         full = _full_kernel(st, "conv3d", rng)
-        ref = O.layers_conv2d_complex_literal(x.astype(np.float64), full,
-                                              st.tensor("conv3d/bias").detach().cpu().numpy().astype(np.float64), strides, padding)
+        bias = st.tensor("conv3d/bias").detach().cpu().numpy().astype(np.float64)
+        ref = O.layers_conv2d_complex_literal(x.astype(np.float64), full, bias, strides, padding)
         assert relerr(y.detach().cpu().numpy(), ref) <= 1e-5
+        g = torch.as_tensor(rng.randn(*y.shape).astype(np.float32)).cuda()
+        ops._PATCH_BWD_DX_ALWAYS = True
+        try:
+            y.backward(g)
+        finally:
+            ops._PATCH_BWD_DX_ALWAYS = False
+        x64 = torch.tensor(x.astype(np.float64), requires_grad=True)
+        k64, b64 = torch.tensor(full, requires_grad=True), torch.tensor(bias, requires_grad=True)
+        layers_conv2d_complex_literal_t(x64, k64, b64, strides, padding).backward(g.cpu().double())
+        tl, tw = st.meta["conv3d/kernel"]["live_taps"]
+        kg = k64.grad.numpy()
+        live = np.stack([np.stack([kg[a, b, 0] for b in tw]) for a in tl])
+        dead = np.abs(kg).sum() - np.abs(live).sum()
+        assert dead <= 1e-9 * np.abs(live).sum()                                   # dead taps never meet data
+        assert relerr(xt.grad.cpu().numpy(), x64.grad.numpy()) <= 1e-5, (shape, kern, strides)
+        assert relerr(st.tensor("conv3d/kernel").grad.cpu().numpy().reshape(live.shape), live) <= 1e-5, (shape, kern, strides)
+        assert relerr(st.tensor("conv3d/bias").grad.cpu().numpy(), b64.grad.numpy()) <= 1e-5
+
+
+def test_patch_backward_route_bits():
+    """dccn_cconv_patch_bwd_supported: bit 0 weight gradient, bit 1 input gradient (stride 1), bit 2 input gradient worth it"""
+    from dl_ofdm_amd import _lib
+    f = _lib.load().dccn_cconv_patch_bwd_supported
+    assert f(8, 560, 1, 2, 560, 1, 5, 1, 1, 1, 64) == 3          # 2 channels: 4 of 64 tile columns used, five taps deep
+    assert f(8, 560, 1, 16, 560, 1, 5, 1, 1, 1, 32) == 7
+    assert f(8, 560, 1, 64, 560, 1, 5, 1, 1, 1, 64) == 7
+    assert f(8, 560, 1, 16, 280, 1, 5, 1, 2, 1, 32) == 1         # strided: input gradient by col2im
+    assert f(8, 560, 1, 3, 560, 1, 5, 1, 1, 1, 32) == 0          # odd channel count: no float4 pieces
 
 
 @pytest.mark.gpu

@@ -118,6 +118,34 @@ def test_conv1d_and_nn_conv1d_literals():
     assert np.abs(canon[..., 0] - want.real).max() < 1e-12 and np.abs(canon[..., 1] - want.imag).max() < 1e-12
 
 
+@pytest.mark.parametrize("shape,F,kern,strides,padding", [
+    ((2, 9, 10, 3, 2), 5, (3, 2), (2, 1), "valid"),
+    ((3, 8, 12, 2, 2), 4, (3, 5), (1, 2), "same"),
+    ((2, 11, 1, 4, 2), 6, (5, 1), (1, 1), "same"),
+])
+def test_torch_twin_of_the_literal_convolution(shape, F, kern, strides, padding):
+    """oracle/torch_ref.layers_conv2d_complex_literal_t (the autograd reference of the general-k backward) is the numpy
+    literal, and its gradients satisfy the adjoint identity <g, J v> = <J^T g, v> of a linear map."""
+    from oracle.torch_ref import layers_conv2d_complex_literal_t, layers_conv1d_complex_literal_t
+    rng = np.random.RandomState(3)
+    x = rng.randn(*shape)
+    k = rng.randn(kern[0], kern[1], 1, shape[3], 2 * F)
+    b = rng.randn(2 * F)
+    xt, kt = torch.tensor(x, requires_grad=True), torch.tensor(k, requires_grad=True)
+    y = layers_conv2d_complex_literal_t(xt, kt, torch.tensor(b), strides, padding)
+    ref = O.layers_conv2d_complex_literal(x, k, b, strides, padding)
+    assert y.shape == ref.shape and np.abs(y.detach().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    g = rng.randn(*ref.shape)
+    y.backward(torch.tensor(g))
+    v = rng.randn(*shape)
+    jv = O.layers_conv2d_complex_literal(v, k, None, strides, padding)             # the layer is linear in x
+    assert abs((g * jv).sum() - (xt.grad.numpy() * v).sum()) <= 1e-10 * np.abs(g * jv).sum()
+    if kern[1] == 1:
+        y1 = layers_conv1d_complex_literal_t(torch.tensor(x[:, :, 0]), torch.tensor(k[:, :, 0]), torch.tensor(b), strides[0], padding)
+        ref1 = O.layers_conv1d_complex_literal(x[:, :, 0], k[:, :, 0], b, strides[0], padding)
+        assert np.abs(y1.numpy() - ref1).max() <= 1e-12 * np.abs(ref1).max()
+
+
 def test_loss_ber_semantics():
     prob = np.array([[[[0.5, 0.5]], [[0.2, 0.8]], [[0.9, 0.1]]]])      # [1,3,1,2]
     bits = np.array([[[1], [1], [1]]])

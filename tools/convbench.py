@@ -1,6 +1,7 @@
 """General-k complex convolution (dev/py/complex.py:51-92 layers_conv1d_complex): implicit GEMM (dccn_cconv_patch_fwd, the
 operand loader gathers the taps) against the im2col + GEMM route (dccn_cconv_im2col writes the k-inflated patch tensor,
-dccn_cconv_gemm_fwd reads it back), forward only, same process, alternating rounds.
+dccn_cconv_gemm_fwd reads it back), same process, alternating rounds: the forward, and the backward (weight + input
+gradient) as implicit GEMMs (dccn_cconv_patch_bwd_w / _bwd_x) against im2col + GEMM + GEMM + col2im.
 
     python tools/convbench.py [--k 5] [--iters 100] [--rounds 5]
 """
@@ -13,6 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl_ofdm_amd import complex as CX          # noqa: E402
+from dl_ofdm_amd import ops                    # noqa: E402
 from dl_ofdm_amd.engine import HipTimer        # noqa: E402
 
 SHAPES = [  # (B, L, C, F)
@@ -53,9 +55,55 @@ def main():
         CX.IMPLICIT_GEMM = True
         med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         flop = 2.0 * B * L * (2 * a.k * C) * (2 * F)
+        # backward of the same layer: one forward graph, its backward replayed (torch.autograd.grad, graph retained)
+        xg = x.clone().requires_grad_()
+        store.begin()
+        y = CX.layers_conv1d_complex(xg, F, a.k, strides=1, padding="same", scope=store)
+        g = torch.randn_like(y)
+        leaves = (xg, store.tensor("conv2d/kernel"), store.tensor("conv2d/bias"))
+        # the parts alone: graphs in which only the input / only the variables require a gradient
+        kv, bv = store.tensor("conv2d/kernel"), store.tensor("conv2d/bias")
+        kv.requires_grad_(False); bv.requires_grad_(False)
+        store.begin()
+        y_x = CX.layers_conv1d_complex(xg, F, a.k, strides=1, padding="same", scope=store)
+        kv.requires_grad_(True); bv.requires_grad_(True)
+        store.begin()
+        y_w = CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+        parts = {"": (y, leaves), "_dx": (y_x, leaves[:1]), "_dw": (y_w, leaves[1:])}
+        bmed = {}
+        for tag, (yy, lv) in parts.items():
+            btimes = {True: [], False: []}
+            for _ in range(a.rounds):
+                for implicit in (True, False):
+                    ops._PATCH_BWD_IM2COL = not implicit
+                    ops._PATCH_BWD_DX_ALWAYS = implicit
+                    for _ in range(5):
+                        torch.autograd.grad(yy, lv, g, retain_graph=True)
+                    torch.cuda.synchronize()
+                    t = HipTimer()
+                    t.start(st_)
+                    for _ in range(a.iters):
+                        torch.autograd.grad(yy, lv, g, retain_graph=True)
+                    t.stop(st_)
+                    btimes[implicit].append(t.elapsed_ms() / a.iters)
+            ops._PATCH_BWD_IM2COL = ops._PATCH_BWD_DX_ALWAYS = False
+            for k, v in btimes.items():
+                bmed[("implicit" if k else "im2col") + tag] = sorted(v)[len(v) // 2]
+        # what the library picks by itself (the input gradient goes implicit only where dccn_cconv_patch_bwd_supported expects a gain)
+        for _ in range(5):
+            torch.autograd.grad(y, leaves, g, retain_graph=True)
+        t = HipTimer()
+        t.start(st_)
+        for _ in range(a.iters):
+            torch.autograd.grad(y, leaves, g, retain_graph=True)
+        t.stop(st_)
+        bmed["default"] = t.elapsed_ms() / a.iters
         print(json.dumps(dict(shape=dict(B=B, L=L, C=C, F=F, k=a.k), implicit_ms=round(med[True], 4), im2col_ms=round(med[False], 4),
                               speedup=round(med[False] / med[True], 2), implicit_tflops=round(flop / med[True] / 1e9, 2),
-                              patch_tensor_mb=round(B * L * a.k * C * 2 * 4 / 1e6, 1))))
+                              patch_tensor_mb=round(B * L * a.k * C * 2 * 4 / 1e6, 1),
+                              bwd_ms={k: round(v, 4) for k, v in bmed.items()},
+                              bwd_speedup=round(bmed["im2col"] / bmed["default"], 2),
+                              bwd_tflops=round(2 * flop / bmed["default"] / 1e9, 2))))
 
 
 if __name__ == "__main__":
