@@ -24,6 +24,29 @@ CHANNELS = ("EPA", "EVA", "ETU")
 SNRS = tuple(range(-10, 30))
 
 
+def visible_gpus_without_hip() -> int:
+    """GPUs this process will see, counted WITHOUT initialising the HIP runtime (its queue limits are read from the
+    environment once, at initialisation): the visibility variables if set, else the DRM render nodes."""
+    import glob
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([t for t in v.split(",") if t.strip() != ""])
+    return len(glob.glob("/dev/dri/renderD*"))
+
+
+def shared_gpu_env(local_world: int, n_gpus: int, env=None) -> Dict[str, str]:
+    """Environment additions for ranks that SHARE a GPU (local_world > n_gpus): one hardware queue per process.
+    Measured (tools/c5share.sh, four config-5 chains as four processes on one MI355X, equaliser seconds per chain):
+    GPU_MAX_HW_QUEUES=1: 4.9-5.9 (serial: 3.9 each, one after the other); the runtime's default of 4 queues per process:
+    4.8-19.4; 2: 24-27; 8: 30-33 -- beyond a handful of queues the scheduler time-slices them in millisecond quanta, and a
+    chain of 5-us launches stalls for most of every quantum.  A value already set by the user is kept."""
+    env = os.environ if env is None else env
+    if n_gpus > 0 and local_world > n_gpus and "GPU_MAX_HW_QUEUES" not in env:
+        return {"GPU_MAX_HW_QUEUES": "1"}
+    return {}
+
+
 def init_distributed(backend: Optional[str] = None):
     """(rank, world, local device index); joins the torch.distributed job described by the environment, if any.
     backend: ``nccl`` (= RCCL over xGMI, one rank per GPU; default) or ``gloo`` (ranks may share a device: rank r works on
@@ -31,12 +54,15 @@ def init_distributed(backend: Optional[str] = None):
 
     Ranks sharing a GPU are not only a test device: config 5's training chains are latency-bound sequences of 73-frame steps
     that keep a few percent of an MI355X busy each, and independent processes own independent hardware queues, so
-    ``torchrun --nproc-per-node 4 ... tools/config5_sweep.py --backend gloo`` on ONE GPU trains the four modulations next to
-    each other (profiles/r04_config5_4ranks_1gpu).  Every model is still trained by exactly one rank with its own seeds: the
+    ``torchrun --nproc-per-node 4 ... tools/config5_sweep.py --backend gloo`` (or ``tools/config5_sweep.py --share 4``) on ONE
+    GPU trains the four modulations next to each other -- with ONE hardware queue per process (shared_gpu_env; set here,
+    before the first HIP call of the process).  Every model is still trained by exactly one rank with its own seeds: the
     result does not depend on the sharing."""
-    import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    os.environ.update(shared_gpu_env(local_world, visible_gpus_without_hip()))
+    import torch
     backend = backend or os.environ.get("DCCN_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if backend == "nccl" and world > 1 and local >= ndev:
@@ -293,6 +319,7 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
         with open(os.path.join(out_dir, "config5_timing.json"), "w") as f:
             import torch.distributed as dist
             json.dump({"world": world, "backend": dist.get_backend() if world > 1 else "none (1 rank)",
+                       "hw_queues_per_process": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                        "classical_workers": workers, "frames": frames, "eq_epochs": eq_epochs, "rx_epoch_scale": rx_epoch_scale,
                        "classical_frames": classical_frames, "points": len(pts), "job_owners": job_owners(nbits_list, world),
                        "per_rank_seconds": all_t}, f, indent=1)

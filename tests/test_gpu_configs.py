@@ -203,6 +203,28 @@ def test_config5_sweep_tool_over_rccl(tmp_path):
     assert tj["world"] == 2 and tj.get("backend") == "nccl"
 
 
+def test_config5_sweep_tool_share_ranks_on_one_gpu(tmp_path):
+    """tools/config5_sweep.py --share 3 (scaled down): the tool re-launches itself as three gloo ranks that share the visible
+    GPU, one hardware queue per process (config5.shared_gpu_env); the CSV equals the 1-rank run byte for byte."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DCCN_BENCH_BACKEND", "DCCN_DIST_BACKEND", "GPU_MAX_HW_QUEUES", "RANK",
+                                                            "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+    common = ["--frames", "1000", "--eq_epochs", "3", "--rx_epoch_scale", "0.01", "--classical_frames", "30",
+              "--snrs=-5,10,29", "--classical_every", "2"]
+    tool = os.path.join(ROOT, "tools", "config5_sweep.py")
+    shared = subprocess.run([sys.executable, tool, "--share", "3", "--out", str(tmp_path / "shared")] + common, cwd=ROOT, env=env,
+                            capture_output=True, text=True, timeout=1500)
+    assert shared.returncode == 0, shared.stderr[-3000:]
+    one = subprocess.run([sys.executable, tool, "--out", str(tmp_path / "one")] + common, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1500)
+    assert one.returncode == 0, one.stderr[-3000:]
+    assert open(str(tmp_path / "one" / "config5_ber.csv")).read() == open(str(tmp_path / "shared" / "config5_ber.csv")).read()
+    tj = json.load(open(str(tmp_path / "shared" / "config5_timing.json")))
+    assert tj["world"] == 3 and tj["backend"] == "gloo" and tj["hw_queues_per_process"] == "1"
+    assert json.load(open(str(tmp_path / "one" / "config5_timing.json")))["hw_queues_per_process"] == "runtime default"
+
+
 def _c5_worker(rank, world, port, out_dir, q, kw, classical_every=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

@@ -164,3 +164,19 @@ def test_config5_unit_ownership_over_ranks():
         w = config5.classical_workers(nb, world)
         owners = [w[u % len(w)] for u in range(4 * 3 * 3 * 14)]
         assert set(owners) == set(w) and all(0 <= r < world for r in owners)
+
+
+def test_ranks_sharing_a_gpu_get_one_hardware_queue_each(monkeypatch):
+    """config5.shared_gpu_env: only when more local ranks than GPUs, never over a value the user set; the GPU count comes
+    from the visibility variables / render nodes, not from a HIP call (the runtime reads its queue limit at initialisation)"""
+    from dl_ofdm_amd import config5
+    assert config5.shared_gpu_env(4, 1, env={}) == {"GPU_MAX_HW_QUEUES": "1"}
+    assert config5.shared_gpu_env(8, 8, env={}) == {}
+    assert config5.shared_gpu_env(1, 1, env={}) == {}
+    assert config5.shared_gpu_env(4, 0, env={}) == {}                       # no GPU visible: nothing to tune
+    assert config5.shared_gpu_env(4, 1, env={"GPU_MAX_HW_QUEUES": "2"}) == {}
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3")
+    assert config5.visible_gpus_without_hip() == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert config5.visible_gpus_without_hip() == 1

@@ -2,6 +2,7 @@
 
     python tools/config5_sweep.py --out profiles/r02_config5 [--frames 20000] [--eq_epochs 600] [--backend nccl|gloo]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/config5_sweep.py --out ...
+    python tools/config5_sweep.py --share 4 --out ...     # ONE GPU: four ranks (gloo) share it, one hardware queue each
 """
 import argparse
 import os
@@ -25,7 +26,24 @@ def main():
     ap.add_argument("--channels", default=",".join(config5.CHANNELS))
     ap.add_argument("--snrs", default="", help="comma separated SNRs in dB (default: -10..29)")
     ap.add_argument("--classical_every", type=int, default=3)
+    ap.add_argument("--share", type=int, default=0, help="started as ONE process: re-launch as this many gloo ranks sharing the "
+                                                          "visible GPU(s) (the four training chains run side by side)")
     a = ap.parse_args()
+    if a.share > 1 and "RANK" not in os.environ:
+        import subprocess
+        argv, skip = [], False
+        for t in sys.argv[1:]:
+            if skip:
+                skip = False
+            elif t == "--share":
+                skip = True
+            elif not t.startswith("--share="):
+                argv.append(t)
+        if not any(t == "--backend" or t.startswith("--backend=") for t in argv):
+            argv += ["--backend", "gloo"]
+        raise SystemExit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(a.share),
+                                          "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+                                          os.path.abspath(__file__)] + argv))
     import torch
     rank, world, local = config5.init_distributed(a.backend)
     import tempfile
