@@ -309,7 +309,10 @@ constexpr int kGenFramesPerBlock = 2;
 template <int S, int K, int CP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a) {
     constexpr int K2 = 2 * K, N2 = 2 * (K + CP), T = S * (K + CP), LDG = K2 + 4;
-    constexpr int G16 = K2 / 16, NTILE = N2 / 16, TPW = (NTILE + 3) / 4;
+    // the cyclic-prefix columns of the ifft matrix are bitwise copies of its last 2 CP columns (t = (t' - CP) mod K,
+    // datagen.py idft_cp_matrix): only the K2 / 16 tiles behind the prefix are multiplied, the prefix is stored twice
+    constexpr int G16 = K2 / 16, NTILE = N2 / 16, CPT = 2 * CP / 16, NMUL = NTILE - CPT, TPW = (NMUL + 3) / 4;
+    static_assert((2 * CP) % 16 == 0 && CPT <= NMUL, "cyclic prefix: whole 16-column tiles");
     constexpr int NSMP = (kGenFramesPerBlock * T + 255) / 256;          // samples per thread (5)
     constexpr int NCELL = 16 * K / 256;                                  // grid cells per thread (4)
     static_assert(kGenFramesPerBlock * S <= 16 && K2 % 16 == 0 && N2 % 16 == 0 && (16 * K) % 256 == 0, "generator tile shape");
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float bfr[TPW][G16][4];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-        const int tile = min(w + 4 * ti, NTILE - 1);
+        const int tile = min(CPT + w + 4 * ti, NTILE - 1);
         const float* B = a.idft + (size_t)(4 * kq) * N2 + 16 * tile + c;
 #pragma unroll
         for (int g = 0; g < G16; ++g)
@@ -432,12 +435,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float* txf = reinterpret_cast<float*>(sTX);
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
-            const int tile = w + 4 * ti;
+            const int tile = CPT + w + 4 * ti;
             if (tile < NTILE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * kq + r, fr = row / S;
-                    if (fr < nfr) txf[fr * 2 * T + (row - fr * S) * N2 + 16 * tile + c] = acc[ti][r];
+                    if (fr < nfr) {
+                        float* o = txf + fr * 2 * T + (row - fr * S) * N2 + 16 * tile + c;
+                        o[0] = acc[ti][r];
+                        if (tile >= NTILE - CPT) o[-K2] = acc[ti][r];              // the prefix: columns 2K.. are columns 0..
+                    }
                 }
             }
         }

@@ -356,6 +356,12 @@ def test_fused_static_generator_matches_the_launch_per_stage_chain(chan, nbits, 
     assert torch.equal(bits_a, bits_b)
     sc = float(tx_a.abs().max())
     assert float((tx_a - tx_b).abs().max()) <= 2e-6 * sc
+    # the cyclic prefix is a copy of the symbol's tail, to the bit (the fused launch multiplies the 2K columns behind the prefix
+    # only and stores the last 2 CP of them twice; the ifft matrix's prefix columns are bitwise copies, so the GEMM route agrees)
+    ncp = gb.CP
+    for t in (tx_a, tx_b):
+        v = t.view(n, gb.S, gb.K + ncp, 2)
+        assert torch.equal(v[:, :, :ncp], v[:, :, gb.K:])
     assert float((x_a - x_b).abs().max()) <= 1e-5 * float(x_a.abs().max())
     assert abs(float(npow_a) - float(npow_b)) <= 1e-6 * float(npow_a)
     want_npow = float((fg.noise.double() ** 2).sum() / (n * gb.T))
