@@ -236,6 +236,54 @@ def test_conv2d_implicit_gemm_two_tap_axes():
         assert relerr(st.tensor("conv3d/bias").grad.cpu().numpy(), b64.grad.numpy()) <= 1e-5
 
 
+@pytest.mark.gpu
+def test_conv2d_random_geometries_forward_and_backward():
+    """48 seeded random geometries of layers_conv2d_complex (kernel sizes up to and beyond the input extent, strides 1-3, SAME /
+    VALID, one or two tap axes, 2-12 channels and filters, outputs of a single position): output and all three gradients of
+    the implicit-GEMM route against the fp64 literal / its autograd twin at 1e-5 -- the operand loaders' index arithmetic
+    (tap decomposition, padding masks, row decomposition by multiply-shift, flipped taps, ragged tiles) on shapes nobody chose."""
+    from dl_ofdm_amd import complex as CX, ops
+    from oracle.torch_ref import layers_conv2d_complex_literal_t
+    rng = np.random.RandomState(20260928)
+    done = 0
+    while done < 48:
+        B, L, Wd = int(rng.randint(1, 6)), int(rng.randint(1, 24)), int(rng.randint(1, 24))
+        C, F = 2 * int(rng.randint(1, 7)), 2 * int(rng.randint(1, 7))
+        kern = (int(rng.randint(1, 8)), int(rng.randint(1, 8)))
+        strides = (int(rng.randint(1, 4)), int(rng.randint(1, 4))) if rng.rand() < 0.4 else (1, 1)
+        padding = "same" if rng.rand() < 0.6 else "valid"
+        if padding == "valid" and (kern[0] > L or kern[1] > Wd):
+            continue
+        x = rng.randn(B, L, Wd, C, 2).astype(np.float32)
+        st = CX.VariableStore(seed=int(rng.randint(1, 1000)))
+        xt = torch.as_tensor(x).cuda().requires_grad_()
+        CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
+        st.set("conv3d/bias", rng.randn(2 * F))
+        st.begin()
+        ops._PATCH_BWD_DX_ALWAYS = True
+        try:
+            y = CX.layers_conv2d_complex(xt, F, kern, strides=strides, padding=padding, scope=st)
+            g = torch.as_tensor(rng.randn(*y.shape).astype(np.float32)).cuda()
+            y.backward(g)
+        finally:
+            ops._PATCH_BWD_DX_ALWAYS = False
+        full = _full_kernel(st, "conv3d", rng)
+        bias = st.tensor("conv3d/bias").detach().cpu().numpy().astype(np.float64)
+        what = (B, L, Wd, C, F, kern, strides, padding)
+        ref = O.layers_conv2d_complex_literal(x.astype(np.float64), full, bias, strides, padding)
+        assert relerr(y.detach().cpu().numpy(), ref) <= 1e-5, what
+        x64 = torch.tensor(x.astype(np.float64), requires_grad=True)
+        k64, b64 = torch.tensor(full, requires_grad=True), torch.tensor(bias, requires_grad=True)
+        layers_conv2d_complex_literal_t(x64, k64, b64, strides, padding).backward(g.cpu().double())
+        tl, tw = st.meta["conv3d/kernel"]["live_taps"]
+        kg = k64.grad.numpy()
+        live = np.stack([np.stack([kg[a, b, 0] for b in tw]) for a in tl])
+        assert relerr(xt.grad.cpu().numpy(), x64.grad.numpy()) <= 1e-5, what
+        assert relerr(st.tensor("conv3d/kernel").grad.cpu().numpy().reshape(live.shape), live) <= 1e-5, what
+        assert relerr(st.tensor("conv3d/bias").grad.cpu().numpy(), b64.grad.numpy()) <= 1e-5, what
+        done += 1
+
+
 def test_patch_backward_route_bits():
     """dccn_cconv_patch_bwd_supported: bit 0 weight gradient, bit 1 input gradient (stride 1), bit 2 input gradient worth it"""
     from dl_ofdm_amd import _lib
