@@ -411,3 +411,37 @@ def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frame
     ma, mb = ea.metrics(), eb.metrics()
     assert ma["conf"] == mb["conf"] and ma["ce_mean"] == mb["ce_mean"] and ma["tx_power"] == mb["tx_power"]
     assert torch.equal(fgs[0].npow, fgs[1].npow)
+
+
+def test_generated_step_refuses_the_double_buffered_plan_and_apply_takes_no_noise_monitor():
+    """edge cases of the fused-generator ABI: (1) dccn_rx_buffers.gen_next together with x_norm_next (the double-buffered
+    pipelining normalises on the backward launch, which has no virtual-input form) is refused, nothing is launched and the
+    parameters stay as they were; (2) dccn_gen_static_apply on a generator armed WITHOUT the noise-power monitor leaves the
+    monitor output alone."""
+    import ctypes as C
+    from dl_ofdm_amd import _lib, ofdm, receiver as R
+    from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
+    from dl_ofdm_amd.engine import RxEngine
+    F = flags(nbits=2, channel="EPA")
+    o = ofdm.ofdm_tx(F)
+    eng = RxEngine(R.rx_dims(F, o), 73, device="cuda", train=True, seed=1, want_prob=False, want_z=False, want_dfft=False)
+    gen = DeviceDataGen(F, o, seed=3)
+    fg = FusedStaticGen(gen, 73, 10.0)
+    eng.train_step_generated(fg, slot=0)
+    torch.cuda.synchronize()
+    before = eng.params.clone()
+    d = fg.arm(eng.label_slot(0), 0)
+    good = eng._pipe_buffers(1, False, 0, False, 1, 0, C.addressof(d), False)
+    vals = {f: getattr(good, f) for f, _ in _lib.RxBuffers._fields_}
+    vals["x_norm_next"] = vals["x_norm"]
+    bad = _lib.RxBuffers(*[vals[f] for f, _ in _lib.RxBuffers._fields_])
+    rc = eng.lib.dccn_rx_train_step(C.byref(eng.shape), C.byref(bad), eng.hp, eng._stream())
+    torch.cuda.synchronize()
+    assert rc == -1 and torch.equal(before, eng.params)            # DCCN_ERR_INVALID_ARG (include/dccn.h)
+    # (2)
+    assert fg.npart is None and fg.npow is None
+    x = torch.empty(73, gen.S, gen.K + gen.CP, 2, device="cuda")
+    bits = torch.empty(73, o.frame_size, 2, dtype=torch.int32, device="cuda")
+    _, _, npow = fg.make_batch(x, bits, slot=0)
+    torch.cuda.synchronize()
+    assert npow is None and torch.isfinite(x).all() and float(x.abs().max()) > 0
