@@ -52,7 +52,7 @@ class RxBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
                 ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p),
-                ("gen_next", c_void_p)]
+                ("gen_next", c_void_p), ("prefetch_fwd", c_int)]
 
 
 class GenStatic(C.Structure):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "dccn_cconv_patch_supported": (_i, [_i] * 9),
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
+    "dccn_rx_prefetch_pays": (_i, [POINTER(RxShape)]),
     "dccn_cconv_patch_bwd_supported": (_i, [_i] * 11),
     "dccn_cconv_patch_bwd_w_workspace_size": (C.c_size_t, [_i] * 7),
     "dccn_cconv_patch_bwd_w": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp, C.c_size_t, _vp]),

@@ -74,7 +74,8 @@ enum TuneKey : int {
     TUNE_ADAM_OVERLAP = 25,     // 1: large layers: the dense kernel's Adam update runs on a second stream next to the C-Conv weight-gradient launch
                                 //    2: ... with non-temporal loads and stores (it must not displace the GEMM's operand panels)
     TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
-    TUNE_COUNT = 26
+    TUNE_FWD_PREFETCH_BIG = 26, // 1: dccn_rx_prefetch_pays answers 1 for the shapes whose dense update runs on the second stream (off: no gain measured)
+    TUNE_COUNT = 27
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -113,7 +114,7 @@ struct TuneTable {
 //           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
 //   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
 //           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
-static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}}};
+static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -1306,6 +1307,10 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             DCCN_TRY(gen_static_launch(b->gen_next, s));
         }
     }
+    // prefetch_fwd needs a batch normalised ahead by THIS call on the single-buffer pipelining (the double-buffered plan hands
+    // its forward over inside the optimizer launch: dccn_rx_norm_rides_backward == 2)
+    if (b->prefetch_fwd && (!train || (b->x_next == nullptr && b->gen_next == nullptr) || b->x_norm_next != nullptr))
+        return DCCN_ERR_INVALID_ARG;
     // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
     const bool pre = train && b->x_prenormalised != 0;
@@ -1463,7 +1468,9 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(cconv_bwd_w_impl(b->x_norm, b->dfft, G + L.o_conv_w, G + L.o_conv_b, L.rows, sh->kin, sh->F, ws_cbw,
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    if (overlap) { ojoin.joined = true; DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0)); }
+    // (overlap: the dense kernel's update on the second stream is joined at the END of the call -- the optimizer launch below
+    // leaves that segment alone (skip_lo / skip_hi), reads the same read-only step state, and with prefetch_fwd the next batch's
+    // C-Conv forward runs next to the update as well)
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
@@ -1541,6 +1548,14 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(norm_impl(b->x_next, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &np, sh->batch, L.cols, 1e-9f,
                            8.0f, nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
+    // prefetch_fwd: R1 of the batch just normalised into x_norm, with the C-Conv kernel just updated -- exactly the launch the
+    // next call would start with (it is told x_prenormalised = 2); fft_out is free: its last reader was the dense dW
+    if (b->prefetch_fwd) {
+        trace.launch(1);
+        DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
+        trace.none();
+    }
+    if (overlap) { ojoin.joined = true; DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0)); }
     return DCCN_OK;
 }
 
@@ -1806,6 +1821,16 @@ int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {
     const bool ok = g_tune[TUNE_NORM_ON_BWD] && rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, nullptr, nullptr, nullptr, nullptr) &&
                     kNormFusedCG == 2 && norm_fused_ok(nullptr, nullptr, sh->batch, cols);
     return ok ? (g_tune[TUNE_FWD_PREFETCH] ? 2 : 1) : 0;
+}
+int dccn_rx_prefetch_pays(const dccn_rx_shape* sh) {
+    if (!shape_ok(sh) || !g_tune[TUNE_FWD_PREFETCH_BIG]) return 0;
+    // the static part of rx_step_impl's `overlap` decision (the dense kernel's update on the second stream)
+    const RxLayout L = rx_layout(sh);
+    const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
+    const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
+    const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;
+    return (g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
+            (((long long)L.dK * L.dN) % 4) == 0) ? 1 : 0;
 }
 int dccn_rx_bwd_fused_supported(const dccn_rx_shape* sh) {
     if (!shape_ok(sh)) return 0;
@@ -2263,7 +2288,7 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
 }
 
 // ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
-static_assert(sizeof(dccn_gen_static) == 168 && sizeof(dccn_rx_buffers) == 200, "ctypes mirrors in dl_ofdm_amd/_lib.py");
+static_assert(sizeof(dccn_gen_static) == 168 && sizeof(dccn_rx_buffers) == 208, "ctypes mirrors in dl_ofdm_amd/_lib.py");
 int dccn_gen_static_supported(int S, int K, int CP) {
     return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
 }

@@ -146,6 +146,9 @@ class RxEngine:
         self._norm_parity = 0
         self._fwd_prefetched = False         # fft_out already holds the C-Conv forward of the prefetched batch
         self._ride = int(self.lib.dccn_rx_norm_rides_backward(C.byref(self.shape))) if train else 0
+        # large layers: the pipelined step also runs the NEXT batch's C-Conv forward, next to the dense kernel's update on the
+        # library's second stream (dccn_rx_buffers.prefetch_fwd)
+        self._prefetch_big = bool(self.lib.dccn_rx_prefetch_pays(C.byref(self.shape))) if train else False
         if self._ride:
             self._norm_bufs[1] = torch.empty_like(self.x_norm)
         # the same buffers in the pipelined mode (dccn.h: x_next / x_prenormalised), built on demand per (label slot, last)
@@ -226,8 +229,8 @@ class RxEngine:
         return self.bits_alt
 
     def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1,
-                      ready: int = 0, gen: int = 0, keep_x: bool = True) -> RxBuffers:
-        key = (slot, last, parity, double, pre, ready, gen, keep_x)
+                      ready: int = 0, gen: int = 0, keep_x: bool = True, prefetch: bool = False) -> RxBuffers:
+        key = (slot, last, parity, double, pre, ready, gen, keep_x, prefetch)
         if key not in self._pipe_bufs:
             vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
             vals["bits"] = self.label_slot(slot).data_ptr()
@@ -238,6 +241,7 @@ class RxEngine:
             vals["norm_slot"] = parity
             vals["x_norm_next"] = self._norm_bufs[parity ^ 1].data_ptr() if (double and not last) else 0
             vals["x_next_ready"] = 0 if last else ready
+            vals["prefetch_fwd"] = 1 if (prefetch and not last) else 0
             self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
         return self._pipe_bufs[key]
 
@@ -275,9 +279,11 @@ class RxEngine:
                 ready = int(x_ready.cuda_event)
                 if not ready:
                     raise _lib.DccnError("x_ready must be an event that has been recorded")
-            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1, ready)
+            pf = self._prefetch_big and not double and not last
+            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1, ready,
+                                      prefetch=pf)
             check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(bufs), self.hp, self._stream()), "dccn_rx_train_step")
-            self._fwd_prefetched = False
+            self._fwd_prefetched = pf              # fft_out holds the C-Conv forward of the batch just normalised
             if double and not last:
                 self._norm_parity ^= 1           # the prefetched batch sits in the other buffer ...
                 self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out

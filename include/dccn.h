@@ -272,7 +272,8 @@ int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_strea
  * arenas (default 0), 23 tile shape of the fused dense + tail launch of large layers (default 0 = 80x64), 24 equaliser step: the Adam
  * updates of dense_3 / dense_4 and the smoothing kernel's gradient fold ride behind the pilot bottleneck's backward launch (default 1),
  * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream next to the C-Conv weight-gradient launch
- * (0 off, 1 on, 2 = default: with non-temporal loads and stores).
+ * (0 off, 1 on, 2 = default: with non-temporal loads and stores), 26 (default 0: measured 4725 vs 4724 us per N = 1024 step) dccn_rx_prefetch_pays answers 1 for those
+ * layers (the pipelined caller then moves the next batch's C-Conv forward next to that update: dccn_rx_buffers.prefetch_fwd).
  * Key 2: 7 (default) = the staged whole-k C-Conv forward, 8-11 its other store slots / 32x128
  * tiles; key 14: presets 1-24, default 14 = ranges of {9,5,2,2,1}/19 of the batch.
  * Set them before workspaces are sized. */
@@ -423,6 +424,14 @@ typedef struct dccn_rx_buffers {
        calls on the single-buffer pipelining only (dccn_rx_norm_rides_backward(shape) == 0); one C call per generated-and-
        trained batch. */
     const dccn_gen_static* gen_next;
+    /* Round 5: prefetch_fwd != 0 (training calls that normalise a next batch -- x_next or gen_next -- on the single-buffer
+       pipelining): the call also runs the C-Conv forward (R1) of THAT batch into fft_out as its last launch, after the C-Conv
+       kernel's own update; the following call is told so with x_prenormalised = 2 and starts at R2.  Same kernels on the same
+       data in the same order per stream: bit-identical training.  Meant for the steps whose optimizer is split over two streams
+       (dccn_rx_prefetch_pays: large layers, N = 1024): the 0.3-ms matrix launch then runs NEXT TO the dense kernel's
+       HBM-bound update instead of behind it -- measured: no gain (the update and the matrix launches already share the
+       memory system; 4725 vs 4724 us per step), so no caller requests it by default (tuning key 26). */
+    int prefetch_fwd;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
@@ -435,6 +444,10 @@ int dccn_rx_dense_tail_fused(const dccn_rx_shape* shape, int train);
  * 2: its optimizer launch then also runs the C-Conv forward of that batch (into fft_out, after the C-Conv kernel's own
  * update, handed over inside the launch), and the following call is told so with x_prenormalised = 2 */
 int dccn_rx_norm_rides_backward(const dccn_rx_shape* shape);
+/* 1 (only with tuning key 26 set): for this shape a training step updates the dense kernel on the library's second stream
+ * (large layers) and dccn_rx_buffers.prefetch_fwd moves the next batch's C-Conv forward next to that update; 0: prefetch_fwd
+ * still works, but only reorders launches on one stream */
+int dccn_rx_prefetch_pays(const dccn_rx_shape* shape);
 /* The backward half of the basic receiver's training step as one launch (small layers, see the query above):
  *   dfft = dz . Wd^T                     (dev/py/model.py:1268-1275 backward; written only when dfft != NULL)
  *   dWd  = fft_out^T . dz, dbd = colsum  (k-major tiles, split-K slabs)

@@ -292,6 +292,47 @@ def test_pipelined_normalisation_is_bitwise_the_plain_step(frames, nbits, kin, F
     b.train_step(xs[0], bs[0])
 
 
+@pytest.mark.parametrize("frames,nbits,kin,F,D", [(300, 2, 80, 64, 320), (1170, 4, 80, 64, 320), (585, 2, 1096, 1024, 4000)])
+def test_requested_forward_prefetch_is_bitwise(frames, nbits, kin, F, D):
+    """dccn_rx_buffers.prefetch_fwd: a pipelined step that also runs the NEXT batch's C-Conv forward as its last launch (large
+    layers: next to the dense kernel's update on the library's second stream; no caller asks for it by default -- tuning key 26,
+    measured without gain -- so it is forced on here); the following call starts at R2 (x_prenormalised = 2).  Eager calls
+    throughout, so every step but the first consumes a prefetched forward: bit-identical to plain steps."""
+    from dl_ofdm_amd.engine import RxDims, RxEngine
+    dims = RxDims(S=7, kin=kin, F=F, D=D, nbits=nbits)
+    rng = np.random.RandomState(8)
+    nb = 5 if F <= 64 else 4
+    xs = [rng.standard_normal((frames, 7, kin, 2)).astype(np.float32) * (1 + 0.1 * t) for t in range(nb)]
+    bs = [rng.randint(0, 2, (frames, D, nbits)).astype(np.int32) for t in range(nb)]
+    a = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True)
+    b = RxEngine(dims, frames, train=True, seed=3, want_prob=True, want_tx_power=True, want_z=False, want_dfft=False)
+    assert not b._prefetch_big
+    if b._ride:
+        pytest.skip("double-buffered pipelining active: the forward is handed over inside the optimizer launch instead")
+    b._prefetch_big = True
+    b.prime(xs[0])
+    for t in range(nb):
+        a.train_step(xs[t], bs[t])
+        if t < nb - 1:
+            b.train_step_pipelined(next_x=xs[t + 1], bits=bs[t], slot=t & 1)
+            assert b._fwd_prefetched
+        else:
+            b.train_step_pipelined(bits=bs[t], last=True)
+            assert not b._fwd_prefetched
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads), t
+        assert torch.equal(a.prob, b.prob) and torch.equal(a.adam_state, b.adam_state), t
+        assert a.metrics() == b.metrics(), t
+    # the protocol's refusals: nothing normalised ahead / evaluation
+    import ctypes as C
+    from dl_ofdm_amd import _lib
+    good = b._pipe_buffers(0, True, 0, False, 1, 0)
+    vals = {f: getattr(good, f) for f, _ in _lib.RxBuffers._fields_}
+    vals["prefetch_fwd"] = 1
+    bad = _lib.RxBuffers(*[vals[f] for f, _ in _lib.RxBuffers._fields_])
+    assert b.lib.dccn_rx_train_step(C.byref(b.shape), C.byref(bad), b.hp, b._stream()) == -1
+
+
 def test_forward_prefetch_on_the_optimizer_launch_is_bitwise():
     """Tuning knob 15 (off by default: measured slower): the optimizer launch of a double-buffered pipelined step also runs
     the C-Conv forward of the next batch, its updated kernel handed over INSIDE the launch (write-through stores, arrival
