@@ -301,6 +301,7 @@ struct GenStaticArgs {
 };
 typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGenFramesPerBlock = 2;
+constexpr int kGenFirPad = 64;             // >= the longest channel response the launch accepts (L <= 64)
 // S, K, CP are compile-time (the N = 64 grid of the reference: 7 symbols, 64 + 16 samples): every index split is a division by a
 // constant, and the per-thread loops over a block's 1024 grid cells and 1120 samples are unrolled -- a thread's cells / samples
 // are INDEPENDENT chains (Philox -> Box-Muller -> store; cell map -> Philox -> constellation table) whose latencies then
@@ -317,14 +318,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int NCELL = 16 * K / 256;                                  // grid cells per thread (4)
     static_assert(kGenFramesPerBlock * S <= 16 && K2 % 16 == 0 && N2 % 16 == 0 && (16 * K) % 256 == 0, "generator tile shape");
     extern __shared__ __attribute__((aligned(16))) float gsm[];
+    // the time-domain frames sit between two runs of kGenFirPad zeros: the 'same' FIR then reads its out-of-range neighbours
+    // as zeros instead of branching around them (adding +-0 leaves every partial sum as it was: same bits as the skipped form)
+    constexpr int TP = T + 2 * kGenFirPad;
     float* sG = gsm;                                   // [16][LDG]   grid rows (frame, symbol), (k, iq) contiguous
-    float2* sTX = reinterpret_cast<float2*>(gsm + 16 * LDG);      // [2][T]  time-domain frames
+    float2* sTX = reinterpret_cast<float2*>(gsm + 16 * LDG);      // [2][pad | T | pad]  time-domain frames
     __shared__ float2 gs[kGenFramesPerBlock][64];
     __shared__ float2 tap[kGenFramesPerBlock][16];
     __shared__ double sh[2][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int f0 = (int)blockIdx.x * kGenFramesPerBlock;
     const int nfr = min(kGenFramesPerBlock, a.frames - f0);
+    static_assert(kGenFramesPerBlock * 2 * kGenFirPad == 256, "one pad cell per thread");
+    sTX[(tid >> 7) * TP + ((tid >> 6) & 1) * (kGenFirPad + T) + (tid & 63)] = make_float2(0.f, 0.f);
 
     // 2 (early). this wave's share of the ifft matrix: tiles w, w + 4, ... ; lane (c, kq) needs idft[16 g + 4 kq + j][16 tile + c]
     const int c = lane & 15, kq = lane >> 4;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * kq + r, fr = row / S;
                     if (fr < nfr) {
-                        float* o = txf + fr * 2 * T + (row - fr * S) * N2 + 16 * tile + c;
+                        float* o = txf + fr * 2 * TP + 2 * kGenFirPad + (row - fr * S) * N2 + 16 * tile + c;
                         o[0] = acc[ti][r];
                         if (tile >= NTILE - CPT) o[-K2] = acc[ti][r];              // the prefix: columns 2K.. are columns 0..
                     }
@@ -451,7 +457,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     __syncthreads();
     if (a.tx_out != nullptr)
-        for (int i = tid; i < nfr * 2 * T; i += 256) a.tx_out[(size_t)f0 * 2 * T + i] = reinterpret_cast<const float*>(sTX)[i];
+        for (int i = tid; i < nfr * 2 * T; i += 256) {
+            const int fr = i / (2 * T);
+            a.tx_out[(size_t)f0 * 2 * T + i] = reinterpret_cast<const float*>(sTX)[fr * 2 * TP + 2 * kGenFirPad + (i - fr * 2 * T)];
+        }
     // 4. 'same' FIR (the loop of fir_same_kernel) and its power
     const int off = (a.L - 1) / 2;
     double pw = 0.0;
@@ -460,12 +469,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int q = 0; q < NSMP; ++q) {
             const int i = min(tid + 256 * q, nfr * T - 1), fr = i / T, t = i - fr * T;
-            const float2* xf = sTX + fr * T;
+            const float2* xf = sTX + fr * TP + kGenFirPad + t + off;
             float2 acc = make_float2(0.f, 0.f);
             for (int l = 0; l < ((a.abl & 8) ? 1 : a.L); ++l) {
-                const int u = t + off - l;
-                if (u < 0 || u >= T) continue;
-                const float2 v = xf[u], gl = gs[fr][l];
+                const float2 v = xf[-l], gl = gs[fr][l];
                 acc.x += gl.x * v.x - gl.y * v.y;
                 acc.y += gl.x * v.y + gl.y * v.x;
             }

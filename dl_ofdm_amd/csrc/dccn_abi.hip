@@ -1265,7 +1265,7 @@ static int gen_static_launch(const dccn_gen_static* g, hipStream_t s) {
         a.abl = abl;
     }
     const int T = g->S * (g->K + g->CP);
-    const size_t smem = (size_t)16 * (2 * g->K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * T * sizeof(float2);
+    const size_t smem = (size_t)16 * (2 * g->K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * (T + 2 * kGenFirPad) * sizeof(float2);
     const int blocks = ceil_div(g->frames, kGenFramesPerBlock);
     hipLaunchKernelGGL((gen_static_frames_kernel<7, 64, 16>), dim3(blocks), dim3(256), smem, s, a);
     DCCN_LAUNCH_CHECK();
