@@ -284,6 +284,31 @@ def test_conv2d_random_geometries_forward_and_backward():
         done += 1
 
 
+def test_multiply_shift_division_of_the_patch_loader_is_exact():
+    """csrc/gemm_f32_mfma.h patch_div_magic / gemm_kmajor.h patch_div (row -> (b, lo, wo) of the implicit weight-gradient GEMM):
+    s = ceil(log2 d), mul = ceil(2^(31+s) / d), q = (n * mul) >> (31 + s) equals n // d for every 0 <= n < 2^31 -- the
+    algorithm restated here and checked at the boundaries of every quotient step and on random pairs (the device code itself is
+    exercised by the convolution tests above)."""
+    def magic(d):
+        s = 0
+        while (1 << s) < d:
+            s += 1
+        shift = 31 + s
+        mul = ((1 << shift) + d - 1) // d
+        assert mul < (1 << 32)
+        return mul, shift
+    rng = np.random.RandomState(11)
+    ds = [1, 2, 3, 5, 7, 64, 73, 560, 4095, 4096, 65535, 65537, (1 << 31) - 1, 1 << 30] + [int(v) for v in rng.randint(1, 1 << 31, 200)]
+    top = (1 << 31) - 1
+    for d in ds:
+        mul, shift = magic(d)
+        ns = {0, 1, d - 1, d, d + 1, top, top - 1, (top // d) * d, max((top // d) * d - 1, 0)}
+        ns |= {int(v) for v in rng.randint(0, 1 << 31, 50)}
+        ns |= {min(int(q) * d + r, top) for q in rng.randint(0, max(top // d, 1) + 1, 20) for r in (0, d - 1)}
+        for n in ns:
+            assert (n * mul) >> shift == n // d, (n, d)
+
+
 def test_patch_backward_route_bits():
     """dccn_cconv_patch_bwd_supported: bit 0 weight gradient, bit 1 input gradient (stride 1), bit 2 input gradient worth it"""
     from dl_ofdm_amd import _lib
