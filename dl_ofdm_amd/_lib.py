@@ -62,7 +62,14 @@ class GenStatic(C.Structure):
                 ("L", c_int), ("identity", c_int), ("snr_db", c_void_p), ("y", c_void_p), ("noise", c_void_p),
                 ("power_partial", c_void_p), ("noise_partial", c_void_p), ("noise_power_out", c_void_p), ("tx_out", c_void_p),
                 ("frames", c_int), ("S", c_int), ("K", c_int), ("CP", c_int), ("D", c_int), ("nbits", c_int),
-                ("seed", C.c_ulonglong), ("offset", C.c_uint)]
+                ("seed", C.c_ulonglong), ("offset", C.c_uint),
+                ("n_profiles", c_int), ("tap_stride", c_int), ("profiles", c_void_p), ("H_out", c_void_p), ("h_rep", c_int)]
+
+
+class GenProfile(C.Structure):
+    """dccn_gen_profile"""
+    _fields_ = [("coeff", c_void_p), ("alpha", c_void_p), ("n_taps", c_int), ("L", c_int), ("identity", c_int),
+                ("reserved", c_int)]
 
 
 class EqShape(C.Structure):

@@ -289,9 +289,16 @@ __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y,
 // What cannot be finished here is the batch-wide 1 / sqrt(mean |y|^2): x = y * that + noise is formed by the consumer -- R0 of
 // the receiver step reads (y, noise, partials) as its virtual input (norm_adam.h NormVirtual), or gen_static_apply_kernel
 // materialises x where a buffer is wanted.
+constexpr int kGenMaxProfiles = 6;
+struct GenProfile {                 // one static fading profile: tap amplitudes, sinc interpolation [n_taps, L]; identity: g = [1]
+    const float* coeff; const float* alpha; int n_taps, L, identity, pad_;
+};
 struct GenStaticArgs {
     int32_t* bits_out; const int* cell_map; const float2* const_tab; float2 pilot; const float* idft;
-    const float* coeff; const float* alpha; int n_taps, L, identity;
+    // frame f runs profile f % n_prof (radio.py:438-452 without Doppler frames; n_prof = 1: one channel for the batch);
+    // tap_stride: taps per frame in the Philox index of the tap draws (channel_taps_kernel's)
+    GenProfile prof[kGenMaxProfiles]; int n_prof, tap_stride;
+    float2* H; int h_rep;           // nullable: fft(g, K) per frame, h_rep copies (channel_taps_kernel's arithmetic)
     const float* snr_db;
     float2* y; float2* noise; double* power_partial; double* noise_partial; float* tx_out;
     int frames, S, K, CP, D, nbits;
@@ -325,10 +332,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float2* sTX = reinterpret_cast<float2*>(gsm + 16 * LDG);      // [2][pad | T | pad]  time-domain frames
     __shared__ float2 gs[kGenFramesPerBlock][64];
     __shared__ float2 tap[kGenFramesPerBlock][16];
+    __shared__ float2 tw[K];                           // (cos, sin) of -2 pi m / K: the frequency response's twiddles
     __shared__ double sh[2][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int f0 = (int)blockIdx.x * kGenFramesPerBlock;
     const int nfr = min(kGenFramesPerBlock, a.frames - f0);
+    // the profiles of the block's two frames (block-uniform; frame 1 of a one-frame block repeats frame 0)
+    const GenProfile P0 = a.prof[f0 % a.n_prof];
+    const GenProfile P1 = a.prof[(f0 + (nfr > 1 ? 1 : 0)) % a.n_prof];
+    const int L0 = P0.identity ? 1 : P0.L, L1 = P1.identity ? 1 : P1.L;
+    if (a.H != nullptr && tid < K) {
+        float sn, cs;
+        sincosf(-6.2831853071795864769f * (float)tid / (float)K, &sn, &cs);
+        tw[tid] = make_float2(cs, sn);
+    }
     static_assert(kGenFramesPerBlock * 2 * kGenFirPad == 256, "one pad cell per thread");
     sTX[(tid >> 7) * TP + ((tid >> 6) & 1) * (kGenFirPad + T) + (tid & 63)] = make_float2(0.f, 0.f);
 
@@ -378,10 +395,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
     // 3 (early). static taps of the block's frames (threads 0..n_taps-1 of waves 0 / 1 draw frame 0 / 1)
-    if (!a.identity && w < nfr && lane < a.n_taps) {
-        const Philox4 p = philox4x32_10((unsigned long long)(f0 + w) * a.n_taps + lane, kStreamTaps, a.offset, a.seed);
+    const GenProfile Pw = w == 0 ? P0 : P1;            // (waves 0 / 1 own the taps of frames 0 / 1)
+    if (w < nfr && !Pw.identity && lane < Pw.n_taps) {
+        const Philox4 p = philox4x32_10((unsigned long long)(f0 + w) * a.tap_stride + lane, kStreamTaps, a.offset, a.seed);
         const float2 z = box_muller(p.v[0], p.v[1]);
-        const float cf = a.coeff[lane] * 0.70710678118654752440f;
+        const float cf = Pw.coeff[lane] * 0.70710678118654752440f;
         tap[w][lane] = make_float2(z.x * cf, z.y * cf);
     }
     // 1. resource grid: label bits (Philox word 0 of the cell), constellation / pilot / guard value
@@ -411,16 +429,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
     __syncthreads();
-    if (!a.identity && w < nfr && lane < a.L) {         // g = taps . alpha (same order as channel_taps_kernel)
-        float2 acc = make_float2(0.f, 0.f);
-        for (int k = 0; k < a.n_taps; ++k) {
-            const float wgt = a.alpha[k * a.L + lane];
-            acc.x += tap[w][k].x * wgt;
-            acc.y += tap[w][k].y * wgt;
+    if (w < kGenFramesPerBlock) {                      // g = taps . alpha (same order as channel_taps_kernel); zeros behind L:
+        float2 acc = make_float2(0.f, 0.f);            // the FIR below runs both frames over the longer of the two responses
+        const int Lw = w == 0 ? L0 : L1;
+        if (w < nfr && lane < Lw) {
+            if (Pw.identity) {
+                acc = make_float2(lane == 0 ? 1.f : 0.f, 0.f);
+            } else {
+                for (int k = 0; k < Pw.n_taps; ++k) {
+                    const float wgt = Pw.alpha[k * Pw.L + lane];
+                    acc.x += tap[w][k].x * wgt;
+                    acc.y += tap[w][k].y * wgt;
+                }
+            }
         }
         gs[w][lane] = acc;
-    } else if (a.identity && w < nfr && lane < a.L) {
-        gs[w][lane] = make_float2(lane == 0 ? 1.f : 0.f, 0.f);
     }
     // 2. tx[row][n] = sum_k grid[row][k] idft[k][n]
     {
@@ -462,16 +485,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             a.tx_out[(size_t)f0 * 2 * T + i] = reinterpret_cast<const float*>(sTX)[fr * 2 * TP + 2 * kGenFirPad + (i - fr * 2 * T)];
         }
     // 4. 'same' FIR (the loop of fir_same_kernel) and its power
-    const int off = (a.L - 1) / 2;
+    // frequency response of the block's frames (channel_taps_kernel's sum, its twiddles from the table: same arguments, same bits)
+    if (a.H != nullptr) {
+        for (int idx = tid; idx < nfr * K; idx += 256) {
+            const int fr = idx / K, f = idx - fr * K, Lf = fr == 0 ? L0 : L1;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int l = 0; l < Lf; ++l) {
+                const float2 t2 = tw[(f * l) % K], gl = gs[fr][l];
+                acc.x += gl.x * t2.x - gl.y * t2.y;
+                acc.y += gl.x * t2.y + gl.y * t2.x;
+            }
+            for (int r = 0; r < a.h_rep; ++r) a.H[((size_t)(f0 + fr) * a.h_rep + r) * K + f] = acc;
+        }
+    }
+    const int off0 = (L0 - 1) / 2, off1 = (L1 - 1) / 2, Lmax = max(L0, nfr > 1 ? L1 : 0);
     double pw = 0.0;
     {
         float2 yv[NSMP];
 #pragma unroll
         for (int q = 0; q < NSMP; ++q) {
             const int i = min(tid + 256 * q, nfr * T - 1), fr = i / T, t = i - fr * T;
-            const float2* xf = sTX + fr * TP + kGenFirPad + t + off;
+            const float2* xf = sTX + fr * TP + kGenFirPad + t + (fr == 0 ? off0 : off1);
             float2 acc = make_float2(0.f, 0.f);
-            for (int l = 0; l < ((a.abl & 8) ? 1 : a.L); ++l) {
+            for (int l = 0; l < ((a.abl & 8) ? 1 : Lmax); ++l) {
                 const float2 v = xf[-l], gl = gs[fr][l];
                 acc.x += gl.x * v.x - gl.y * v.y;
                 acc.y += gl.x * v.y + gl.y * v.x;

@@ -1243,9 +1243,20 @@ static bool gen_static_ok(const dccn_gen_static* g) {
     if (!g || !g->bits_out || !g->cell_map || !g->const_tab || !g->idft || !g->snr_db || !g->y || !g->noise || !g->power_partial)
         return false;
     if (g->frames <= 0 || g->frames > 65535 || g->S <= 0 || 2 * g->S > 16 || g->K <= 0 || g->CP < 0 || g->D <= 0 || g->nbits < 1 ||
-        g->nbits > 4 || g->L <= 0 || g->L > 64)
+        g->nbits > 4 || (g->n_profiles == 0 && (g->L <= 0 || g->L > 64)))
         return false;
-    if (!g->identity && (!g->coeff || !g->alpha || g->n_taps <= 0 || g->n_taps > 16)) return false;
+    if (g->n_profiles < 0 || g->n_profiles > kGenMaxProfiles || (g->n_profiles > 0 && !g->profiles) || g->tap_stride < 0 ||
+        (g->H_out && g->h_rep <= 0))
+        return false;
+    if (g->n_profiles == 0) {
+        if (!g->identity && (!g->coeff || !g->alpha || g->n_taps <= 0 || g->n_taps > 16)) return false;
+        if (g->tap_stride != 0 && g->tap_stride < g->n_taps) return false;
+    }
+    for (int i = 0; i < g->n_profiles; ++i) {
+        const dccn_gen_profile& q = g->profiles[i];
+        if (q.L <= 0 || q.L > 64) return false;
+        if (!q.identity && (!q.coeff || !q.alpha || q.n_taps <= 0 || q.n_taps > 16 || g->tap_stride < q.n_taps)) return false;
+    }
     // the instantiated shape: the reference's N = 64 frame with the long cyclic prefix, 7 symbols x (64 + 16) samples
     return g->S == 7 && g->K == 64 && g->CP == 16 && aligned16(g->y) && aligned16(g->noise);
 }
@@ -1255,7 +1266,21 @@ static int gen_static_launch(const dccn_gen_static* g, hipStream_t s) {
     GenStaticArgs a;
     a.bits_out = g->bits_out; a.cell_map = g->cell_map; a.const_tab = reinterpret_cast<const float2*>(g->const_tab);
     a.pilot = make_float2(g->pilot_re, g->pilot_im); a.idft = g->idft;
-    a.coeff = g->coeff; a.alpha = g->alpha; a.n_taps = g->n_taps; a.L = g->L; a.identity = g->identity;
+    memset(a.prof, 0, sizeof(a.prof));
+    if (g->n_profiles == 0) {
+        a.prof[0].coeff = g->coeff; a.prof[0].alpha = g->alpha; a.prof[0].n_taps = g->n_taps; a.prof[0].L = g->L;
+        a.prof[0].identity = g->identity;
+        a.n_prof = 1;
+        a.tap_stride = g->tap_stride > 0 ? g->tap_stride : g->n_taps;
+    } else {
+        for (int i = 0; i < g->n_profiles; ++i) {
+            a.prof[i].coeff = g->profiles[i].coeff; a.prof[i].alpha = g->profiles[i].alpha;
+            a.prof[i].n_taps = g->profiles[i].n_taps; a.prof[i].L = g->profiles[i].L; a.prof[i].identity = g->profiles[i].identity;
+        }
+        a.n_prof = g->n_profiles;
+        a.tap_stride = g->tap_stride;
+    }
+    a.H = reinterpret_cast<float2*>(g->H_out); a.h_rep = g->h_rep;
     a.snr_db = g->snr_db; a.y = reinterpret_cast<float2*>(g->y); a.noise = reinterpret_cast<float2*>(g->noise);
     a.power_partial = g->power_partial; a.noise_partial = g->noise_partial; a.tx_out = g->tx_out;
     a.frames = g->frames; a.S = g->S; a.K = g->K; a.CP = g->CP; a.D = g->D; a.nbits = g->nbits;
@@ -2288,7 +2313,7 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
 }
 
 // ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
-static_assert(sizeof(dccn_gen_static) == 168 && sizeof(dccn_rx_buffers) == 208, "ctypes mirrors in dl_ofdm_amd/_lib.py");
+static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208, "ctypes mirrors in dl_ofdm_amd/_lib.py");
 int dccn_gen_static_supported(int S, int K, int CP) {
     return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
 }

@@ -251,7 +251,8 @@ class FusedStaticGen:
 
     def __init__(self, gen: DeviceDataGen, n_frames: int, snr_db, want_noise_power: bool = False):
         if not self.supported(gen):
-            raise _lib.DccnError("FusedStaticGen: static single-profile N = 64 channels only")
+            raise _lib.DccnError("FusedStaticGen: static N = 64 channels only (one profile, or the frame-interleaved profiles of "
+                                 "mixRayleigh / mixAll without Doppler frames)")
         self.gen, self.n = gen, int(n_frames)
         dev, f32 = gen.device, dict(dtype=torch.float32, device=gen.device)
         self.snr = torch.empty(self.n, **f32)
@@ -267,11 +268,21 @@ class FusedStaticGen:
                                    p(gen.idft), p(gen.coeff), p(gen.alpha), gen.n_taps, gen.L, 1 if gen.identity else 0,
                                    p(self.snr), p(self.y), p(self.noise), p(self.ppart), p(self.npart), None, None,
                                    self.n, gen.S, gen.K, gen.CP, gen.D, gen.nbits, gen.seed, 0)
+        if gen.mixed:
+            # radio.py:438-452: frame f runs profile f % n_profiles; the launch-per-stage path draws 16 tap slots per frame
+            self._profiles = (_lib.GenProfile * len(gen.profiles))(*[
+                _lib.GenProfile(p(pr["coeff"]), p(pr["alpha"]), pr["n_taps"], pr["L"], 1 if pr["identity"] else 0, 0)
+                for pr in gen.profiles])
+            self.desc.n_profiles, self.desc.tap_stride = len(gen.profiles), 16
+            self.desc.profiles = C.addressof(self._profiles)
 
     @staticmethod
     def supported(gen: DeviceDataGen) -> bool:
-        return (not gen.mixed and not gen.doppler and not gen.align_window and
-                bool(gen.lib.dccn_gen_static_supported(gen.S, gen.K, gen.CP)))
+        if gen.doppler or gen.align_window or not bool(gen.lib.dccn_gen_static_supported(gen.S, gen.K, gen.CP)):
+            return False
+        if gen.mixed:                       # static frames only: no (profile, Doppler) pair in any frame plan
+            return (not gen.mix) and len(gen.profiles) <= 6 and all(pr["L"] <= 64 and pr["n_taps"] <= 16 for pr in gen.profiles)
+        return True
 
     def set_snr(self, snr_db):
         if np.isscalar(snr_db):
@@ -280,11 +291,21 @@ class FusedStaticGen:
             self.snr.copy_(torch.as_tensor(np.asarray(snr_db, dtype=np.float32).reshape(-1)) if not isinstance(snr_db, torch.Tensor)
                            else snr_db.reshape(-1).to(torch.float32))
 
-    def arm(self, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None) -> "_lib.GenStatic":
+    def arm(self, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None,
+            out_H: Optional[torch.Tensor] = None, snr: Optional[torch.Tensor] = None) -> "_lib.GenStatic":
         """the descriptor for the NEXT launch: labels go to ``out_bits``, the batch offset is the generator's current one (which
-        is advanced: call once per batch)"""
+        is advanced: call once per batch).  ``out_H`` float32 [n, K, 2] or [n, S, K, 2]: the frequency response per frame (per
+        symbol); ``snr``: a float32 device tensor of n per-frame SNRs to read instead of the generator's own copy."""
         g, d = self.gen, self.desc
         d.bits_out = out_bits.data_ptr()
+        if out_H is not None:
+            per = (self.n, g.S, g.K, 2)
+            if tuple(out_H.shape) not in (per, (self.n, g.K, 2)) or out_H.dtype != torch.float32 or not out_H.is_contiguous():
+                raise ValueError("out_H must be a contiguous float32 tensor of shape %s or %s" % (per, (self.n, g.K, 2)))
+            d.H_out, d.h_rep = out_H.data_ptr(), (g.S if out_H.dim() == 4 else 1)
+        else:
+            d.H_out, d.h_rep = None, 0
+        d.snr_db = self.snr.data_ptr() if snr is None else snr.data_ptr()
         d.offset = g.offset & 0xFFFFFFFF
         d.seed = g.seed
         d.noise_power_out = self.npow[slot & 1].data_ptr() if self.npow is not None else None
@@ -292,9 +313,11 @@ class FusedStaticGen:
         g.offset = (g.offset + 1) & 0xFFFFFFFF
         return d
 
-    def make_batch(self, out_x: torch.Tensor, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None):
-        """generate + materialise: (x, bits, noise power or None), two launches (the first batch of a pipelined loop, tests)"""
-        d = self.arm(out_bits, slot, tx_out)
+    def make_batch(self, out_x: torch.Tensor, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None,
+                   out_H: Optional[torch.Tensor] = None, snr: Optional[torch.Tensor] = None):
+        """generate + materialise: (x, bits, noise power or None), two launches (the first batch of a pipelined loop, the
+        equaliser's epoch loop, tests)"""
+        d = self.arm(out_bits, slot, tx_out, out_H, snr)
         st = self.gen._stream()
         check(self.gen.lib.dccn_gen_static_frames(C.byref(d), st), "dccn_gen_static_frames")
         npw = self.npow[slot & 1] if self.npow is not None else None

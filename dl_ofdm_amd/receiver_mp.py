@@ -76,6 +76,8 @@ class Flags:
     align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
     pipeline_norm: Optional[bool] = None  # device_data: step i normalises batch i+1 on its optimizer launch (None: when the library can)
     overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
+    fused_generator: bool = True     # device_data, static channels: one generator launch per batch (datagen.FusedStaticGen; same
+                                     # draws, transmitted frames equal to rounding) instead of the launch-per-stage chain
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
 
 
@@ -303,6 +305,15 @@ class DeviceEpochLoop:
         self.acc = torch.zeros(5, dtype=torch.float32, device=dev)
         self.snr = torch.zeros(self.steps, B, dtype=torch.float32, device=dev)
         self.snr_rows = [self.snr[i] for i in range(self.steps)]
+        # static channels (one profile, or mixRayleigh's frame-interleaved profiles without Doppler frames): the whole
+        # generator chain of a batch is ONE launch + the launch that forms x (datagen.FusedStaticGen) instead of 5 to 12
+        self.fg = None
+        if getattr(FLAGS, "fused_generator", True):
+            from .datagen import FusedStaticGen
+            if FusedStaticGen.supported(gen):
+                self.fg = FusedStaticGen(gen, B, 0.0, want_noise_power=gen.want_noise_power)
+                if self.fg.npow is not None:
+                    self.npow = [self.fg.npow[k] for k in range(n)]
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
         self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
         self.i = 0
@@ -316,6 +327,9 @@ class DeviceEpochLoop:
 
     def _generate(self, i: int, q: int):
         pl, gen = self.pls[q], self.gen
+        if self.fg is not None:
+            self.fg.make_batch(pl.x, pl.bits, slot=q, out_H=self.H[q], snr=self.snr_rows[i])     # (advances gen.offset)
+            return
         tx, _ = gen.transmit(pl.batch, out_bits=pl.bits)
         gen.channel(tx, self.snr_rows[i], out_x=pl.x, out_H=self.H[q], out_npow=self.npow[q])
         gen.offset += 1

@@ -360,7 +360,22 @@ typedef struct dccn_gen_static {
     int frames, S, K, CP, D, nbits;
     unsigned long long seed;
     unsigned offset;
+    /* Frame-interleaved static profiles ('mixRayleigh' without Doppler frames, dev/py/radio.py:438-452): frame f runs profile
+       f % n_profiles of `profiles` (a HOST array of at most 6, read during the call); n_profiles = 0: the single profile
+       (coeff, alpha, n_taps, L, identity) above.  tap_stride: taps per frame in the Philox index of the tap draws (0 = n_taps;
+       16 reproduces the draws of dccn_channel_groups_awgn). */
+    int n_profiles, tap_stride;
+    const struct dccn_gen_profile* profiles;
+    /* nullable: H [frames * h_rep, K, 2] = fft(g, K) of every frame's impulse response, h_rep copies per frame (the mixed
+       channels report the response per symbol: h_rep = S) -- the values dccn_channel_awgn / _groups_awgn put into `H` */
+    float* H_out;
+    int h_rep;
 } dccn_gen_static;
+typedef struct dccn_gen_profile {
+    const float* coeff;           /* [n_taps] (null when identity) */
+    const float* alpha;           /* [n_taps, L] */
+    int n_taps, L, identity, reserved;
+} dccn_gen_profile;
 int dccn_gen_static_supported(int S, int K, int CP);      /* 1: shapes the fused launch is instantiated for (N = 64) */
 int dccn_gen_static_partials(int frames);
 int dccn_gen_static_frames(const dccn_gen_static* g, dccn_stream_t stream);

@@ -372,6 +372,39 @@ def test_fused_static_generator_matches_the_launch_per_stage_chain(chan, nbits, 
     assert np.abs(x_b.cpu().numpy() - want_x).max() <= 2e-7 * np.abs(want_x).max()
 
 
+@pytest.mark.parametrize("chan,nbits,n", [("mixRayleigh", 2, 73), ("mixRayleigh", 4, 146), ("mixAll", 1, 9), ("EPA", 2, 73)])
+def test_fused_generator_with_interleaved_profiles_and_frequency_response(chan, nbits, n):
+    """The frame-interleaved static profiles of the equaliser's training channel (radio.py:438-452 without Doppler frames: frame f
+    runs profile f % n_profiles -- flat / ETU / EVA / EPA, responses of different lengths side by side in one block) and the
+    frequency response H the equaliser's monitor reads, from the ONE fused launch: against dccn_ofdm_tx_frames +
+    dccn_channel_groups_awgn (or dccn_channel_awgn) at the same (seed, offset) with per-frame SNRs taken from a caller's tensor.
+    Same bits for the labels and for H (same tap draws, same sums, same twiddle arguments); frames to rounding."""
+    from dl_ofdm_amd import ofdm
+    from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
+    F = flags(nbits=nbits, channel=chan)
+    o = ofdm.ofdm_tx(F)
+    snr = torch.linspace(-3.0, 27.0, n, device="cuda")
+    ga, gb = DeviceDataGen(F, o, seed=21), DeviceDataGen(F, o, seed=21)
+    ga.offset = gb.offset = 6
+    assert FusedStaticGen.supported(gb) and gb.mixed == chan.startswith("mix")
+    tx_a, bits_a = ga.transmit(n)
+    x_a, npow_a, H_a = ga.channel(tx_a, snr, want_H=True)
+    fg = FusedStaticGen(gb, n, 0.0, want_noise_power=True)
+    hshape = (n, gb.S, gb.K, 2) if gb.mixed else (n, gb.K, 2)
+    x_b, bits_b, tx_b = torch.empty_like(x_a), torch.empty_like(bits_a), torch.empty_like(tx_a)
+    H_b = torch.full(hshape, float("nan"), device="cuda")
+    _, _, npow_b = fg.make_batch(x_b, bits_b, slot=1, tx_out=tx_b, out_H=H_b, snr=snr)
+    torch.cuda.synchronize()
+    assert gb.offset == 7 and torch.equal(bits_a, bits_b)
+    assert torch.equal(torch.view_as_real(H_a).reshape(hshape), H_b)
+    assert float((tx_a - tx_b).abs().max()) <= 2e-6 * float(tx_a.abs().max())
+    assert float((x_a - x_b).abs().max()) <= 1e-5 * float(x_a.abs().max())
+    assert abs(float(npow_a) - float(npow_b)) <= 1e-6 * float(npow_a)
+    if gb.mixed:                             # neighbouring frames really run different channels
+        Hc = torch.view_as_complex(H_b)[:, 0]
+        assert float((Hc[0].abs() - Hc[1].abs()).abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("frames,nbits", [(1170, 2), (73, 4)])
 def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frames, nbits):
     """RxEngine.train_step_generated (ONE C call per batch: generator launch + the four step launches, R0 reading (y, noise,

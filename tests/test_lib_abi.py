@@ -41,7 +41,8 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.RxShape) == 24
     # 18 pointers/sizes + x_next + x_prenormalised (padded) + x_norm_next + (norm_slot, keep_dense_grad) + reg_uniform_dense (padded)
     assert C.sizeof(_lib.RxBuffers) == 26 * 8          # ... + x_next_ready + gen_next + prefetch_fwd (padded)
-    assert C.sizeof(_lib.GenStatic) == 168             # (static_assert'ed against the C struct in csrc/dccn_abi.hip)
+    assert C.sizeof(_lib.GenStatic) == 200             # (static_assert'ed against the C struct in csrc/dccn_abi.hip)
+    assert C.sizeof(_lib.GenProfile) == 32
 
 
 

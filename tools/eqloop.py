@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--channel", default="EPA")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--out", default="")
+    ap.add_argument("--fused", type=int, default=1, help="0: the launch-per-stage generator chain in the loop variants")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -31,6 +32,7 @@ def main():
     F = M.Flags(nbits=args.nbits, channel=args.channel, nfilter=64, device_data=True, seed=1) if hasattr(M, "Flags") else None
     if F is None:
         F = M.parse_flags(["--nbits=%d" % args.nbits, "--channel=%s" % args.channel, "--device_data=True"])
+    F.fused_generator = bool(args.fused)
     o = ofdm.ofdm_tx(F)
     rx_params = glorot_init(R.rx_dims(F, o), 1)
     tr = EqualizerTrainer(F, o, rx_params, device="cuda", seed=1)
