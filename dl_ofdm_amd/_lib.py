@@ -85,7 +85,7 @@ class EqBuffers(C.Structure):
                 ("rx_params", c_void_p), ("out_eq", c_void_p), ("chest", c_void_p), ("snr_db", c_void_p),
                 ("pilot_carriers", c_void_p), ("prob", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("reg_uniform", c_int), ("rx_folded", c_void_p),
-                ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int)]
+                ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int), ("x_next_virtual", c_void_p)]
 
 
 class ChannelGroup(C.Structure):

@@ -47,6 +47,7 @@ struct EqOptArgs : EqOptPtrs {
     // EQJ_NORM_NEXT: `input:0` of the NEXT batch (dccn_eq_buffers.x_next), norm_adam.h norm_fused_body
     const float* nx; float* ny; double* npower;
     int nbatch, ncols;
+    NormVirtual nv;               // nx as (y, noise, power partials) of the fused generator (dccn_eq_buffers.x_next_virtual)
 };
 
 struct AdamCoef {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dc
     const int bx = (int)blockIdx.x - J.block0;
     if (J.kind == EQJ_NORM_NEXT) {
         norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, 1e-9f, 8.0f, a.npower, nullptr, nullptr, nullptr,
-                                                     hp, bx, J.blocks);
+                                                     hp, bx, J.blocks, a.nv);
         return;
     }
     if (J.kind == EQJ_TAIL_FINALIZE) {
@@ -368,9 +369,10 @@ struct EqOptBuilder {
         }
     }
     // (first job of the table: its blocks are dispatched first -- a latency chain, not a stream)
-    void norm_next(const float* x, float* y, int batch, int cols, double* power_partial, int nblocks) {
+    void norm_next(const float* x, float* y, int batch, int cols, double* power_partial, int nblocks,
+                   const NormVirtual nv = norm_virtual_none()) {
         EqOptJob* J = add(EQJ_NORM_NEXT, nblocks);
-        if (J) { a.nx = x; a.ny = y; a.nbatch = batch; a.ncols = cols; a.npower = power_partial; }
+        if (J) { a.nx = x; a.ny = y; a.nbatch = batch; a.ncols = cols; a.npower = power_partial; a.nv = nv; }
     }
     void tail_finalize(const TailFinalizeArgs& fin) {
         EqOptJob* J = add(EQJ_TAIL_FINALIZE, tail_finalize_blocks(fin.P));

@@ -476,12 +476,27 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     ob.a.param = b->eq_params; ob.a.grad = G; ob.a.m = b->adam_m; ob.a.v = b->adam_v; ob.a.reg_coef = b->reg_coef;
     ob.a.state = b->adam;
     const bool uni = b->reg_uniform != 0 && b->reg_coef != nullptr;
-    if (rides && b->x_next != nullptr && norm_fused_ok(b->x_next, w.x_norm, B, ncols)) {
+    const dccn_gen_static* gv = b->x_next_virtual;
+    if (gv != nullptr && (!gv->y || !gv->noise || !gv->power_partial || gv->frames != B ||
+                          2 * (gv->K + gv->CP) * gv->S != ncols))
+        return DCCN_ERR_INVALID_ARG;
+    const float* rin = gv ? gv->y : b->x_next;
+    if (rides && rin != nullptr && norm_fused_ok(rin, w.x_norm, B, ncols)) {
         // `input:0` of the next batch: x_norm is read by the layer norm only, long before this launch
         PowerPartials pn;
-        norm_power_partials(B, ncols, w.ws_norm, w.n_norm, b->x_next, w.x_norm, &pn, nslot ^ 1);
-        ob.norm_next(b->x_next, w.x_norm, B, ncols, b->tx_power != nullptr ? const_cast<double*>(pn.partial) : nullptr,
-                     norm_fused_blocks(ncols));
+        norm_power_partials(B, ncols, w.ws_norm, w.n_norm, rin, w.x_norm, &pn, nslot ^ 1);
+        NormVirtual nv = norm_virtual_none();
+        if (gv) {                                       // (y, noise, partials) of the fused generator as the input: norm_adam.h
+            nv.y = gv->y; nv.noise = gv->noise; nv.ppart = gv->power_partial;
+            nv.npart = ceil_div(gv->frames, kGenFramesPerBlock);
+            nv.total = (double)gv->frames * (double)(gv->S * (gv->K + gv->CP));
+            nv.npart_noise = gv->noise_partial; nv.n_noise = nv.npart;
+            nv.npow_out = gv->noise_partial ? gv->noise_power_out : nullptr;
+        }
+        ob.norm_next(rin, w.x_norm, B, ncols, b->tx_power != nullptr ? const_cast<double*>(pn.partial) : nullptr,
+                     norm_fused_blocks(ncols), nv);
+    } else if (gv != nullptr) {
+        return DCCN_ERR_INVALID_ARG;                    // nothing else would form that batch: ask dccn_eq_norm_rides first
     }
     eq_opt_dense(ob, d, 0, ds0, K2, uni);
     if (fconv.slabs) ob.cconv_fold(d.o[2], d.o[3], fconv.slabs, fconv.colsum, fconv.splits, fconv.slab, K, K);

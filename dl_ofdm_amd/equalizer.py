@@ -67,24 +67,30 @@ class _FusedPlan:
         self._partner = None
         self.graphs: Dict[object, C.c_void_p] = {}
 
-    def _buffers(self, x_next=None, pre: int = 0, slot: int = 0) -> EqBuffers:
+    def _buffers(self, x_next=None, pre: int = 0, slot: int = 0, virt: int = 0) -> EqBuffers:
         tr = self.tr
         p = lambda t: t.data_ptr()          # noqa: E731
         return EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
                          p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
                          p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
                          p(self.ws), self.nws, 1, p(tr.rx_folded(self.shape)),        # reg_uniform: _flatten() fills one value per dense tensor
-                         None if x_next is None else p(x_next), int(pre), int(slot))
+                         None if x_next is None else p(x_next), int(pre), int(slot), (virt or None) if x_next is not None else None)
 
-    def pipe_with(self, other: "_FusedPlan", slot: int):
+    def pipe_with(self, other: "_FusedPlan", slot: int, virt=None):
         """Training steps of this plan normalise `other`'s input on their optimizer launch (include/dccn.h
-        dccn_eq_buffers.x_next); run(True, pipe=0) starts a chain (own normalisation), pipe=1 continues one."""
+        dccn_eq_buffers.x_next); run(True, pipe=0) starts a chain (own normalisation), pipe=1 continues one.
+        ``virt`` (a ``_lib.GenStatic`` the caller keeps alive): that input is never written -- the launch reads the fused
+        generator's (y, noise, power partials) instead (dccn_eq_buffers.x_next_virtual); the caller issues the generator launch
+        of the batch before the step, and only a chain's FIRST batch has to sit in ``x``."""
         assert other.ws is self.ws
+        self._virt = virt
+        other._x_virtual = virt is not None               # `other.x` is stale for every batch but a chain's first
         for key in [k for k in self.graphs if isinstance(k, tuple)]:      # captured with the previous partner's pointers
             self.tr.lib.dccn_rx_graph_destroy(self.graphs.pop(key))
         # 0 starts a chain, 1 continues it, 2 ends it (consumes the batch normalised ahead, normalises nothing: the last
         # step of an epoch), 3 = a one-step chain is the plain step
-        self.pipe_buffers = {0: self._buffers(other.x, 0, slot), 1: self._buffers(other.x, 1, slot),
+        va = C.addressof(virt) if virt is not None else 0
+        self.pipe_buffers = {0: self._buffers(other.x, 0, slot, va), 1: self._buffers(other.x, 1, slot, va),
                              2: self._buffers(None, 1, slot), 3: self._buffers(None, 0, slot)}
         self._partner = other
 
@@ -105,6 +111,9 @@ class _FusedPlan:
         assert pipe is None or train
         ahead, wskey = self._ahead(), self.ws.data_ptr()
         if pipe in (1, 2) and ahead.get(wskey) is not self:      # an eval / plain run used the workspace in between
+            if getattr(self, "_x_virtual", False):
+                raise _lib.DccnError("the batch normalised ahead was lost and this plan's input was never materialised "
+                                     "(x_next_virtual): start the chain again from a materialised batch (pipe=0)")
             pipe = 0 if pipe == 1 else 3
         bufs = self.buffers if pipe is None else self.pipe_buffers[pipe]
         ahead[wskey] = self._partner if pipe in (0, 1) else None

@@ -76,6 +76,7 @@ class Flags:
     align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
     pipeline_norm: Optional[bool] = None  # device_data: step i normalises batch i+1 on its optimizer launch (None: when the library can)
     overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
+    virtual_next: bool = True        # ... and the pipelined loop never writes x for any batch but an epoch's first (x_next_virtual)
     fused_generator: bool = True     # device_data, static channels: one generator launch per batch (datagen.FusedStaticGen; same
                                      # draws, transmitted frames equal to rounding) instead of the launch-per-stage chain
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
@@ -314,6 +315,18 @@ class DeviceEpochLoop:
                 self.fg = FusedStaticGen(gen, B, 0.0, want_noise_power=gen.want_noise_power)
                 if self.fg.npow is not None:
                     self.npow = [self.fg.npow[k] for k in range(n)]
+        # ... and in the pipelined loop the second of those launches goes too: the optimizer launch of step i reads batch i + 1
+        # as (y, noise, power partials) -- dccn_eq_buffers.x_next_virtual; only an epoch's first batch is materialised
+        self.virt = None
+        if self.fg is not None and self.pipeline and getattr(FLAGS, "virtual_next", True):
+            from . import _lib
+            self.virt = []
+            for q in range(2):                                       # plan q normalises plan q ^ 1's batch (monitor slot q ^ 1)
+                d = _lib.GenStatic.from_buffer_copy(self.fg.desc)
+                d.noise_power_out = self.fg.npow[q ^ 1].data_ptr() if self.fg.npow is not None else None
+                self.virt.append(d)
+            self.pls[0].pipe_with(self.pls[1], 0, virt=self.virt[0])
+            self.pls[1].pipe_with(self.pls[0], 1, virt=self.virt[1])
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
         self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
         self.i = 0
@@ -326,9 +339,14 @@ class DeviceEpochLoop:
         self.fresh_epoch = True
 
     def _generate(self, i: int, q: int):
+        from ._lib import check
         pl, gen = self.pls[q], self.gen
         if self.fg is not None:
-            self.fg.make_batch(pl.x, pl.bits, slot=q, out_H=self.H[q], snr=self.snr_rows[i])     # (advances gen.offset)
+            if self.virt is not None and i > 0:                      # frames only: the running step forms x in registers
+                d = self.fg.arm(pl.bits, q, None, self.H[q], self.snr_rows[i])
+                check(gen.lib.dccn_gen_static_frames(self.C.byref(d), gen._stream()), "dccn_gen_static_frames")
+            else:
+                self.fg.make_batch(pl.x, pl.bits, slot=q, out_H=self.H[q], snr=self.snr_rows[i])     # (advances gen.offset)
             return
         tx, _ = gen.transmit(pl.batch, out_bits=pl.bits)
         gen.channel(tx, self.snr_rows[i], out_x=pl.x, out_H=self.H[q], out_npow=self.npow[q])

@@ -626,6 +626,13 @@ typedef struct dccn_eq_buffers {
     const float* x_next;
     int x_prenormalised;
     int norm_slot;
+    /* Round 5: the next batch as the fused generator left it (host pointer to its descriptor, read during the call / at graph
+       capture): instead of x_next the optimizer launch normalises y / sqrt(mean |y|^2) + noise formed in registers from
+       (y, noise, power_partial) -- the values dccn_gen_static_apply would write, so results keep their bits -- and, when
+       noise_partial and noise_power_out are set, finishes the noise-power monitor.  The CALLER issues dccn_gen_static_frames
+       for that batch on the same stream before this call (the step itself launches nothing for it: the call stays
+       graph-capturable, the generator's per-batch arguments stay outside the graph).  Honoured like x_next. */
+    const dccn_gen_static* x_next_virtual;
 } dccn_eq_buffers;
 /* 1: dccn_eq_train_step honours dccn_eq_buffers.x_next for this shape */
 int dccn_eq_norm_rides(const dccn_eq_shape* shape);
