@@ -75,7 +75,8 @@ enum TuneKey : int {
                                 //    2: ... with non-temporal loads and stores (it must not displace the GEMM's operand panels)
     TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
     TUNE_FWD_PREFETCH_BIG = 26, // 1: dccn_rx_prefetch_pays answers 1 for the shapes whose dense update runs on the second stream (off: no gain measured)
-    TUNE_COUNT = 27
+    TUNE_DENSE_RAGGED = 27,     // 1: large layers' fused dense + tail: a short last row tile (<= 32 rows) runs 32x64 blocks in the same grid
+    TUNE_COUNT = 28
 };
 // (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
 struct TuneTable {
@@ -114,7 +115,7 @@ struct TuneTable {
 //           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
 //   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
 //           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
-static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}}};
+static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}, {1}}};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -1111,6 +1112,37 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     const bool few = g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && nbits <= 2 && M <= 96 && fewrow_ng_c(p, false) >= 10 &&
                      few_tiles <= kTailBlocksMax && few_tiles <= dense_tail_max_blocks(M, N);
     int st;
+    // 80x64 tiles over a row count that leaves <= 32 rows for the last tile row (C4: 585 = 7 x 80 + 25): that row as 32x64 blocks
+    const int rag = (variant == 13 && nbits <= 2 && g_tune[TUNE_DENSE_RAGGED] && M > 80) ? M % 80 : 0;
+    if (rag > 0 && rag <= 32) {
+        const int M1 = M - rag;
+        GemmParams p1 = p, p2 = p;
+        TailEpiParams t1 = tp, t2 = tp;
+        p1.M = M1;
+        p2.M = rag; p2.A = p.A + (size_t)M1 * p.lda; p2.C = p.C ? p.C + (size_t)M1 * p.ldc : nullptr;
+        t2.bits = tp.bits + (size_t)M1 * (N / 2) * nbits;
+        t2.prob = tp.prob ? tp.prob + (size_t)M1 * (N / 2) * nbits * 2 : nullptr;
+        t2.dz = tp.dz ? tp.dz + (size_t)M1 * N : nullptr;
+        const size_t sm = tune_smem_min();
+        if (nbits == 1) st = bwd ? launch_dense_tail16_ragged<5, 2, 64, 1, true, 2>(p1, t1, p2, t2, s, sm) : launch_dense_tail16_ragged<5, 2, 64, 1, false, 2>(p1, t1, p2, t2, s, sm);
+        else st = bwd ? launch_dense_tail16_ragged<5, 2, 64, 2, true, 2>(p1, t1, p2, t2, s, sm) : launch_dense_tail16_ragged<5, 2, 64, 2, false, 2>(p1, t1, p2, t2, s, sm);
+        DCCN_TRY(st);
+        const int nrag = (M1 / 80) * ceil_div(N, 64) + ceil_div(N, 64);
+        const int P = bwd ? tail_param_count(nbits) : 0;
+        const bool pw = pp != nullptr && power_out != nullptr;
+        TailFinalizeArgs fa;
+        fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nrag; fa.P = P; fa.count = cells * nbits;
+        fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
+        fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
+        fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
+        if (defer) {
+            *defer = fa;
+            return DCCN_OK;
+        }
+        hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(P)), dim3(256), 0, s, fa);
+        DCCN_LAUNCH_CHECK();
+        return DCCN_OK;
+    }
     if (few && nbits == 1) st = bwd ? launch_fewrow_tail<1, true>(p, tp, s) : launch_fewrow_tail<1, false>(p, tp, s);
     else if (few && nbits == 2) st = bwd ? launch_fewrow_tail<2, true>(p, tp, s) : launch_fewrow_tail<2, false>(p, tp, s);
     else if (nbits == 1) st = bwd ? dense_tail_launch<1, true>(variant, p, tp, s) : dense_tail_launch<1, false>(variant, p, tp, s);

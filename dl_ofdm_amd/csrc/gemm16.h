@@ -795,6 +795,37 @@ static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hip
     return DCCN_OK;
 }
 
+// Large layers whose row count leaves a short last row tile (N = 1024: 585 frames = 7 x 80 + 25): the last tile row runs
+// TM2 x 16 rows instead of a mostly empty TM1 x 16 one -- both tile shapes in ONE grid, the long blocks first (they are the
+// critical path; the short ones fill the second round).  p1 / t1: rows [0, M1); p2 / t2: the rest, pointers already offset.
+template <int TM1, int TM2, int BK, int NB, bool BWD, int PD>
+__global__ __launch_bounds__(256) void dense_tail_ragged_kernel(const GemmParams p1, const TailEpiParams t1, const GemmParams p2,
+                                                                const TailEpiParams t2, const int T1, const int T2) {
+    const int b = (int)blockIdx.x;
+    if (b < T1) gemm16_block<OP_KCONTIG, OP_ICONTIG, 1, 4, TM1, 1, BK, 1, 0, EPI_TAIL, NB, BWD, PD>(p1, t1, b, T1, 0, b);
+    else gemm16_block<OP_KCONTIG, OP_ICONTIG, 1, 4, TM2, 1, BK, 1, 0, EPI_TAIL, NB, BWD, PD>(p2, t2, b - T1, T2, 0, b);
+}
+template <int TM, int BK, int NB, bool BWD>
+constexpr size_t dense_tail16_smem() {
+    using CF = Cfg16<OP_KCONTIG, OP_ICONTIG, 1, 4, TM, 1, BK, 1>;
+    constexpr int wfl = NB >= 3 ? CF::BM * (CF::BN + 2) + CF::BM * (CF::BN / 2) + ((tail_param_count(NB) + 3) & ~3) : 0;
+    constexpr int rfl = (NB == 4 && BWD) ? tail_quad4_lds_floats(CF::NT) : tail_reduce_lds_floats<NB, BWD>(CF::NT);
+    return CF::smem_bytes(wfl + rfl);
+}
+template <int TM1, int TM2, int BK, int NB, bool BWD, int PD>
+static int launch_dense_tail16_ragged(const GemmParams& p1, const TailEpiParams& t1, const GemmParams& p2, const TailEpiParams& t2,
+                                      hipStream_t s, size_t smem_min = 0) {
+    auto kern = dense_tail_ragged_kernel<TM1, TM2, BK, NB, BWD, PD>;
+    size_t smem = dense_tail16_smem<TM1, BK, NB, BWD>();
+    if (dense_tail16_smem<TM2, BK, NB, BWD>() > smem) smem = dense_tail16_smem<TM2, BK, NB, BWD>();
+    if (smem < smem_min) smem = smem_min;
+    DCCN_TRY(set_smem_attr(kern, smem));
+    const int T1 = ceil_div(p1.N, 64) * ceil_div(p1.M, 16 * TM1), T2 = ceil_div(p2.N, 64) * ceil_div(p2.M, 16 * TM2);
+    hipLaunchKernelGGL(kern, dim3(T1 + T2), dim3(256), smem, s, p1, t1, p2, t2, T1, T2);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
+
 template <int WGM, int WGN, int TM, int TN, int BK, int WWGM, int WWGN, int WTM, int WTN, int ACTX = 1>
 static int launch_dense_bwd16(const GemmParams& px, const GemmParams& pw, int splits_w, hipStream_t s,
                               size_t smem_min = 0) {

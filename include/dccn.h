@@ -274,6 +274,7 @@ int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_strea
  * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream next to the C-Conv weight-gradient launch
  * (0 off, 1 on, 2 = default: with non-temporal loads and stores), 26 (default 0: measured 4725 vs 4724 us per N = 1024 step) dccn_rx_prefetch_pays answers 1 for those
  * layers (the pipelined caller then moves the next batch's C-Conv forward next to that update: dccn_rx_buffers.prefetch_fwd).
+ * 27 (default 1) large layers' fused dense + tail: a short last row tile (<= 32 of 80 rows) runs as 32x64 blocks in the same grid.
  * Key 2: 7 (default) = the staged whole-k C-Conv forward, 8-11 its other store slots / 32x128
  * tiles; key 14: presets 1-24, default 14 = ranges of {9,5,2,2,1}/19 of the batch.
  * Set them before workspaces are sized. */
