@@ -103,6 +103,24 @@ def _cards(pci=None):
     return devs
 
 
+def copy_bandwidth_tbs(dev):
+    import torch
+    try:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return round(10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 3)
+    except Exception:                                    # (diagnostic only)
+        return None
+
+
 def gpu_clock_state(pci=None):
     """sclk / mclk / fclk / socclk DPM state, performance level, power cap and draw of every amdgpu card the box exposes
     (sysfs, read-only; the container sees the host's /sys/class/drm).  `step.boundaries[*].sclk_mhz` is the clock the CUs
@@ -626,7 +644,10 @@ def main():
             result["cpu_baseline"] = cpu_baseline(c)
         cu, wf, hbm, arch = _lib.device_info()
         result["device"] = {"arch": arch, "cus": cu, "clocks_before_timed_regions": clocks_before,
-                            "clocks_after_timed_regions": clocks_after, "box": box_fingerprint(pci)}
+                            "clocks_after_timed_regions": clocks_after, "box": box_fingerprint(pci),
+                            # the box's HBM speed as a plain device-to-device copy sees it (1 GiB, read + write): one box of the
+                            # round's pool ran the same build 11 % slower per step with its HBM-bound launches 50 % longer
+                            "copy_1GiB_TBps": copy_bandwidth_tbs(dev)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
