@@ -405,8 +405,8 @@ def test_fused_generator_with_interleaved_profiles_and_frequency_response(chan, 
         assert float((Hc[0].abs() - Hc[1].abs()).abs().max()) > 1e-3
 
 
-@pytest.mark.parametrize("frames,nbits", [(1170, 2), (73, 4)])
-def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frames, nbits):
+@pytest.mark.parametrize("frames,nbits,chan", [(1170, 2, "EPA"), (73, 4, "EPA"), (300, 2, "mixRayleigh")])
+def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frames, nbits, chan):
     """RxEngine.train_step_generated (ONE C call per batch: generator launch + the four step launches, R0 reading (y, noise,
     power partials) as its virtual input) against the same generator materialising x for train_step_pipelined: the same
     batches in the same order => the same bits in every parameter, Adam slot and metric after six steps -- and the
@@ -414,7 +414,7 @@ def test_generated_steps_equal_pipelined_steps_on_the_materialised_batches(frame
     from dl_ofdm_amd import ofdm, receiver as R
     from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
     from dl_ofdm_amd.engine import RxEngine
-    F = flags(nbits=nbits, channel="EPA")
+    F = flags(nbits=nbits, channel=chan)
     o = ofdm.ofdm_tx(F)
     dims = R.rx_dims(F, o)
     engs, gens, fgs = [], [], []
