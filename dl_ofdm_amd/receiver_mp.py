@@ -76,6 +76,7 @@ class Flags:
     align_window: bool = False      # extension: delay generated frames by the channel's centre-tap advance (datagen.py)
     pipeline_norm: Optional[bool] = None  # device_data: step i normalises batch i+1 on its optimizer launch (None: when the library can)
     overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
+    step_graph: bool = False         # device_data: replay the equaliser step as a hipGraph instead of 21 eager launches (same results)
     virtual_next: bool = True        # ... and the pipelined loop never writes x for any batch but an epoch's first (x_next_virtual)
     fused_generator: bool = True     # device_data, static channels: one generator launch per batch (datagen.FusedStaticGen; same
                                      # draws, transmitted frames equal to rounding) instead of the launch-per-stage chain
@@ -330,6 +331,9 @@ class DeviceEpochLoop:
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
         self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
         self.i = 0
+        # the step as 21 eager launches per call (default) or as a hipGraph replay: 0.188 vs 0.196 ms per loop step (tools/eqloop.py
+        # --graph 0 / 1; host issue 0.156 vs 0.125 ms) -- the replay costs the GPU 3-7 us per step, the eager calls cost the host 30
+        self.step_graph = bool(getattr(FLAGS, "step_graph", False))
         if self.overlap:
             self.side = torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event() for _ in range(2)]      # set q holds a finished batch
@@ -402,7 +406,7 @@ class DeviceEpochLoop:
                 self._produce(i + 1, q ^ 1)                          # the next batch, while this step runs
             self.torch.cuda.current_stream(tr.device).wait_event(self.ready[q])
         pl = self.pls[q]
-        pl.run(True, pipe=pipe)
+        pl.run(True, pipe=pipe, graph=self.step_graph)
         npow = self.npow[q] if self.gen.want_noise_power else None
         check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H[q].data_ptr(), self.per_symbol, pl.batch,
                                                 self.F.nsymbol, self.o.K, pl.metrics_buf.data_ptr(), pl.tx_power.data_ptr(),

@@ -730,20 +730,21 @@ def test_virtual_next_batch_trains_the_same_equaliser_on_interleaved_profiles():
     frame by frame): the pipelined loop whose optimizer launch reads the next batch as the fused generator's (y, noise, power
     partials) -- x never written but for an epoch's first batch, the noise-power monitor finished by that launch -- against the
     same loop materialising every batch (dccn_gen_static_apply): identical history (losses, BER, tx / noise power, channel
-    RMS) and parameters over 3 epochs of 28 steps, through hipGraph replays of the step."""
+    RMS) and parameters over 3 epochs of 28 steps -- with the step issued eagerly (the loop's default) and as hipGraph replays."""
     from dl_ofdm_amd import receiver as R, receiver_mp as H
     from dl_ofdm_amd.engine import glorot_init
     from dl_ofdm_amd import ofdm
     out = []
-    for virt in (False, True):
+    for virt, graph in ((False, False), (True, False), (True, True)):
         hf = H.Flags(nbits=2, nfilter=64, channel="mixRayleigh", msg_length=7 * 2048, batch_size=512, max_epoch_num=3,
-                     early_stop=100, token="VN", save_dir="/tmp/_eq_virt_%d/" % virt, seed=8, eval_frames=512,
-                     device_data=True, virtual_next=virt)
+                     early_stop=100, token="VN", save_dir="/tmp/_eq_virt_%d%d/" % (virt, graph), seed=8, eval_frames=512,
+                     device_data=True, virtual_next=virt, step_graph=graph)
         o = ofdm.ofdm_tx(hf)
         res = H.train(hf, verbose=False, run_test=False, rx_params=glorot_init(R.rx_dims(hf, o), 1))
         out.append((res["history"], res["trainer"].params.detach().clone()))
-    assert out[0][0] == out[1][0]
-    assert torch.equal(out[0][1], out[1][1])
+    for o in out[1:]:
+        assert out[0][0] == o[0]
+        assert torch.equal(out[0][1], o[1])
     assert all(np.isfinite(h["train_loss"]) and 0.0 < h["train_ber"] < 0.6 for h in out[0][0])
 
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--out", default="")
     ap.add_argument("--fused", type=int, default=1, help="0: the launch-per-stage generator chain in the loop variants")
+    ap.add_argument("--graph", type=int, default=0, help="1: the loop variants replay the step's hipGraph instead of issuing it eagerly")
     ap.add_argument("--virtual", type=int, default=1, help="0: the pipelined loop materialises every batch (no x_next_virtual)")
     args = ap.parse_args()
     import numpy as np
@@ -35,6 +36,7 @@ def main():
         F = M.parse_flags(["--nbits=%d" % args.nbits, "--channel=%s" % args.channel, "--device_data=True"])
     F.fused_generator = bool(args.fused)
     F.virtual_next = bool(args.virtual)
+    F.step_graph = bool(args.graph)
     o = ofdm.ofdm_tx(F)
     rx_params = glorot_init(R.rx_dims(F, o), 1)
     tr = EqualizerTrainer(F, o, rx_params, device="cuda", seed=1)
