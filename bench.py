@@ -331,6 +331,8 @@ def measure_sweep(dev, rank, world, reps=2, frames=None):
             "points_per_rank": [len(sweep.shard(pts, r, world)) for r in range(world)], "scaling": "strong",
             "seconds": best, "points_per_s": len(pts) / best, "symbols_per_s": nsym / best,
             "bits_counted": int(t[:, 5].sum()), "ber_first_last": [float(ber[0]), float(ber[-1])],
+            "receiver": "seed-1 initialisation, NOT trained: this object times the sharded evaluation path; its BER (~0.5) says "
+                        "nothing about the receiver (trained curves: profiles/*_config5/config5_ber.csv)",
             "collective": "one all-reduce of the [40, 6] float64 table" if world > 1 else "none (1 rank)"}
 
 
@@ -352,7 +354,7 @@ def measure_e2e(dev, c, steps=200, warmup=30, channel="EPA", snr_db=10.0):
     gen.want_noise_power = False
 
     from dl_ofdm_amd.datagen import FusedStaticGen, SideStreamFeeder
-    fused = FusedStaticGen.supported(gen) and not eng._ride
+    fused = FusedStaticGen.supported(gen, eng)
     count = [0]
     if fused:
         # round 5: ONE C call per batch -- the fused generator launch of the next batch + the four launches of the step, whose
@@ -403,6 +405,44 @@ def measure_e2e(dev, c, steps=200, warmup=30, channel="EPA", snr_db=10.0):
             "ce_mean_last": m["ce_mean"], "ber_last": m["berlin"]}
 
 
+def launch_ranks(n: int) -> int:
+    """Re-run this command line as `n` ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port); the
+    children see WORLD_SIZE and take the normal path.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """`with Watchdog(seconds, what):` -- if the block has not finished in time, print what hung and end the process
+    (rc 3): a collective that never completes cannot be interrupted from Python any other way."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def _fire(self):
+        sys.stderr.write("bench.py: %s did not complete within %.0f s -- giving up\n" % (self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -429,6 +469,11 @@ def main():
     ap.add_argument("--sweep-frames", type=int, default=0, help="frames per sweep point (default 20 000, the reference's)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as the
+        # driver's torch.distributed.run command line would (dev/py/locals.py:28-38: one process per job)
+        raise SystemExit(launch_ranks(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -440,8 +485,6 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     # DCCN_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices); the real runs use nccl (= RCCL over xGMI), one rank per GPU
     backend = os.environ.get("DCCN_BENCH_BACKEND", "nccl")
@@ -453,10 +496,15 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # a rendezvous or first collective that never completes (a rank that died, a wedged xGMI link) ends the job with a
+        # message and rc 3 instead of hanging until the caller's limit
+        with Watchdog(float(os.environ.get("DCCN_BENCH_INIT_TIMEOUT", "300")),
+                      "rank %d: init_process_group(%s) / first barrier" % (rank, backend)):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
 
     c = CONFIGS[args.config]
     S, kin = 7, c["nfft"] + c["cp"]

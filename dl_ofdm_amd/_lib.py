@@ -88,6 +88,13 @@ class EqBuffers(C.Structure):
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int), ("x_next_virtual", c_void_p)]
 
 
+class EqMonitor(C.Structure):
+    """dccn_eq_monitor"""
+    _fields_ = [("chest", c_void_p), ("chan", c_void_p), ("chan_per_symbol", c_int), ("B", c_int), ("S", c_int), ("K", c_int),
+                ("metrics", c_void_p), ("tx_power", c_void_p), ("noise_power", c_void_p), ("acc5", c_void_p),
+                ("rms_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 class ChannelGroup(C.Structure):
     """dccn_channel_group"""
     _fields_ = [("frames", c_void_p), ("n_frames", c_int), ("coeff", c_void_p), ("alpha", c_void_p),
@@ -135,6 +142,13 @@ SIGNATURES = {
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
     "dccn_rx_prefetch_pays": (_i, [POINTER(RxShape)]),
+    "dccn_rx_gen_next_supported": (_i, [POINTER(RxShape)]),
+    "dccn_chain_group_max": (_i, []),
+    "dccn_eq_group_supported": (_i, [POINTER(EqShape)]),
+    "dccn_eq_train_step_grouped": (_i, [_i, _vp, _vp, AdamHParams, _vp]),
+    "dccn_gen_static_frames_grouped": (_i, [_i, _vp, _vp]),
+    "dccn_gen_static_apply_grouped": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "dccn_eq_monitor_accumulate_grouped": (_i, [_i, _vp, _vp]),
     "dccn_cconv_patch_bwd_supported": (_i, [_i] * 11),
     "dccn_cconv_patch_bwd_w_workspace_size": (C.c_size_t, [_i] * 7),
     "dccn_cconv_patch_bwd_w": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp, C.c_size_t, _vp]),

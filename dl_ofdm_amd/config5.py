@@ -104,9 +104,16 @@ def _broadcast(t, src: int, group=None):
 
 def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs: int, rx_epoch_scale: float = 1.0,
                  rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
-                 timing: Optional[dict] = None, ckpt_dir: Optional[str] = None):
+                 timing: Optional[dict] = None, ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None):
     """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
     eq_epochs <= 0: the reference driver's cap of 4000 * nbits epochs (run_local_ofdm.py:96; early stopping ends it sooner).
+
+    chain_streams (default: one per chain this rank owns): the rank's chains train NEXT TO each other, each in a host thread
+    of this process issuing to a HIP stream of its own -- the reference driver starts them as OS processes
+    (run_local_ofdm.py:61-118, locals.py:28-38).  A chain is a latency-bound sequence of 73-frame steps that keeps a few
+    percent of an MI355X busy; several hardware queues of ONE process interleave on the chip without the context switches
+    that separate processes pay.  Every chain draws from generators of its own (host RandomState, device Philox streams),
+    so the trained arenas are the bits a serial run (chain_streams=1) produces.
 
     world > 1: each chain is trained by its owner only (job_owners); the owner then broadcasts the two flat arenas
     (receiver 2.3 MB, equaliser 7 MB) and the other ranks build the same trainer around them.  Training is bitwise
@@ -117,6 +124,7 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
     from .equalizer import EqualizerTrainer
     owners = job_owners(nbits_list, world)
     t0, trainers, flags = time.time(), {}, {}
+    mine = []
     for nbits in sorted(owners, reverse=True):
         save = os.path.join(ckpt_dir or out_dir, "ckpt_r%d/" % rank)      # (~90 MB of best-model archives per rank)
         rf = R.Flags(nbits=nbits, nfilter=64, channel="AWGN", SNR=5.0 * nbits,
@@ -125,8 +133,11 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         hf = H.Flags(nbits=nbits, nfilter=64, channel="mixRayleigh", max_epoch_num=eq_epochs if eq_epochs > 0 else 4000 * nbits, early_stop=200,
                      token=rf.token, save_dir=save, device_data=True, seed=10 + nbits, test_frames=frames)
         flags[nbits] = (rf, hf)
-        if owners[nbits] != rank:
-            continue
+        if owners[nbits] == rank:
+            mine.append(nbits)
+
+    def chain(nbits):
+        rf, hf = flags[nbits]
         t1 = time.time()
         res = R.train(rf, device=device, verbose=False, run_test=False)
         t2 = time.time()
@@ -139,8 +150,46 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         if verbose:
             print("rank %d nbits %d: receiver %d epochs %.0f s, equaliser %d epochs %.0f s"
                   % (rank, nbits, len(res["history"]), t2 - t1, len(out["history"]), time.time() - t2), flush=True)
+
+    n_streams = len(mine) if chain_streams is None else max(1, min(int(chain_streams), len(mine)))
+    if n_streams <= 1:
+        for nbits in mine:
+            chain(nbits)
+    else:
+        # longest chain first (`mine` is sorted that way); a worker thread owns one HIP stream and takes the next chain when
+        # its own has finished.  Worker exceptions are re-raised here.
+        import queue
+        import threading
+        todo, errors = queue.Queue(), []
+        for nbits in mine:
+            todo.put(nbits)
+
+        def worker():
+            st = torch.cuda.Stream(device=device)
+            try:
+                with torch.cuda.stream(st):
+                    while True:
+                        try:
+                            nbits = todo.get_nowait()
+                        except queue.Empty:
+                            break
+                        chain(nbits)
+                        st.synchronize()
+            except BaseException as e:                  # noqa: BLE001 -- handed to the caller's thread
+                errors.append(e)
+
+        torch.cuda.synchronize(device)
+        ths = [threading.Thread(target=worker, name="c5-chain-%d" % i) for i in range(n_streams)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize(device)
+        if errors:
+            raise errors[0]
     if timing is not None:
         timing["train_total"] = time.time() - t0
+        timing["chain_streams"] = n_streams
     if world > 1:
         t3 = time.time()
         for nbits in sorted(owners, reverse=True):
@@ -258,7 +307,7 @@ def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: S
 def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frames: int = 1500, rx_epoch_scale: float = 1.0,
         nbits_list: Sequence[int] = (1, 2, 3, 4), channels: Sequence[str] = CHANNELS, snrs: Sequence[int] = SNRS,
         classical_every: int = 3, rank: int = 0, world: int = 1, device="cuda", verbose: bool = True,
-        ckpt_dir: Optional[str] = None):
+        ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None):
     """Train (chains dealt to ranks), sweep (points dealt to ranks), classical curves (units dealt to ranks); rank 0
     writes ``<out_dir>/config5_ber.csv`` and ``config5_timing.json`` (wall time per stage and rank).  Returns
     (points, BER per point)."""
@@ -280,7 +329,7 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
                                 reduce=False)
         timing["classical_early"] = time.time() - tc
     trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
-                            timing=timing, ckpt_dir=ckpt_dir)
+                            timing=timing, ckpt_dir=ckpt_dir, chain_streams=chain_streams)
     t1 = time.time()
     pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world)
     ber, _ = sweep.ber_loss(table)
@@ -294,7 +343,9 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     timing["total"] = time.time() - t0
     # seconds this rank spent neither training, sweeping nor on classical units: waiting for the longest chain (the
     # `broadcast` entry is that wait plus 9 MB per modulation over xGMI) -- the config's scaling cap, stated per rank
-    busy = sum(v for k, v in timing.items() if k.startswith(("train_rx_", "train_eq_"))) + timing["sweep"] + \
+    # (chains training next to each other on streams of their own: their wall time is train_total, not the sum of the chains')
+    busy = (timing["train_total"] if timing.get("chain_streams", 1) > 1 else
+            sum(v for k, v in timing.items() if k.startswith(("train_rx_", "train_eq_")))) + timing["sweep"] + \
         timing["classical"] + timing.get("classical_early", 0.0)
     timing["idle"] = max(0.0, timing["total"] - busy)
     all_t = [timing]

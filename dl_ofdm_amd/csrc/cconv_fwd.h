@@ -39,7 +39,8 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 // BM x BN: the block's output tile, 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4: every x row is read by ONE block --
 // half the HBM-side traffic of the launch -- and the whole [Wa|Wb], 40 KB that live in the L2, by every block)
 template <int KS, int WS, int BM = 64, int BN = 64>
-__global__ __launch_bounds__(kGemmThreads) void cconv_fwd_staged_kernel(const GemmParams p) {
+__global__ __launch_bounds__(kGemmThreads) void cconv_fwd_staged_kernel(const GemmParams p0, const ChainOffs co) {
+    const GemmParams p = p0.at_chain(co.off[blockIdx.z]);           // chain groups (common.h)
     constexpr int K = 32 * KS, LD = K + 4;
     static_assert((BM == 64 && BN == 64) || (BM == 32 && BN == 128), "tile shapes");
     constexpr int NA = BM * 8 / 256;              // float4 pieces of x per thread and stage
@@ -191,11 +192,11 @@ static int launch_cconv_fwd_staged(const GemmParams& p, hipStream_t s) {
     if (p.K == 160) {
         auto kern = cconv_fwd_staged_kernel<5, WS, BM, BN>;
         DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem5));
-        hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem5, s, p);
+        DCCN_LAUNCH_CHAINS_Z(kern, grid, dim3(kGemmThreads), smem5, s, p);
     } else {
         auto kern = cconv_fwd_staged_kernel<4, WS, BM, BN>;
         DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem4));
-        hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem4, s, p);
+        DCCN_LAUNCH_CHAINS_Z(kern, grid, dim3(kGemmThreads), smem4, s, p);
     }
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <map>
 #include <utility>
+#include <type_traits>
 #include "../../include/dccn.h"
 
 namespace dccn {
@@ -111,6 +112,53 @@ struct StepTraceScope {
     void launch(int i) const { tl_stamp = (base && i >= 0 && i < kStampLaunches) ? base + (size_t)i * kStampBlocks * kStampWords : nullptr; }
     void none() const { tl_stamp = nullptr; }
 };
+
+// ---- chain groups: G shape-identical, independent training chains carried by ONE launch sequence ---------------------------
+// (the reference driver starts such chains as OS processes: dev/py/run_local_ofdm.py:61-118, one per modulation / variant.)
+// Every buffer of chain g lies at the SAME offset inside that chain's arena, so a launch planned for chain 0's pointers serves
+// chain g after adding ONE byte offset (arena_g - arena_0) to every pointer argument: the chain index is a grid dimension
+// (blockIdx.z; blockIdx.y where z is taken), the offsets travel by value in the kernel arguments.  A converted kernel takes a
+// trailing `ChainOffs`; outside a grouped call the table is {0} and the grid dimension is 1: same blocks, same arithmetic.
+constexpr int kMaxChains = 8;
+struct ChainOffs {
+    long long off[kMaxChains];          // bytes
+};
+struct ChainCtx {
+    int G;                              // chains carried by the launches issued from this thread right now (1 = no group)
+    ChainOffs co;
+    int nbits[kMaxChains];              // per-chain modulation (the frozen receiver's tail is the only nbits-dependent stage)
+};
+extern thread_local ChainCtx tl_chain;
+struct ChainScope {                     // RAII: a (sub-)group for the launches of a scope
+    ChainCtx saved;
+    explicit ChainScope(const ChainCtx& c) : saved(tl_chain) { tl_chain = c; }
+    ~ChainScope() { tl_chain = saved; }
+};
+// (pointer arithmetic on char*, never a round trip through an integer: the compiler must keep seeing a GLOBAL address -- after
+// an inttoptr it falls back to flat_load / flat_store, which wait on the LDS counter too and cost the step 20 %)
+template <typename T>
+__device__ __forceinline__ T* chain_at(T* p, const long long off) {
+    using U = typename std::remove_const<T>::type;
+    return p == nullptr ? p : reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<U*>(p)) + off);
+}
+// launch with the chain index on grid dimension z / y; the kernel's LAST parameter is the ChainOffs table
+#define DCCN_LAUNCH_CHAINS_Z(kern, grid, block, smem, s, ...)                                        \
+    do {                                                                                               \
+        dim3 g__ = (grid);                                                                             \
+        g__.z = (unsigned)::dccn::tl_chain.G;                                                          \
+        hipLaunchKernelGGL(kern, g__, block, smem, s, __VA_ARGS__, ::dccn::tl_chain.co);               \
+    } while (0)
+#define DCCN_LAUNCH_CHAINS_Y(kern, grid, block, smem, s, ...)                                        \
+    do {                                                                                               \
+        dim3 g__ = (grid);                                                                             \
+        g__.y = (unsigned)::dccn::tl_chain.G;                                                          \
+        hipLaunchKernelGGL(kern, g__, block, smem, s, __VA_ARGS__, ::dccn::tl_chain.co);               \
+    } while (0)
+// a launch site that has NOT been converted refuses to run inside a group (it would serve chain 0 only)
+#define DCCN_NO_CHAINS()                                               \
+    do {                                                               \
+        if (::dccn::tl_chain.G != 1 || ::dccn::tl_chain.co.off[0] != 0) return DCCN_ERR_UNSUPPORTED; \
+    } while (0)
 
 // ---- wave reductions (wave64) on the DPP crossbar: no LDS round trips ------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror sums each 16-lane row

@@ -305,6 +305,24 @@ struct GenStaticArgs {
     unsigned offset; unsigned long long seed;
     int abl;            // timing ablations (DCCN_GEN_ABL, experiments only: results are wrong when set): 1 no noise draws, 2 no
                         // label draws, 4 no ifft matrix loads, 8 no FIR
+    __device__ __forceinline__ GenStaticArgs at_chain(const long long coff) const {     // chain groups (common.h)
+        GenStaticArgs q = *this;
+        q.bits_out = chain_at(bits_out, coff); q.cell_map = chain_at(cell_map, coff); q.const_tab = chain_at(const_tab, coff);
+        q.idft = chain_at(idft, coff);
+        // (prof[] is indexed by the frame number: the kernel reads the profile it needs from the argument segment and rebases
+        // that one -- a rebased copy of the table would live in scratch memory)
+        q.H = chain_at(H, coff); q.snr_db = chain_at(snr_db, coff); q.y = chain_at(y, coff); q.noise = chain_at(noise, coff);
+        q.power_partial = chain_at(power_partial, coff); q.noise_partial = chain_at(noise_partial, coff); q.tx_out = chain_at(tx_out, coff);
+        return q;
+    }
+};
+// what differs between the chains of a group besides their arenas: the modulation and the Philox stream (n == 0: one chain,
+// the values of GenStaticArgs stand)
+struct GenChainScalars {
+    int n;
+    int nbits[kMaxChains];
+    unsigned offset[kMaxChains];
+    unsigned long long seed[kMaxChains];
 };
 typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGenFramesPerBlock = 2;
@@ -315,7 +333,10 @@ constexpr int kGenFirPad = 64;             // >= the longest channel response th
 // overlap instead of adding up (the first version walked them one after the other with run-time divisions: 26.8 us per launch;
 // profiles/r05_e2e_kernel_stats.txt has this one)
 template <int S, int K, int CP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a0, const GenChainScalars gc,
+                                                                                                           const ChainOffs co) {
+    GenStaticArgs a = a0.at_chain(co.off[blockIdx.z]);
+    if (gc.n > 0) { a.nbits = gc.nbits[blockIdx.z]; a.offset = gc.offset[blockIdx.z]; a.seed = gc.seed[blockIdx.z]; }
     constexpr int K2 = 2 * K, N2 = 2 * (K + CP), T = S * (K + CP), LDG = K2 + 4;
     // the cyclic-prefix columns of the ifft matrix are bitwise copies of its last 2 CP columns (t = (t' - CP) mod K,
     // datagen.py idft_cp_matrix): only the K2 / 16 tiles behind the prefix are multiplied, the prefix is stored twice
@@ -338,8 +359,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int f0 = (int)blockIdx.x * kGenFramesPerBlock;
     const int nfr = min(kGenFramesPerBlock, a.frames - f0);
     // the profiles of the block's two frames (block-uniform; frame 1 of a one-frame block repeats frame 0)
-    const GenProfile P0 = a.prof[f0 % a.n_prof];
-    const GenProfile P1 = a.prof[(f0 + (nfr > 1 ? 1 : 0)) % a.n_prof];
+    GenProfile P0 = a0.prof[f0 % a.n_prof];
+    GenProfile P1 = a0.prof[(f0 + (nfr > 1 ? 1 : 0)) % a.n_prof];
+    {
+        const long long coff = co.off[blockIdx.z];
+        P0.coeff = chain_at(P0.coeff, coff); P0.alpha = chain_at(P0.alpha, coff);
+        P1.coeff = chain_at(P1.coeff, coff); P1.alpha = chain_at(P1.alpha, coff);
+    }
     const int L0 = P0.identity ? 1 : P0.L, L1 = P1.identity ? 1 : P1.L;
     if (a.H != nullptr && tid < K) {
         float sn, cs;
@@ -534,11 +560,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 // x = y / sqrt(mean |y|^2) + noise where a buffer is wanted (the first batch of a pipelined loop, tests, iq dumps): the
 // expression of awgn_kernel on the generator's y and noise.  grid: any; 256 threads.
-__global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ noise,
-                                                               const double* __restrict__ ppart, int npart, double total,
-                                                               float4* __restrict__ x, long long n4,
-                                                               const double* __restrict__ npart_noise, int n_noise,
-                                                               float* __restrict__ npow_out) {
+__global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* y_, const float4* noise_, const double* ppart_, int npart,
+                                                               double total, float4* x_, long long n4, const double* npart_noise_,
+                                                               int n_noise, float* npow_out_, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float4* __restrict__ y = chain_at(y_, coff);
+    const float4* __restrict__ noise = chain_at(noise_, coff);
+    const double* __restrict__ ppart = chain_at(ppart_, coff);
+    float4* __restrict__ x = chain_at(x_, coff);
+    const double* __restrict__ npart_noise = chain_at(npart_noise_, coff);
+    float* __restrict__ npow_out = chain_at(npow_out_, coff);
     __shared__ double sh4[4];
     __shared__ float s_inv;
     const float inv = batch_power_inv_scale(ppart, npart, total, sh4, &s_inv);

@@ -23,6 +23,7 @@
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
+thread_local ChainCtx tl_chain = {1, {{0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
 StepTraceState g_step_trace;
 thread_local unsigned long long* tl_stamp = nullptr;
 
@@ -189,8 +190,8 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
     if (norm_fused_ok(x, y, batch, cols)) {
         // the whole batch of a column strip fits in one block's registers: single pass, single launch
         const int blocks = norm_fused_blocks(cols);
-        hipLaunchKernelGGL((norm_fused_kernel<kNormFusedCG, kNormFusedRPT>), dim3(blocks), dim3(128 * kNormFusedCG), 0, s,
-                           x, y, batch, cols, eps, peak, want_power ? pw : nullptr, mean, var, adam, hp);
+        DCCN_LAUNCH_CHAINS_Z((norm_fused_kernel<kNormFusedCG, kNormFusedRPT>), dim3(blocks), dim3(128 * kNormFusedCG), 0, s,
+                             x, y, batch, cols, eps, peak, want_power ? pw : nullptr, mean, var, adam, hp);
         DCCN_LAUNCH_CHECK();
         if (pp) {
             pp->partial = pw;
@@ -199,6 +200,7 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
         }
         return DCCN_OK;
     }
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(moments_kernel, dim3(gx, kNormRowChunks), dim3(64, 4), 0, s, x, batch, cols, partial, adam, hp);
     DCCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(normalise_kernel, dim3(gx, gy), dim3(64, 4), 0, s, x, y, partial, batch, cols, eps, peak,
@@ -945,11 +947,11 @@ template <int NB>
 static int tail_launch(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob, float* dz,
                        long long cells, int nblk, TailBlockMetrics* bm, float* bg, hipStream_t s) {
     if (bwd)
-        hipLaunchKernelGGL((demod_tail_kernel<NB, true>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
-                           dz, cells, bm, bg);
+        DCCN_LAUNCH_CHAINS_Z((demod_tail_kernel<NB, true>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
+                             dz, cells, bm, bg);
     else
-        hipLaunchKernelGGL((demod_tail_kernel<NB, false>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
-                           dz, cells, bm, bg);
+        DCCN_LAUNCH_CHAINS_Z((demod_tail_kernel<NB, false>), dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp, prob,
+                             dz, cells, bm, bg);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -975,11 +977,11 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
         case 4:
             if (bwd) {                                   // four lanes per cell (tail.h): 50 accumulators per lane, not 200
                 if (prob)
-                    hipLaunchKernelGGL(demod_tail_quad4_kernel<true>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp,
-                                       prob, dz, cells, bm, bg, tl_stamp);
+                    DCCN_LAUNCH_CHAINS_Z(demod_tail_quad4_kernel<true>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits, tailp,
+                                         prob, dz, cells, bm, bg, tl_stamp);
                 else
-                    hipLaunchKernelGGL(demod_tail_quad4_kernel<false>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits,
-                                       tailp, prob, dz, cells, bm, bg, tl_stamp);
+                    DCCN_LAUNCH_CHAINS_Z(demod_tail_quad4_kernel<false>, dim3(nblk), dim3(kTailThreads), 0, s, z, bits,
+                                         tailp, prob, dz, cells, bm, bg, tl_stamp);
                 DCCN_LAUNCH_CHECK();
                 st = DCCN_OK;
             } else {
@@ -999,6 +1001,7 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
         *defer = fa;
         return DCCN_OK;
     }
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(P)), dim3(256), 0, s, fa);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -1292,7 +1295,7 @@ static bool gen_static_ok(const dccn_gen_static* g) {
     // the instantiated shape: the reference's N = 64 frame with the long cyclic prefix, 7 symbols x (64 + 16) samples
     return g->S == 7 && g->K == 64 && g->CP == 16 && aligned16(g->y) && aligned16(g->noise);
 }
-static int gen_static_launch(const dccn_gen_static* g, hipStream_t s) {
+static int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenChainScalars* chains = nullptr) {
     if (!gen_static_ok(g)) return DCCN_ERR_INVALID_ARG;
     if (ceil_div(g->frames, kGenFramesPerBlock) > kChanPartials) return DCCN_ERR_INVALID_ARG;
     GenStaticArgs a;
@@ -1317,16 +1320,31 @@ static int gen_static_launch(const dccn_gen_static* g, hipStream_t s) {
     a.power_partial = g->power_partial; a.noise_partial = g->noise_partial; a.tx_out = g->tx_out;
     a.frames = g->frames; a.S = g->S; a.K = g->K; a.CP = g->CP; a.D = g->D; a.nbits = g->nbits;
     a.offset = g->offset; a.seed = g->seed;
+#ifdef DCCN_ABLATION
     {
         static const int abl = getenv("DCCN_GEN_ABL") ? atoi(getenv("DCCN_GEN_ABL")) : 0;      // timing experiments only
         a.abl = abl;
     }
+#else
+    a.abl = 0;              // (the ablation switches of tools/genbench.py exist in `make ablation` builds only)
+#endif
     const int T = g->S * (g->K + g->CP);
     const size_t smem = (size_t)16 * (2 * g->K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * (T + 2 * kGenFirPad) * sizeof(float2);
     const int blocks = ceil_div(g->frames, kGenFramesPerBlock);
-    hipLaunchKernelGGL((gen_static_frames_kernel<7, 64, 16>), dim3(blocks), dim3(256), smem, s, a);
+    GenChainScalars gc;
+    if (chains) gc = *chains;
+    else memset(&gc, 0, sizeof(gc));
+    if (tl_chain.G > 1 && gc.n != tl_chain.G) return DCCN_ERR_UNSUPPORTED;      // (a group needs every chain's seed / offset)
+    DCCN_LAUNCH_CHAINS_Z((gen_static_frames_kernel<7, 64, 16>), dim3(blocks), dim3(256), smem, s, a, gc);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
+}
+
+// batches whose pipelined normalisation can read the fused generator's (y, noise, partials) as its input: the single-pass R0
+// (norm_fused_kernel: <= 128 * kNormFusedRPT rows) and one power partial per generator block
+static bool rx_gen_next_shape_ok(int batch, int cols) {
+    return kNormFusedCG == 2 && (cols % 4) == 0 && batch > 0 && batch <= 128 * kNormFusedRPT &&
+           ceil_div(batch, kGenFramesPerBlock) <= kChanPartials;
 }
 
 // side != nullptr: run the dense weight-gradient branch on `side` (fork/join by events),
@@ -1359,6 +1377,11 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         // (the double-buffered pipelining -- R0 on the backward launch, knob 18 -- has no virtual-input form: refuse rather than
         // normalise a stale x_next)
         if (b->x_norm_next != nullptr) return DCCN_ERR_INVALID_ARG;
+        // ... and everything the optimizer launch will need to form that batch is checked HERE, before the generator, the
+        // forward, the backward and the update have been issued (dccn_rx_gen_next_supported is the caller's query)
+        if (!rx_gen_next_shape_ok(sh->batch, L.cols) || !gen_static_ok(b->gen_next) ||
+            !norm_fused_ok(b->gen_next->y, b->x_norm, sh->batch, L.cols))
+            return DCCN_ERR_INVALID_ARG;
         if (b->x_next_ready == nullptr) {
             trace.launch(7);
             DCCN_TRY(gen_static_launch(b->gen_next, s));
@@ -1644,6 +1667,7 @@ const char* dccn_strerror(int status) {
         case DCCN_ERR_LAUNCH: return "HIP launch/runtime error";
         case DCCN_ERR_NO_DEVICE: return "no HIP device visible";
         case DCCN_ERR_STATE: return "object used in the wrong state";
+        case DCCN_ERR_UNSUPPORTED: return "a grouped call reached a launch that cannot carry several chains";
         default: return "unknown status";
     }
 }
@@ -1879,6 +1903,10 @@ int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {
                     kNormFusedCG == 2 && norm_fused_ok(nullptr, nullptr, sh->batch, cols);
     return ok ? (g_tune[TUNE_FWD_PREFETCH] ? 2 : 1) : 0;
 }
+int dccn_rx_gen_next_supported(const dccn_rx_shape* sh) {
+    if (!shape_ok(sh) || dccn_rx_norm_rides_backward(sh) != 0) return 0;
+    return rx_gen_next_shape_ok(sh->batch, sh->S * sh->kin * 2) ? 1 : 0;
+}
 int dccn_rx_prefetch_pays(const dccn_rx_shape* sh) {
     if (!shape_ok(sh) || !g_tune[TUNE_FWD_PREFETCH_BIG]) return 0;
     // the static part of rx_step_impl's `overlap` decision (the dense kernel's update on the second stream)
@@ -2085,6 +2113,174 @@ int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, d
                        dccn_stream_t stream) {
     return eq_step_impl(shape, buf, true, hp, (hipStream_t)stream);
 }
+// ---- chain groups: G independent equaliser chains per launch sequence (common.h ChainCtx) ------------------------------
+// every device pointer of chain g must lie at ONE byte offset from chain 0's (the chains' arenas have the same layout)
+struct ChainOffsetCheck {
+    long long off[kMaxChains];
+    bool have[kMaxChains];
+    bool ok = true;
+    int n;
+    explicit ChainOffsetCheck(int n_) : n(n_) { for (int g = 0; g < kMaxChains; ++g) { off[g] = 0; have[g] = false; } }
+    // pointers p[g] (field f of every chain's struct)
+    void field(const void* const* p) {
+        for (int g = 0; g < n && ok; ++g) {
+            if ((p[g] == nullptr) != (p[0] == nullptr)) { ok = false; return; }
+            if (p[g] == nullptr) continue;
+            const long long d = (long long)(reinterpret_cast<const char*>(p[g]) - reinterpret_cast<const char*>(p[0]));
+            if (!have[g]) { off[g] = d; have[g] = true; }
+            else if (off[g] != d) ok = false;
+        }
+    }
+    bool finish(ChainCtx* ctx) {
+        if (!ok) return false;
+        ctx->G = n;
+        for (int g = 0; g < kMaxChains; ++g) { ctx->co.off[g] = 0; ctx->nbits[g] = 0; }
+        for (int g = 0; g < n; ++g) {
+            if (!have[g] || (off[g] & 255) != 0 || (g > 0 && off[g] == 0)) return false;
+            ctx->co.off[g] = off[g];
+        }
+        return true;
+    }
+};
+#define CHAIN_FIELD(chk, arr, n, member)                                             \
+    do {                                                                             \
+        const void* f__[kMaxChains];                                                 \
+        for (int g__ = 0; g__ < (n); ++g__) f__[g__] = (const void*)((arr)[g__]->member); \
+        (chk).field(f__);                                                            \
+    } while (0)
+
+static bool gen_static_same_plan(const dccn_gen_static* a, const dccn_gen_static* b) {
+    if (a->frames != b->frames || a->S != b->S || a->K != b->K || a->CP != b->CP || a->D != b->D || a->n_taps != b->n_taps ||
+        a->L != b->L || a->identity != b->identity || a->n_profiles != b->n_profiles || a->tap_stride != b->tap_stride ||
+        a->h_rep != b->h_rep || a->pilot_re != b->pilot_re || a->pilot_im != b->pilot_im)
+        return false;
+    for (int i = 0; i < a->n_profiles; ++i)
+        if (a->profiles[i].n_taps != b->profiles[i].n_taps || a->profiles[i].L != b->profiles[i].L ||
+            a->profiles[i].identity != b->profiles[i].identity)
+            return false;
+    return true;
+}
+static void gen_static_chain_fields(ChainOffsetCheck& chk, const dccn_gen_static* const* g, int n) {
+    CHAIN_FIELD(chk, g, n, bits_out); CHAIN_FIELD(chk, g, n, cell_map); CHAIN_FIELD(chk, g, n, const_tab);
+    CHAIN_FIELD(chk, g, n, idft); CHAIN_FIELD(chk, g, n, coeff); CHAIN_FIELD(chk, g, n, alpha); CHAIN_FIELD(chk, g, n, snr_db);
+    CHAIN_FIELD(chk, g, n, y); CHAIN_FIELD(chk, g, n, noise); CHAIN_FIELD(chk, g, n, power_partial);
+    CHAIN_FIELD(chk, g, n, noise_partial); CHAIN_FIELD(chk, g, n, noise_power_out); CHAIN_FIELD(chk, g, n, tx_out);
+    CHAIN_FIELD(chk, g, n, H_out);
+    for (int i = 0; i < g[0]->n_profiles && chk.ok; ++i) {
+        CHAIN_FIELD(chk, g, n, profiles[i].coeff);
+        CHAIN_FIELD(chk, g, n, profiles[i].alpha);
+    }
+}
+
+int dccn_chain_group_max(void) { return kMaxChains; }
+
+int dccn_gen_static_frames_grouped(int n_chains, const dccn_gen_static* const* g, dccn_stream_t stream) {
+    if (n_chains < 1 || n_chains > kMaxChains || !g) return DCCN_ERR_INVALID_ARG;
+    for (int i = 0; i < n_chains; ++i)
+        if (!g[i] || !gen_static_ok(g[i]) || !gen_static_same_plan(g[0], g[i])) return DCCN_ERR_INVALID_ARG;
+    if (n_chains == 1) return gen_static_launch(g[0], (hipStream_t)stream);
+    ChainOffsetCheck chk(n_chains);
+    gen_static_chain_fields(chk, g, n_chains);
+    ChainCtx ctx;
+    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
+    GenChainScalars gc;
+    memset(&gc, 0, sizeof(gc));
+    gc.n = n_chains;
+    for (int i = 0; i < n_chains; ++i) { gc.nbits[i] = g[i]->nbits; gc.offset[i] = g[i]->offset; gc.seed[i] = g[i]->seed; ctx.nbits[i] = g[i]->nbits; }
+    ChainScope scope(ctx);
+    return gen_static_launch(g[0], (hipStream_t)stream, &gc);
+}
+
+int dccn_gen_static_apply_grouped(int n_chains, const dccn_gen_static* const* g, float* const* x_out, float* const* noise_power,
+                                  dccn_stream_t stream) {
+    if (n_chains < 1 || n_chains > kMaxChains || !g || !x_out) return DCCN_ERR_INVALID_ARG;
+    for (int i = 0; i < n_chains; ++i)
+        if (!g[i] || !x_out[i] || !gen_static_ok(g[i]) || !gen_static_same_plan(g[0], g[i])) return DCCN_ERR_INVALID_ARG;
+    if (n_chains == 1) return dccn_gen_static_apply(g[0], x_out[0], noise_power ? noise_power[0] : nullptr, stream);
+    ChainOffsetCheck chk(n_chains);
+    gen_static_chain_fields(chk, g, n_chains);
+    chk.field(reinterpret_cast<const void* const*>(x_out));
+    if (noise_power) chk.field(reinterpret_cast<const void* const*>(noise_power));
+    ChainCtx ctx;
+    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
+    ChainScope scope(ctx);
+    return dccn_gen_static_apply(g[0], x_out[0], noise_power ? noise_power[0] : nullptr, stream);
+}
+
+int dccn_eq_group_supported(const dccn_eq_shape* shape) {
+    if (!eq_shape_ok(shape) || g_tune[TUNE_EQ_REPLAN] != 1 || !g_tune[TUNE_FEWROW] || g_tune[TUNE_SKINNY] <= 0) return 0;
+    const EqDims d = eq_dims(shape);
+    // the launches that carry a chain index: the few-row plan of the fused step (<= 96 frames), the pilot bottleneck as one
+    // launch per direction, the frozen receiver folded into one matrix
+    return (d.B <= 96 && (d.Pp == 16 || d.Pp == 32) && dccn_eq_norm_rides(shape) == 1 && (d.S * 2 * d.nsc) % 16 == 0 &&
+            d.S * 2 * d.nsc <= 1152) ? 1 : 0;
+}
+
+int dccn_eq_train_step_grouped(int n_chains, const dccn_eq_shape* const* shapes, const dccn_eq_buffers* const* bufs,
+                               dccn_adam_hparams hp, dccn_stream_t stream) {
+    if (n_chains < 1 || n_chains > kMaxChains || !shapes || !bufs) return DCCN_ERR_INVALID_ARG;
+    for (int i = 0; i < n_chains; ++i) {
+        if (!shapes[i] || !bufs[i] || !eq_shape_ok(shapes[i])) return DCCN_ERR_INVALID_ARG;
+        const dccn_eq_shape *a = shapes[0], *c = shapes[i];
+        // one launch plan: everything but the modulation agrees
+        if (a->batch != c->batch || a->S != c->S || a->K != c->K || a->CP != c->CP || a->cp != c->cp || a->F != c->F || a->D != c->D ||
+            a->pilot_size != c->pilot_size || a->P != c->P)
+            return DCCN_ERR_INVALID_ARG;
+        const dccn_eq_buffers *p = bufs[0], *q = bufs[i];
+        if (p->workspace_bytes != q->workspace_bytes || p->reg_uniform != q->reg_uniform || p->x_prenormalised != q->x_prenormalised ||
+            p->norm_slot != q->norm_slot || (p->x_next_virtual == nullptr) != (q->x_next_virtual == nullptr))
+            return DCCN_ERR_INVALID_ARG;
+        if (q->prob != nullptr) return DCCN_ERR_INVALID_ARG;          // (its size depends on the modulation: not part of the arena)
+    }
+    if (n_chains == 1) return eq_step_impl(shapes[0], bufs[0], true, hp, (hipStream_t)stream);
+    if (!dccn_eq_group_supported(shapes[0])) return DCCN_ERR_UNSUPPORTED;
+    ChainOffsetCheck chk(n_chains);
+    CHAIN_FIELD(chk, bufs, n_chains, x); CHAIN_FIELD(chk, bufs, n_chains, bits); CHAIN_FIELD(chk, bufs, n_chains, eq_params);
+    CHAIN_FIELD(chk, bufs, n_chains, eq_grads); CHAIN_FIELD(chk, bufs, n_chains, adam_m); CHAIN_FIELD(chk, bufs, n_chains, adam_v);
+    CHAIN_FIELD(chk, bufs, n_chains, reg_coef); CHAIN_FIELD(chk, bufs, n_chains, adam); CHAIN_FIELD(chk, bufs, n_chains, rx_params);
+    CHAIN_FIELD(chk, bufs, n_chains, out_eq); CHAIN_FIELD(chk, bufs, n_chains, chest); CHAIN_FIELD(chk, bufs, n_chains, snr_db);
+    CHAIN_FIELD(chk, bufs, n_chains, pilot_carriers); CHAIN_FIELD(chk, bufs, n_chains, metrics); CHAIN_FIELD(chk, bufs, n_chains, tx_power);
+    CHAIN_FIELD(chk, bufs, n_chains, workspace); CHAIN_FIELD(chk, bufs, n_chains, rx_folded); CHAIN_FIELD(chk, bufs, n_chains, x_next);
+    if (bufs[0]->x_next_virtual != nullptr) {
+        const dccn_gen_static* gv[kMaxChains];
+        for (int i = 0; i < n_chains; ++i) {
+            gv[i] = bufs[i]->x_next_virtual;
+            if (!gen_static_same_plan(gv[0], gv[i])) return DCCN_ERR_INVALID_ARG;
+        }
+        CHAIN_FIELD(chk, gv, n_chains, y); CHAIN_FIELD(chk, gv, n_chains, noise); CHAIN_FIELD(chk, gv, n_chains, power_partial);
+        CHAIN_FIELD(chk, gv, n_chains, noise_partial); CHAIN_FIELD(chk, gv, n_chains, noise_power_out);
+    }
+    ChainCtx ctx;
+    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
+    if (bufs[0]->rx_folded == nullptr) return DCCN_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_chains; ++i) ctx.nbits[i] = shapes[i]->nbits;
+    ChainScope scope(ctx);
+    return eq_step_impl(shapes[0], bufs[0], true, hp, (hipStream_t)stream);
+}
+
+int dccn_eq_monitor_accumulate_grouped(int n_chains, const dccn_eq_monitor* const* m, dccn_stream_t stream) {
+    if (n_chains < 1 || n_chains > kMaxChains || !m) return DCCN_ERR_INVALID_ARG;
+    for (int i = 0; i < n_chains; ++i) {
+        if (!m[i]) return DCCN_ERR_INVALID_ARG;
+        if (m[i]->chan_per_symbol != m[0]->chan_per_symbol || m[i]->B != m[0]->B || m[i]->S != m[0]->S || m[i]->K != m[0]->K ||
+            m[i]->workspace_bytes != m[0]->workspace_bytes)
+            return DCCN_ERR_INVALID_ARG;
+    }
+    const dccn_eq_monitor* a = m[0];
+    if (n_chains == 1)
+        return dccn_eq_monitor_accumulate(a->chest, a->chan, a->chan_per_symbol, a->B, a->S, a->K, a->metrics, a->tx_power,
+                                          a->noise_power, a->acc5, a->rms_out, a->workspace, a->workspace_bytes, stream);
+    ChainOffsetCheck chk(n_chains);
+    CHAIN_FIELD(chk, m, n_chains, chest); CHAIN_FIELD(chk, m, n_chains, chan); CHAIN_FIELD(chk, m, n_chains, metrics);
+    CHAIN_FIELD(chk, m, n_chains, tx_power); CHAIN_FIELD(chk, m, n_chains, noise_power); CHAIN_FIELD(chk, m, n_chains, acc5);
+    CHAIN_FIELD(chk, m, n_chains, rms_out); CHAIN_FIELD(chk, m, n_chains, workspace);
+    ChainCtx ctx;
+    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
+    ChainScope scope(ctx);
+    return dccn_eq_monitor_accumulate(a->chest, a->chan, a->chan_per_symbol, a->B, a->S, a->K, a->metrics, a->tx_power,
+                                      a->noise_power, a->acc5, a->rms_out, a->workspace, a->workspace_bytes, stream);
+}
+
 int dccn_eq_norm_rides(const dccn_eq_shape* shape) {
     if (!eq_shape_ok(shape)) return 0;
     const EqDims d = eq_dims(shape);
@@ -2216,9 +2412,9 @@ int dccn_equalize_fwd(const float* y, const float* h, float* eq, float* corr, lo
 int dccn_equalize_bwd(const float* y, const float* h, const float* d_eq, const float* d_corr, float* dy, float* dh,
                       long long n_pairs, dccn_stream_t stream) {
     if (!y || !h || (!d_eq && !d_corr) || (!dy && !dh) || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(equalize_bwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)y, (const float2*)h, (const float2*)d_eq, (const float2*)d_corr, (float2*)dy,
-                       (float2*)dh, n_pairs);
+    DCCN_LAUNCH_CHAINS_Z(equalize_bwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
+                         (const float2*)y, (const float2*)h, (const float2*)d_eq, (const float2*)d_corr, (float2*)dy,
+                         (float2*)dh, n_pairs);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -2359,11 +2555,11 @@ int dccn_gen_static_apply(const dccn_gen_static* g, float* x_out, float* noise_p
     const int np = dccn_gen_static_partials(g->frames);
     long long blocks = ceil_div_ll(n4, 256);
     if (blocks > 4 * kCUs) blocks = 4 * kCUs;
-    hipLaunchKernelGGL(gen_static_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(g->y), reinterpret_cast<const float4*>(g->noise),
-                       (const double*)g->power_partial, np, (double)g->frames * (double)T, reinterpret_cast<float4*>(x_out), n4,
-                       (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np,
-                       (noise_power && g->noise_partial) ? noise_power : nullptr);
+    DCCN_LAUNCH_CHAINS_Z(gen_static_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                         reinterpret_cast<const float4*>(g->y), reinterpret_cast<const float4*>(g->noise),
+                         (const double*)g->power_partial, np, (double)g->frames * (double)T, reinterpret_cast<float4*>(x_out), n4,
+                         (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np,
+                         (noise_power && g->noise_partial) ? noise_power : nullptr);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -2584,7 +2780,7 @@ int dccn_eq_monitor_accumulate(const float* chest, const float* chan, int chan_p
     a.metrics = metrics; a.tx_power = tx_power; a.noise_power = noise_power; a.acc = acc5; a.rms_out = rms_out;
     a.counter = static_cast<unsigned*>(workspace);
     a.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) + 256);
-    hipLaunchKernelGGL(eq_monitor_kernel, dim3(eq_monitor_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
+    DCCN_LAUNCH_CHAINS_Z(eq_monitor_kernel, dim3(eq_monitor_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -2602,8 +2798,8 @@ int dccn_eq_bottleneck_fwd(const float* y, const float* W1, const float* b1, con
     if (!y || !W1 || !W2 || !d1 || !d2 || !eq_bottleneck_ok(B, SK2, P, y, W1, W2) || !aligned16(d1)) return DCCN_ERR_INVALID_ARG;
     const int q = eq_bottleneck_q(B, SK2);
     auto kern = P == 32 ? eq_bottleneck_fwd_kernel<2> : eq_bottleneck_fwd_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, (hipStream_t)stream, y, W1, b1, W2, b2,
-                       d1, d2, B, SK2, q);
+    DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, (hipStream_t)stream, y, W1, b1, W2, b2,
+                         d1, d2, B, SK2, q);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -2625,8 +2821,8 @@ int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, co
     memset(&no_ride, 0, sizeof(no_ride));
     dccn_adam_hparams no_hp;
     memset(&no_hp, 0, sizeof(no_hp));
-    hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
-                       pw1, pb1, B, SK2, q, tiles, no_ride, no_hp);
+    DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
+                         pw1, pb1, B, SK2, q, tiles, no_ride, no_hp);
     DCCN_LAUNCH_CHECK();
     // (the fused equaliser step leaves these sums to its optimizer launch)
     DCCN_TRY(launch_splitk_reduce2(pw2, tiles, (long long)P * SK2, dW2, (long long)P * SK2, pb2, (long long)SK2, db2, (long long)SK2, s));

@@ -93,11 +93,17 @@ __device__ __forceinline__ void bn_join(const bn_f32x4 (&acc)[NP], float (*part)
 // frames and recomputes the frames' P bottleneck values for itself -- redundant long-k work (P columns only) that buys
 // enough blocks to fill the chip at 73 frames (5 row tiles)
 template <int NP>
-__global__ __launch_bounds__(256) void eq_bottleneck_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W1,
-                                                                const float* __restrict__ b1, const float* __restrict__ W2,
-                                                                const float* __restrict__ b2, float* __restrict__ d1,
-                                                                float* __restrict__ d2, const int B, const int SK2,
-                                                                const int q) {
+__global__ __launch_bounds__(256) void eq_bottleneck_fwd_kernel(const float* y_, const float* W1_, const float* b1_, const float* W2_,
+                                                                const float* b2_, float* d1_, float* d2_, const int B, const int SK2,
+                                                                const int q, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ y = chain_at(y_, coff);
+    const float* __restrict__ W1 = chain_at(W1_, coff);
+    const float* __restrict__ b1 = chain_at(b1_, coff);
+    const float* __restrict__ W2 = chain_at(W2_, coff);
+    const float* __restrict__ b2 = chain_at(b2_, coff);
+    float* __restrict__ d1 = chain_at(d1_, coff);
+    float* __restrict__ d2 = chain_at(d2_, coff);
     constexpr int P = 16 * NP;
     __shared__ float part[4][16][P + 1];
     __shared__ float t1[16][P + 1];
@@ -135,19 +141,28 @@ __global__ __launch_bounds__(256) void eq_bottleneck_fwd_kernel(const float* __r
 
 // slabs of block t: pW2 + t*P*SK2 ([P][SK2]), pb2 + t*SK2, pW1 + t*SK2*P ([SK2][P]), pb1 + t*P
 template <int NP>
-__global__ __launch_bounds__(256) void eq_bottleneck_bwd_kernel(const float* __restrict__ dd2, const float* __restrict__ d1,
-                                                                const float* __restrict__ y, const float* __restrict__ W1,
-                                                                const float* __restrict__ W2, const float* __restrict__ dy_in,
-                                                                float* __restrict__ dy_out, float* __restrict__ pW2,
-                                                                float* __restrict__ pb2, float* __restrict__ pW1,
-                                                                float* __restrict__ pb1, const int B, const int SK2,
-                                                                const int q, const int row_tiles, const EqRideArgs ride,
-                                                                const dccn_adam_hparams hp) {
+__global__ __launch_bounds__(256) void eq_bottleneck_bwd_kernel(const float* dd2_, const float* d1_, const float* y_, const float* W1_,
+                                                                const float* W2_, const float* dy_in_, float* dy_out_, float* pW2_,
+                                                                float* pb2_, float* pW1_, float* pb1_, const int B, const int SK2,
+                                                                const int q, const int row_tiles, const EqRideArgs ride0,
+                                                                const dccn_adam_hparams hp, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ dd2 = chain_at(dd2_, coff);
+    const float* __restrict__ d1 = chain_at(d1_, coff);
+    const float* __restrict__ y = chain_at(y_, coff);
+    const float* __restrict__ W1 = chain_at(W1_, coff);
+    const float* __restrict__ W2 = chain_at(W2_, coff);
+    const float* __restrict__ dy_in = chain_at(dy_in_, coff);
+    float* __restrict__ dy_out = chain_at(dy_out_, coff);
+    float* __restrict__ pW2 = chain_at(pW2_, coff);
+    float* __restrict__ pb2 = chain_at(pb2_, coff);
+    float* __restrict__ pW1 = chain_at(pW1_, coff);
+    float* __restrict__ pb1 = chain_at(pb1_, coff);
     constexpr int P = 16 * NP;
     // grid rows behind the batch's row tiles: optimizer riders (eq_opt.h EqRideArgs), dispatched after every block of the
     // launch's own work
     if ((int)blockIdx.y >= row_tiles) {
-        eq_ride_body(ride, hp, ((int)blockIdx.y - row_tiles) * (int)gridDim.x + (int)blockIdx.x);
+        eq_ride_body(ride0, hp, ((int)blockIdx.y - row_tiles) * (int)gridDim.x + (int)blockIdx.x, coff);
         return;
     }
     __shared__ float part[4][16][P + 1];

@@ -30,17 +30,29 @@ struct EqOptJob {
     int reg_uniform;         // SUM: reg_coef holds one value over the job's segment (a dense kernel or bias: keras l2(0.01) on
                              // every element, model.py:371-462; a C-Conv kernel: zero) -- read once instead of streamed
     int kin, F;              // CCONV_FOLD: kin, F; CONV2D_FOLD: L, W
+    __device__ __forceinline__ EqOptJob at_chain(const long long coff) const {          // chain groups (common.h)
+        EqOptJob q = *this;
+        q.src = chain_at(src, coff); q.src2 = chain_at(src2, coff);
+        return q;
+    }
 };
 constexpr int kEqOptJobs = 24;
 struct EqOptPtrs {
     float* param; float* grad; float* m; float* v;
     const float* reg_coef;
     const dccn_adam_state* state;
+    __device__ __forceinline__ void move_to_chain(const long long coff) {
+        param = chain_at(param, coff); grad = chain_at(grad, coff); m = chain_at(m, coff); v = chain_at(v, coff);
+        reg_coef = chain_at(reg_coef, coff); state = chain_at(state, coff);
+    }
 };
 struct EqOptArgs : EqOptPtrs {
     int njobs;
     EqOptJob job[kEqOptJobs];
-    TailFinalizeArgs fin;
+    // EQJ_TAIL_FINALIZE: chain g of a group (common.h) runs fin[fin_class[g]] -- chains of different modulations leave
+    // different slab counts / gradient lengths; one chain: fin[0]
+    TailFinalizeArgs fin[4];
+    int fin_class[kMaxChains];
     // EQJ_PILOT_SNR
     const float2* ps_eq; const int* ps_carriers; float* ps_out;
     int ps_frames, ps_S, ps_K, ps_P;
@@ -49,6 +61,7 @@ struct EqOptArgs : EqOptPtrs {
     int nbatch, ncols;
     NormVirtual nv;               // nx as (y, noise, power partials) of the fused generator (dccn_eq_buffers.x_next_virtual)
 };
+static_assert(sizeof(EqOptArgs) + sizeof(dccn_adam_hparams) + sizeof(ChainOffs) <= 4096, "kernel argument block");
 
 struct AdamCoef {
     float alpha, omb1, omb2, eps;
@@ -253,38 +266,55 @@ struct EqRideArgs {
     EqOptPtrs p;
     int njobs, blocks;
     EqOptJob job[3];         // EQJ_SUM (no slabs) / EQJ_CONV2D_FOLD
+    __device__ __forceinline__ EqRideArgs at_chain(const long long coff) const {
+        EqRideArgs q = *this;
+        q.p.move_to_chain(coff);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) q.job[i] = job[i].at_chain(coff);
+        return q;
+    }
 };
-__device__ __forceinline__ void eq_ride_body(const EqRideArgs& r, const dccn_adam_hparams& hp, const int bx) {
+// coff: the chain's arena offset (common.h); the table itself stays in the kernel-argument segment (indexing a rebased COPY of
+// it would put the copy into scratch memory), only the job this block runs is rebased
+__device__ __forceinline__ void eq_ride_body(const EqRideArgs& r, const dccn_adam_hparams& hp, const int bx, const long long coff = 0) {
     if (bx >= r.blocks) return;
     int j = 0;
     while (j + 1 < r.njobs && bx >= r.job[j + 1].block0) ++j;
+    const EqOptJob J = r.job[j].at_chain(coff);
+    EqOptPtrs p = r.p;
+    p.move_to_chain(coff);
     AdamCoef k;
-    k.alpha = r.p.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
-    if (r.job[j].kind == EQJ_CONV2D_FOLD) eq_opt_conv2d(r.p, r.job[j], k, bx - r.job[j].block0);
-    else eq_opt_sum(r.p, r.job[j], k, bx - r.job[j].block0);
+    k.alpha = p.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
+    if (J.kind == EQJ_CONV2D_FOLD) eq_opt_conv2d(p, J, k, bx - J.block0);
+    else eq_opt_sum(p, J, k, bx - J.block0);
 }
 
-__global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a, const dccn_adam_hparams hp) {
+__global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a0, const dccn_adam_hparams hp, const ChainOffs co) {
+    const int chain = (int)blockIdx.z;                               // chain groups (common.h)
+    const long long coff = co.off[chain];
     int j = 0;
-    while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].block0) ++j;      // (block-uniform scan of the table)
-    const EqOptJob& J = a.job[j];
+    while (j + 1 < a0.njobs && (int)blockIdx.x >= a0.job[j + 1].block0) ++j;      // (block-uniform scan of the table)
+    const EqOptJob J = a0.job[j].at_chain(coff);
     const int bx = (int)blockIdx.x - J.block0;
     if (J.kind == EQJ_NORM_NEXT) {
-        norm_fused_body<kNormFusedCG, kNormFusedRPT>(a.nx, a.ny, a.nbatch, a.ncols, 1e-9f, 8.0f, a.npower, nullptr, nullptr, nullptr,
-                                                     hp, bx, J.blocks, a.nv);
+        norm_fused_body<kNormFusedCG, kNormFusedRPT>(chain_at(a0.nx, coff), chain_at(a0.ny, coff), a0.nbatch, a0.ncols, 1e-9f, 8.0f,
+                                                     chain_at(a0.npower, coff), nullptr, nullptr, nullptr, hp, bx, J.blocks,
+                                                     a0.nv.at_chain(coff));
         return;
     }
     if (J.kind == EQJ_TAIL_FINALIZE) {
-        demod_tail_finalize_body(a.fin, bx);
+        demod_tail_finalize_body(a0.fin[a0.fin_class[chain]].at_chain(coff), bx);
         return;
     }
     if (J.kind == EQJ_PILOT_SNR) {
         const int frame = bx * 4 + (int)(threadIdx.x >> 6);
-        if (frame < a.ps_frames)
-            pilot_snr_body<false>(a.ps_eq, nullptr, nullptr, a.ps_carriers, a.ps_out, a.ps_S, a.ps_K, a.ps_P, frame,
-                                  (int)(threadIdx.x & 63));
+        if (frame < a0.ps_frames)
+            pilot_snr_body<false>(chain_at(a0.ps_eq, coff), nullptr, nullptr, chain_at(a0.ps_carriers, coff), chain_at(a0.ps_out, coff),
+                                  a0.ps_S, a0.ps_K, a0.ps_P, frame, (int)(threadIdx.x & 63));
         return;
     }
+    EqOptPtrs a = a0;
+    a.move_to_chain(coff);
     AdamCoef k;
     k.alpha = a.state->alpha; k.omb1 = 1.0f - hp.beta1; k.omb2 = 1.0f - hp.beta2; k.eps = hp.eps;
     if (J.kind == EQJ_SUM) {
@@ -374,16 +404,21 @@ struct EqOptBuilder {
         EqOptJob* J = add(EQJ_NORM_NEXT, nblocks);
         if (J) { a.nx = x; a.ny = y; a.nbatch = batch; a.ncols = cols; a.npower = power_partial; a.nv = nv; }
     }
-    void tail_finalize(const TailFinalizeArgs& fin) {
-        EqOptJob* J = add(EQJ_TAIL_FINALIZE, tail_finalize_blocks(fin.P));
-        if (J) a.fin = fin;
+    void tail_finalize(const TailFinalizeArgs* fin, int n_class, const int* fin_class) {
+        int blocks_ = 0;
+        for (int c = 0; c < n_class; ++c) blocks_ = tail_finalize_blocks(fin[c].P) > blocks_ ? tail_finalize_blocks(fin[c].P) : blocks_;
+        EqOptJob* J = add(EQJ_TAIL_FINALIZE, blocks_);
+        if (J) {
+            for (int c = 0; c < n_class; ++c) a.fin[c] = fin[c];
+            for (int g = 0; g < kMaxChains; ++g) a.fin_class[g] = fin_class[g];
+        }
     }
 };
 
 static int launch_eq_opt(EqOptBuilder& b, dccn_adam_hparams hp, hipStream_t s) {
     if (b.status != DCCN_OK) return b.status;
     if (b.blocks <= 0) return DCCN_OK;
-    hipLaunchKernelGGL(eq_opt_kernel, dim3((unsigned)b.blocks), dim3(256), 0, s, b.a, hp);
+    DCCN_LAUNCH_CHAINS_Z(eq_opt_kernel, dim3((unsigned)b.blocks), dim3(256), 0, s, b.a, hp);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

@@ -65,9 +65,12 @@ static void eq_layer_ws(const EqDims& d, size_t (&n)[EQL_COUNT]) {
 static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool train, EqWs& w) {
     const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
     w.n_norm = norm_ws_bytes(d.B, d.S * d.nsc * 2);
-    w.n_tail = tail_ws_bytes((long long)d.B * d.D, sh->nbits);
-    {
-        const size_t f = dense_tail_ws_bytes(d.B, 2 * d.D, sh->nbits);
+    // the layout does not depend on the modulation (the tail's slabs and gradient are sized for 16-QAM): chains of different
+    // modulations carried by one launch sequence (dccn_eq_train_step_grouped) see the same offsets
+    w.n_tail = 0;
+    for (int nb = 1; nb <= 4; ++nb) {
+        const size_t t = tail_ws_bytes((long long)d.B * d.D, nb), f = dense_tail_ws_bytes(d.B, 2 * d.D, nb);
+        if (t > w.n_tail) w.n_tail = t;
         if (f > w.n_tail) w.n_tail = f;
     }
     w.ws_norm = c.take<char>(w.n_norm);
@@ -110,7 +113,7 @@ static void eq_carve(Carver& c, const dccn_eq_shape* sh, const EqDims& d, bool t
     w.dd1 = c.take<float>(B * d.Pp);
     w.dflat = c.take<float>(B * SK2);
     w.dt1 = c.take<float>(R * K2);
-    w.dtail = c.take<float>(tail_param_count(sh->nbits));
+    w.dtail = c.take<float>(tail_param_count(4));
     w.bn_part = c.take<float>((d.Pp == 16 || d.Pp == 32) ? eq_bottleneck_part_floats(d.B, d.SK2, d.Pp) : 0);
 }
 static size_t eq_ws_bytes(const dccn_eq_shape* sh, int train) {
@@ -215,11 +218,12 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     // model.py:363 layer_norm, :369 dense, :378 C-Conv "DFT"; the expansion of the :428 smoothing C-Conv (S x K, same)
     // into the block-Toeplitz matrix of a dense layer depends on the parameters only and shares the launch
     if (replan) {
-        hipLaunchKernelGGL(eq_prep_kernel, dim3(B + ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s, (const float*)w.x_norm,
-                           w.ln, B, d.S * N2, 1e-12f, P + d.o[12], P + d.o[13], w.T, w.be, d.S, K,
-                           pre ? b->adam : (dccn_adam_state*)nullptr, hp);
+        DCCN_LAUNCH_CHAINS_Z(eq_prep_kernel, dim3(B + ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s, (const float*)w.x_norm,
+                             w.ln, B, d.S * N2, 1e-12f, P + d.o[12], P + d.o[13], w.T, w.be, d.S, K,
+                             pre ? b->adam : (dccn_adam_state*)nullptr, hp);
         DCCN_LAUNCH_CHECK();
     } else {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(B), dim3(256), 0, s, (const float*)w.x_norm, w.ln, (float*)nullptr,
                            (float*)nullptr, d.S * N2, 1e-12f);
         DCCN_LAUNCH_CHECK();
@@ -230,8 +234,8 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     if (bn) {                               // both layers of the bottleneck in one launch (eq_bottleneck.h)
         auto kern = d.Pp == 32 ? eq_bottleneck_fwd_kernel<2> : eq_bottleneck_fwd_kernel<1>;
         const int q = eq_bottleneck_q(B, SK2);
-        hipLaunchKernelGGL(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, s, (const float*)w.y, P + d.o[4],
-                           P + d.o[5], P + d.o[6], P + d.o[7], w.d1, w.d2, B, SK2, q);
+        DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, s, (const float*)w.y, P + d.o[4],
+                             P + d.o[5], P + d.o[6], P + d.o[7], w.d1, w.d2, B, SK2, q);
         DCCN_LAUNCH_CHECK();
     } else {
         DCCN_TRY(dense_fwd_impl(w.y, P + d.o[4], P + d.o[5], w.d1, B, SK2, d.Pp, s));
@@ -242,12 +246,14 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         bool fused = false;                 // tanh in the GEMM's store when the plan has the stage (few-row batches)
         DCCN_TRY(dense_fwd_impl(w.d3, P + d.o[10], P + d.o[11], w.d4, B, SK2, SK2, s, 0, 2, &fused));
         if (!fused) {
+            DCCN_NO_CHAINS();
             hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.d4, w.d4, nBK);
             DCCN_LAUNCH_CHECK();
         }
     }
     // :428 smoothing C-Conv as a dense layer -> channel estimate
     if (!replan) {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks_n((long long)SK2 * SK2)), dim3(256), 0, s,
                            P + d.o[12], P + d.o[13], w.T, w.be, d.S, K, d.S, K);
         DCCN_LAUNCH_CHECK();
@@ -262,21 +268,25 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         if (want_snr && train) {
             snr_pending = true;
         } else if (want_snr) {
+            DCCN_NO_CHAINS();
             hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
                                d.S, K, sh->P);
             DCCN_LAUNCH_CHECK();
         }
     } else if (replan && want_snr) {
         const int eb = (int)ew_blocks_n(nBK / 2);
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(equalize_fwd_snr_kernel, dim3(eb + ceil_div(B, 4)), dim3(256), 0, s, (const float2*)w.y,
                            (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2, eb, b->pilot_carriers, b->snr_db, B,
                            d.S, K, sh->P);
         DCCN_LAUNCH_CHECK();
     } else {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
                            (const float2*)h, (float2*)w.eq, (float2*)w.corr, nBK / 2);
         DCCN_LAUNCH_CHECK();
         if (want_snr) {
+            DCCN_NO_CHAINS();
             hipLaunchKernelGGL(pilot_snr_kernel, dim3(B), dim3(64), 0, s, (const float2*)w.eq, b->pilot_carriers, b->snr_db,
                                d.S, K, sh->P);
             DCCN_LAUNCH_CHECK();
@@ -289,6 +299,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     } else {
         DCCN_TRY(cconv_fwd_impl(w.corr, P + d.o[14], P + d.o[15], w.corc, R, K, K, s));
         DCCN_TRY(cconv_fwd_impl(w.eq, P + d.o[16], P + d.o[17], w.eqc, R, K, K, s));
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(concat_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float2*)w.eqc,
                            (const float2*)w.corc, (float4*)w.cat, (long long)R * K);
         DCCN_LAUNCH_CHECK();
@@ -306,28 +317,57 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     const bool folded = few_rx && Mf != nullptr && g_tune[TUNE_FEWROW] >= 1 && aligned16(Mf) && aligned16(b->out_eq) &&
                         (fK % 16) == 0 && fK <= 1152;
     if (!folded) DCCN_TRY(cconv_fwd_impl(b->out_eq + d.win, Q + L.o_conv_w, Q + L.o_conv_b, w.fft, R, rsh.kin, d.F, s, N2));
-    TailFinalizeArgs fin;
-    bool fin_deferred = false;              // training: the tail's metric reduction rides on the optimizer launch
+    // the tail is the one stage whose kernels depend on the modulation: the chains of a group (common.h ChainCtx) run it class by
+    // class -- one launch (pair) per distinct nbits, carrying the chains of that modulation -- everything else is one launch
+    // for all of them.  fin[c] / fin_class: the metric reduction each chain's optimizer-launch job runs.
+    TailFinalizeArgs fin[4];
+    int fin_class[kMaxChains] = {0, 0, 0, 0, 0, 0, 0, 0}, n_class = 0;
+    const bool fin_deferred = replan && train;   // training: the tail's metric reduction rides on the optimizer launch
     // the receiver's linear part as this step runs it: (input rows, weights, bias, k extent)
     const float* rxA = folded ? b->out_eq : w.fft;
     const float* rxW = folded ? Mf : Q + L.o_dense_w;
     const float* rxb = folded ? Mf + (size_t)fK * L.dN : Q + L.o_dense_b;
     const int rxK = folded ? fK : L.dK;
-    // BPSK / QPSK: the tail rides on the few-row tiles themselves (dense_tail_impl picks the fewrow.h form for <= 96 rows)
-    const bool few_tail = few_rx && sh->nbits <= 2 && dense_tail_ok(rxA, rxW, B, rxK, L.dN, sh->nbits);
-    if ((few_tail || !few_rx) && dense_tail_planned(sh->nbits, train, B, L.dN) &&
-        dense_tail_ok(rxA, rxW, B, rxK, L.dN, sh->nbits)) {                      // dense + tail in one launch
-        fin_deferred = replan && train;
-        DCCN_TRY(dense_tail_impl(train, rxA, rxW, rxb, nullptr, b->bits, Q + L.o_tail, b->prob,
-                                 b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, rxK, L.dN, sh->nbits,
-                                 &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? &fin : nullptr));
+    auto tail_section = [&](const int nbits, TailFinalizeArgs* fin_out) -> int {
+        // BPSK / QPSK: the tail rides on the few-row tiles themselves (dense_tail_impl picks the fewrow.h form for <= 96 rows)
+        const bool few_tail = few_rx && nbits <= 2 && dense_tail_ok(rxA, rxW, B, rxK, L.dN, nbits);
+        if ((few_tail || !few_rx) && dense_tail_planned(nbits, train, B, L.dN) &&
+            dense_tail_ok(rxA, rxW, B, rxK, L.dN, nbits)) {                      // dense + tail in one launch
+            DCCN_TRY(dense_tail_impl(train, rxA, rxW, rxb, nullptr, b->bits, Q + L.o_tail, b->prob,
+                                     b->metrics, train ? w.dz : nullptr, train ? w.dtail : nullptr, B, rxK, L.dN, nbits,
+                                     &pp, b->tx_power, w.ws_tail, w.n_tail, s, fin_deferred ? fin_out : nullptr));
+        } else {
+            if (folded) DCCN_TRY(dense_fwd_impl(b->out_eq, Mf, Mf + (size_t)fK * L.dN, w.z, B, fK, L.dN, s));
+            else DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
+            DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
+                               train ? w.dtail : nullptr, L.cells, nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s,
+                               fin_deferred ? fin_out : nullptr));
+        }
+        return DCCN_OK;
+    };
+    if (tl_chain.G == 1) {
+        DCCN_TRY(tail_section(sh->nbits, &fin[0]));
+        n_class = 1;
     } else {
-        fin_deferred = replan && train;     // (the tail's metric reduction rides on the optimizer launch either way)
-        if (folded) DCCN_TRY(dense_fwd_impl(b->out_eq, Mf, Mf + (size_t)fK * L.dN, w.z, B, fK, L.dN, s));
-        else DCCN_TRY(dense_fwd_impl(w.fft, Q + L.o_dense_w, Q + L.o_dense_b, w.z, B, L.dK, L.dN, s));
-        DCCN_TRY(tail_impl(train, w.z, b->bits, Q + L.o_tail, b->prob, b->metrics, train ? w.dz : nullptr,
-                           train ? w.dtail : nullptr, L.cells, sh->nbits, &pp, b->tx_power, w.ws_tail, w.n_tail, s,
-                           fin_deferred ? &fin : nullptr));
+        if (!folded || !fin_deferred) return DCCN_ERR_UNSUPPORTED;
+        const ChainCtx all = tl_chain;
+        bool done[kMaxChains] = {false, false, false, false, false, false, false, false};
+        for (int g = 0; g < all.G; ++g) {
+            if (done[g]) continue;
+            if (n_class >= 4) return DCCN_ERR_INVALID_ARG;
+            ChainCtx sub = all;
+            sub.G = 0;
+            for (int h = g; h < all.G; ++h) {
+                if (all.nbits[h] != all.nbits[g]) continue;
+                sub.co.off[sub.G] = all.co.off[h]; sub.nbits[sub.G] = all.nbits[h];
+                ++sub.G;
+                done[h] = true;
+                fin_class[h] = n_class;
+            }
+            ChainScope scope(sub);
+            DCCN_TRY(tail_section(all.nbits[g], &fin[n_class]));
+            ++n_class;
+        }
     }
     if (!train) return DCCN_OK;
 
@@ -338,6 +378,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     } else {
         DCCN_TRY(dense_bwd_x_impl(w.dz, Q + L.o_dense_w, w.dfft, B, L.dK, L.dN, s));
         if (!d.cp) {                                        // nothing flows back into the cyclic-prefix samples
+            DCCN_NO_CHAINS();
             hipLaunchKernelGGL(zero_fill_kernel, dim3(ew_blocks_n((long long)R * N2)), dim3(256), 0, s, w.dout,
                                (long long)R * N2);
             DCCN_LAUNCH_CHECK();
@@ -354,6 +395,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                                  w.ws_l[EQL_DENSE5], w.n_l[EQL_DENSE5], s, 1, nullptr, nullptr, keep_slabs ? &ds5 : nullptr,
                                  pair ? w.deqc : nullptr, pair ? (long long)(w.dcorc - w.deqc) : 0, pair ? &split_done : nullptr));
     if (!split_done) {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(split_pairs_kernel, dim3(ew_blocks_n((long long)R * K)), dim3(256), 0, s, (const float4*)w.dcat,
                            (float2*)w.deqc, (float2*)w.dcorc, (long long)R * K);
         DCCN_LAUNCH_CHECK();
@@ -369,9 +411,9 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         DCCN_TRY(cconv_bwd_x_impl(w.dcorc, P + d.o[14], w.dcorr, R, K, K, s));
         DCCN_TRY(cconv_bwd_w_impl(w.corr, w.dcorc, G + d.o[14], G + d.o[15], R, K, K, w.ws_l[EQL_PAIR], w.n_l[EQL_PAIR], s));
     }
-    hipLaunchKernelGGL(equalize_bwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
-                       (const float2*)h, (const float2*)w.deq, (const float2*)w.dcorr, (float2*)w.dy, (float2*)w.dh,
-                       nBK / 2);
+    DCCN_LAUNCH_CHAINS_Z(equalize_bwd_kernel, dim3(ew_blocks_n(nBK / 2)), dim3(256), 0, s, (const float2*)w.y,
+                         (const float2*)h, (const float2*)w.deq, (const float2*)w.dcorr, (float2*)w.dy, (float2*)w.dh,
+                         nBK / 2);
     DCCN_LAUNCH_CHECK();
     bool tg_fused = false;                  // tanh gradient on the dX store: dd4 = (dh . T^T) (1 - d4^2)
     DCCN_TRY(dense_bwd_full_impl(w.d4, w.dh, w.T, w.dd4, w.dT, w.dbe, B, SK2, SK2, w.ws_l[EQL_SMOOTH], w.n_l[EQL_SMOOTH], s, 3,
@@ -384,11 +426,13 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         dsT.dw_slabs = dsT.db_slabs = nullptr;
     }
     if (!replan) {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(d.S * K + 1), dim3(64), 0, s, (const float*)w.dT,
                            (const float*)w.dbe, G + d.o[12], G + d.o[13], d.S, K, d.S, K);
         DCCN_LAUNCH_CHECK();
     }
     if (!tg_fused) {
+        DCCN_NO_CHAINS();
         hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, (const float*)w.dd4, (const float*)w.d4,
                            w.dd4, nBK);
         DCCN_LAUNCH_CHECK();
@@ -440,9 +484,9 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                 rode[li] = true;
             }
         }
-        hipLaunchKernelGGL(kern, dim3(nx, bn_tiles + ceil_div(ride.blocks, nx)), dim3(256), 0, s, (const float*)w.dd2,
-                           (const float*)w.d1, (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2,
-                           bn_w1, bn_b1, B, SK2, q, bn_tiles, ride, hp);
+        DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx, bn_tiles + ceil_div(ride.blocks, nx)), dim3(256), 0, s, (const float*)w.dd2,
+                             (const float*)w.d1, (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2,
+                             bn_w1, bn_b1, B, SK2, q, bn_tiles, ride, hp);
         DCCN_LAUNCH_CHECK();
         dy_sum = w.dflat;
     } else {
@@ -454,6 +498,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         DCCN_TRY(dense_bwd_full_impl(w.y, w.dd1, P + d.o[4], w.dflat, G + d.o[4], G + d.o[5], B, SK2, d.Pp, w.ws_l[EQL_DENSE1],
                                      w.n_l[EQL_DENSE1], s, 4, w.dy, &add_fused, keep_slabs ? &ds1 : nullptr));
         if (!add_fused) {
+            DCCN_NO_CHAINS();
             hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks_n(nBK)), dim3(256), 0, s, w.dy, (const float*)w.dflat, nBK);
             DCCN_LAUNCH_CHECK();
         }
@@ -521,7 +566,7 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         else { ob.plain(d.o[i], d.sz[i]); ob.plain(d.o[i + 1], d.sz[i + 1]); }
     }
     eq_opt_dense(ob, d, 18, ds5, N2, uni);
-    if (fin_deferred) ob.tail_finalize(fin);
+    if (fin_deferred) ob.tail_finalize(fin, n_class, fin_class);
     if (snr_pending) ob.pilot_snr(w.eq, b->pilot_carriers, b->snr_db, B, d.S, K, sh->P);
     return launch_eq_opt(ob, hp, s);
 }

@@ -114,10 +114,15 @@ __global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restr
 
 // real-valued backward of the pair above; d_corr may be null.  corr = (er^2+ei^2, 0), so only its
 // real cotangent reaches eq.
-__global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
-                                                           const float2* __restrict__ d_eq,
-                                                           const float2* __restrict__ d_corr, float2* __restrict__ dy,
-                                                           float2* __restrict__ dh, long long n) {
+__global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* y_, const float2* h_, const float2* d_eq_, const float2* d_corr_,
+                                                           float2* dy_, float2* dh_, long long n, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float2* __restrict__ y = chain_at(y_, coff);
+    const float2* __restrict__ h = chain_at(h_, coff);
+    const float2* __restrict__ d_eq = chain_at(d_eq_, coff);
+    const float2* __restrict__ d_corr = chain_at(d_corr_, coff);
+    float2* __restrict__ dy = chain_at(dy_, coff);
+    float2* __restrict__ dh = chain_at(dh_, coff);
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float2 yv = y[i], hv = h[i];
@@ -209,8 +214,16 @@ struct EqMonitorArgs {
     float* rms_out;             // nullable: this step's chan_rms
     double* partial;            // [blocks]
     unsigned* counter;          // zero before the first launch; the last block leaves it zero again
+    __device__ __forceinline__ EqMonitorArgs at_chain(const long long coff) const {      // chain groups (common.h)
+        EqMonitorArgs q = *this;
+        q.chest = chain_at(chest, coff); q.chan = chain_at(chan, coff); q.metrics = chain_at(metrics, coff);
+        q.tx_power = chain_at(tx_power, coff); q.noise_power = chain_at(noise_power, coff); q.acc = chain_at(acc, coff);
+        q.rms_out = chain_at(rms_out, coff); q.partial = chain_at(partial, coff); q.counter = chain_at(counter, coff);
+        return q;
+    }
 };
-__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a) {
+__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0, const ChainOffs co) {
+    const EqMonitorArgs a = a0.at_chain(co.off[blockIdx.z]);
     __shared__ double red[4];
     __shared__ unsigned s_last;
     const long long cols = (long long)a.B * a.K * 2;
@@ -334,10 +347,17 @@ __global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* _
 // the equaliser step's second launch: layer_norm of the normalised frames (one block per frame) and, in the blocks behind
 // them, the expansion of the smoothing kernel -- two independent 5 us launches as one
 // adam != nullptr: the optimizer's per-step bookkeeping rides here (steps whose normalisation the previous step already ran)
-__global__ __launch_bounds__(256) void eq_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int frames, int cols,
-                                                      float eps, const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ T, float* __restrict__ bias_eff, int L, int W,
-                                                      dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp) {
+__global__ __launch_bounds__(256) void eq_prep_kernel(const float* x_, float* y_, int frames, int cols, float eps, const float* w_,
+                                                      const float* bias_, float* T_, float* bias_eff_, int L, int W,
+                                                      dccn_adam_state* adam_, dccn_adam_hparams hp, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ x = chain_at(x_, coff);
+    float* __restrict__ y = chain_at(y_, coff);
+    const float* __restrict__ w = chain_at(w_, coff);
+    const float* __restrict__ bias = chain_at(bias_, coff);
+    float* __restrict__ T = chain_at(T_, coff);
+    float* __restrict__ bias_eff = chain_at(bias_eff_, coff);
+    dccn_adam_state* __restrict__ adam = chain_at(adam_, coff);
     if (adam != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         adam->alpha = adam_alpha(adam, hp);
         adam->beta1_power = adam->beta1_power * hp.beta1;

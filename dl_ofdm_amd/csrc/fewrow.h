@@ -183,15 +183,20 @@ __device__ __forceinline__ void fewrow_tail_tile(const GemmParams& p, const Tail
     tail_block_reduce<NB, BWD, 256>(A, red, tp.blk_metrics, tp.blk_grads, L);
 }
 
+// (chain groups, common.h: blockIdx.z = chain, every pointer moves by that chain's arena offset)
 template <int NG, int NB, bool BWD>
-__global__ __launch_bounds__(256) void fewrow_tail_kernel(const GemmParams p, const TailEpiParams tp) {
+__global__ __launch_bounds__(256) void fewrow_tail_kernel(const GemmParams p0, const TailEpiParams tp0, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];
+    const GemmParams p = p0.at_chain(coff);
+    const TailEpiParams tp = tp0.at_chain(coff);
     stamp_mark(p.stamp, 0);
     fewrow_tail_tile<NG, NB, BWD>(p, tp, (int)blockIdx.x, (int)gridDim.x);
     stamp_mark(p.stamp, 1);
 }
 
 template <int BKIND, int NG, int NB, int TAG>
-__global__ __launch_bounds__(256) void fewrow_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void fewrow_kernel(const GemmParams p0, const ChainOffs co) {
+    const GemmParams p = p0.at_chain(co.off[blockIdx.z]);
     stamp_mark(p.stamp, 0);
     fewrow_tile<BKIND, NG, NB>(p, (int)blockIdx.x, (int)gridDim.x);
     stamp_mark(p.stamp, 1);
@@ -304,7 +309,10 @@ static inline bool fewrow_dw_ok(const GemmParams& pw) {
 // dense backward of a few-row batch in ONE grid: dX tiles as above (ACTX: element-wise stage of the caller's graph on the
 // way out) and the unsplit dW = X^T . dY tiles of gemm16.h behind them (k = the few rows: one or two k-tiles)
 template <int NG, int ACTX, int WWGM, int WWGN, int WTM, int WTN, int BK, bool DWFEW>
-__global__ __launch_bounds__(256) void dense_bwd_fewrow_kernel(const GemmParams px, const GemmParams pw, const int nx, const int tw) {
+__global__ __launch_bounds__(256) void dense_bwd_fewrow_kernel(const GemmParams px0, const GemmParams pw0, const int nx, const int tw,
+                                                               const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];
+    const GemmParams px = px0.at_chain(coff), pw = pw0.at_chain(coff);
     const int b = (int)blockIdx.x;
     stamp_mark(px.stamp, 0);
     if (b < nx) {
@@ -345,11 +353,11 @@ template <int BKIND, int NB, int TAG>
 static int launch_fewrow(const GemmParams& p, hipStream_t s) {
     const int T = ceil_div(p.M, 16) * (p.N / 16);
     switch (fewrow_ng(p)) {
-        case 18: hipLaunchKernelGGL((fewrow_kernel<BKIND, 18, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
-        case 14: hipLaunchKernelGGL((fewrow_kernel<BKIND, 14, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((fewrow_kernel<BKIND, 10, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((fewrow_kernel<BKIND, 4, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((fewrow_kernel<BKIND, 3, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        case 18: DCCN_LAUNCH_CHAINS_Z((fewrow_kernel<BKIND, 18, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        case 14: DCCN_LAUNCH_CHAINS_Z((fewrow_kernel<BKIND, 14, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        case 10: DCCN_LAUNCH_CHAINS_Z((fewrow_kernel<BKIND, 10, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        case 4: DCCN_LAUNCH_CHAINS_Z((fewrow_kernel<BKIND, 4, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
+        case 3: DCCN_LAUNCH_CHAINS_Z((fewrow_kernel<BKIND, 3, NB, TAG>), dim3(T), dim3(256), 0, s, p); break;
         default: return DCCN_ERR_INVALID_ARG;
     }
     DCCN_LAUNCH_CHECK();
@@ -361,9 +369,9 @@ template <int NB, bool BWD>
 static int launch_fewrow_tail(const GemmParams& p, const TailEpiParams& tp, hipStream_t s) {
     const int T = ceil_div(p.M, 16) * (p.N / 16);
     switch (fewrow_ng_c(p, false)) {
-        case 18: hipLaunchKernelGGL((fewrow_tail_kernel<18, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
-        case 14: hipLaunchKernelGGL((fewrow_tail_kernel<14, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
-        case 10: hipLaunchKernelGGL((fewrow_tail_kernel<10, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
+        case 18: DCCN_LAUNCH_CHAINS_Z((fewrow_tail_kernel<18, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
+        case 14: DCCN_LAUNCH_CHAINS_Z((fewrow_tail_kernel<14, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
+        case 10: DCCN_LAUNCH_CHAINS_Z((fewrow_tail_kernel<10, NB, BWD>), dim3(T), dim3(256), 0, s, p, tp); break;
         default: return DCCN_ERR_INVALID_ARG;
     }
     DCCN_LAUNCH_CHECK();
@@ -378,12 +386,12 @@ static int launch_dense_bwd_fewrow_ng(const GemmParams& px, const GemmParams& pw
     if (fewrow_dw_ok(pw)) {                      // the weight gradient on one-latency tiles as well
         auto kern = dense_bwd_fewrow_kernel<NG, ACTX, 2, 2, 2, 2, 64, true>;
         DCCN_TRY(set_smem_attr(kern, kFewrowDwSmem));
-        hipLaunchKernelGGL(kern, dim3(nx + tw), dim3(256), kFewrowDwSmem, s, px, pw, nx, tw);
+        DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx + tw), dim3(256), kFewrowDwSmem, s, px, pw, nx, tw);
     } else {
         const size_t smem = CW::smem_bytes(0);
         auto kern = dense_bwd_fewrow_kernel<NG, ACTX, 2, 2, 2, 2, 64, false>;
         DCCN_TRY(set_smem_attr(kern, smem));
-        hipLaunchKernelGGL(kern, dim3(nx + tw), dim3(256), smem, s, px, pw, nx, tw);
+        DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx + tw), dim3(256), smem, s, px, pw, nx, tw);
     }
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;

@@ -46,6 +46,12 @@ struct TailEpiParams {
     TailBlockMetrics* blk_metrics;  // one slab per block
     float* blk_grads;
     float inv_count;                // 1 / (cells * NB)
+    __device__ __forceinline__ TailEpiParams at_chain(const long long off) const {     // chain groups (common.h)
+        TailEpiParams q = *this;
+        q.bits = chain_at(bits, off); q.tailp = chain_at(tailp, off); q.prob = chain_at(prob, off); q.dz = chain_at(dz, off);
+        q.blk_metrics = chain_at(blk_metrics, off); q.blk_grads = chain_at(blk_grads, off);
+        return q;
+    }
 };
 
 // One operand tile: BI rows (the M or N index) x BK columns (k), staged by NT threads.
@@ -773,6 +779,7 @@ static int launch_gemm16(const GemmParams& p, int splits, hipStream_t s, size_t 
     DCCN_TRY(set_smem_attr(kern, smem));
     TailEpiParams none{};
     dim3 grid(ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), 1, splits);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, grid, dim3(CF::NT), smem, s, p, none);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -790,6 +797,7 @@ static int launch_dense_tail16(const GemmParams& p, const TailEpiParams& tp, hip
     if (smem < smem_min) smem = smem_min;
     DCCN_TRY(set_smem_attr(kern, smem));
     dim3 grid(ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), 1, 1);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, grid, dim3(CF::NT), smem, s, p, tp);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -821,6 +829,7 @@ static int launch_dense_tail16_ragged(const GemmParams& p1, const TailEpiParams&
     if (smem < smem_min) smem = smem_min;
     DCCN_TRY(set_smem_attr(kern, smem));
     const int T1 = ceil_div(p1.N, 64) * ceil_div(p1.M, 16 * TM1), T2 = ceil_div(p2.N, 64) * ceil_div(p2.M, 16 * TM2);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, dim3(T1 + T2), dim3(256), smem, s, p1, t1, p2, t2, T1, T2);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -837,6 +846,7 @@ static int launch_dense_bwd16(const GemmParams& px, const GemmParams& pw, int sp
     DCCN_TRY(set_smem_attr(kern, smem));
     const int nx = ceil_div(px.N, CX::BN) * ceil_div(px.M, CX::BM);
     const int tw = ceil_div(pw.N, CW::BN) * ceil_div(pw.M, CW::BM);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(256), smem, s, px, pw, nx, tw);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -849,6 +859,7 @@ static int launch_bwd_w16_finalize(const GemmParams& p, int splits, const TailFi
     const size_t smem = CF::smem_bytes(0);
     DCCN_TRY(set_smem_attr(kern, smem));
     const int tiles = ceil_div(p.N, CF::BN) * ceil_div(p.M, CF::BM), gemm_blocks = tiles * splits;
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, dim3(gemm_blocks + tail_finalize_blocks(fin.P)), dim3(256), smem, s, p, tiles, gemm_blocks,
                        fin);
     DCCN_LAUNCH_CHECK();

@@ -88,6 +88,16 @@ struct GemmParams {
     const dccn_adam_state* ad_state;
     float ad_omb1, ad_omb2, ad_eps;
     unsigned long long* stamp;   // step timeline stamps of this launch (common.h stamp_mark), nullptr = none
+    // chain groups (common.h): the same launch for the chain whose arena lies `off` bytes behind chain 0's
+    __device__ __forceinline__ GemmParams at_chain(const long long off) const {
+        GemmParams q = *this;
+        q.A = chain_at(A, off); q.B = chain_at(B, off); q.C = chain_at(C, off);
+        q.bias = chain_at(bias, off); q.colsum = chain_at(colsum, off);
+        q.aux = chain_at(aux, off); q.out2 = chain_at(out2, off); q.out3 = chain_at(out3, off);
+        q.ad_p = chain_at(ad_p, off); q.ad_m = chain_at(ad_m, off); q.ad_v = chain_at(ad_v, off);
+        q.ad_reg = chain_at(ad_reg, off); q.ad_gate = chain_at(ad_gate, off); q.ad_state = chain_at(ad_state, off);
+        return q;
+    }
 };
 
 constexpr int kGemmThreads = 256;
@@ -605,7 +615,8 @@ __device__ __forceinline__ GemmParams group_params(const GemmParams& p, const Gr
     return q;
 }
 template <int KA, int KB, int BM, int BN, int BK, int TAG, bool VEC, int NBUF, int CMAP>
-__global__ __launch_bounds__(kGemmThreads) void gemm_grouped_kernel(const GemmParams p, const GroupStride gs) {
+__global__ __launch_bounds__(kGemmThreads) void gemm_grouped_kernel(const GemmParams p0, const GroupStride gs, const ChainOffs co) {
+    const GemmParams p = p0.at_chain(co.off[blockIdx.z]);           // chain groups (common.h); y = the layer of the pair
     const GemmParams q = group_params(p, gs, (int)blockIdx.y);
     stamp_mark(p.stamp, 0);
     gemm_block<KA, KB, BM, BN, BK, 0, VEC, NBUF, CMAP>(q, (int)blockIdx.x, (int)gridDim.x, 0);
@@ -617,7 +628,7 @@ static int launch_gemm_grouped(const GemmParams& p, const GroupStride& gs, int g
     constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK, NBUF>();
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     dim3 grid(ceil_div(p.N, BN) * ceil_div(p.M, BM), groups, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p, gs);
+    DCCN_LAUNCH_CHAINS_Z(kern, grid, dim3(kGemmThreads), smem, s, p, gs);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -657,6 +668,7 @@ static int launch_gemm_cfg2(const GemmParams& p, int splits, hipStream_t s) {
     constexpr size_t smem = gemm_smem_bytes<KA, KB, BM, BN, BK, NBUF>();
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     dim3 grid(ceil_div(p.N, BN) * ceil_div(p.M, BM), 1, splits);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), smem, s, p);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -677,6 +689,7 @@ static int launch_dense_bwd_grouped(const GemmParams& px, const GemmParams& pw, 
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     const int nx = ceil_div(px.N, BN) * ceil_div(px.M, BM);
     const int tw = ceil_div(pw.N, BN) * ceil_div(pw.M, BM);
+    DCCN_NO_CHAINS();
     hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
@@ -804,6 +817,7 @@ static int launch_splitk_reduce(const float* partial, int splits, long long slab
     const bool vec4 = (n % 4 == 0) && (slab % 4 == 0) && aligned16(partial) && aligned16(out);
     const long long units = vec4 ? n / 4 : n;
     const unsigned blocks = (unsigned)ceil_div_ll(units, kRedLanes);
+    DCCN_NO_CHAINS();
     if (vec4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, partial, splits, slab, out, n);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, partial, splits, slab, out, n);
     DCCN_LAUNCH_CHECK();
@@ -814,6 +828,7 @@ static int launch_splitk_reduce2(const float* pa, int splits, long long slab_a, 
                                  const float* pb, long long slab_b, float* out_b, long long nb, hipStream_t s) {
     const bool vec4 = (na % 4 == 0) && (slab_a % 4 == 0) && aligned16(pa) && aligned16(out_a);
     const int blocks_a = (int)ceil_div_ll(vec4 ? na / 4 : na, kRedLanes), blocks_b = (int)ceil_div_ll(nb, kRedLanes);
+    DCCN_NO_CHAINS();
     if (vec4)
         hipLaunchKernelGGL(splitk_reduce2_kernel<true>, dim3(blocks_a + blocks_b), dim3(256), 0, s, pa, slab_a, out_a, na,
                            blocks_a, pb, slab_b, out_b, nb, splits);

@@ -255,8 +255,11 @@ static inline bool kmajor_ok(const GemmParams& p) {
 
 // stand-alone launch: grid (tiles, 1, splits)
 template <int COLSUM, int TAG, bool APATCH = false>
-__global__ __launch_bounds__(kGemmThreads) void gemm_kmajor_kernel(const GemmParams p) {
-    kmajor_block<COLSUM, 64, APATCH>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+__global__ __launch_bounds__(kGemmThreads) void gemm_kmajor_kernel(const GemmParams p0, const ChainOffs co) {
+    // chain groups (common.h): y = the chain (z carries the k ranges); its arena offset enters as the block's operand
+    // offsets -- a shifted copy of the parameter block would put the dynamically indexed koff[] into scratch memory
+    const long long c4 = co.off[blockIdx.y] / 4;
+    kmajor_block<COLSUM, 64, APATCH>(p0, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, c4, c4, c4, c4);
 }
 
 template <int COLSUM, int TAG, bool APATCH = false>
@@ -264,7 +267,7 @@ static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
     auto kern = gemm_kmajor_kernel<COLSUM, TAG, APATCH>;
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), kmajor_smem_bytes<64>()));
     dim3 grid(ceil_div(p.N, 64) * ceil_div(p.M, 64), 1, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(kGemmThreads), kmajor_smem_bytes<64>(), s, p);
+    DCCN_LAUNCH_CHAINS_Y(kern, grid, dim3(kGemmThreads), kmajor_smem_bytes<64>(), s, p);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -272,17 +275,20 @@ static int launch_kmajor(const GemmParams& p, int splits, hipStream_t s) {
 // dense backward in one grid: blocks [0, nx) = the dX tiles (gemm_f32_mfma.h, k-contiguous operands), the rest = the
 // dW (tile, split) items in the k-major form.  CMAP: column map of the dX stores (gemm_store)
 template <int BK, int CMAP = CMAP_NONE>
-__global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_km_kernel(const GemmParams px, const GemmParams pw,
-                                                                            const int nx, const int tw) {
+__global__ __launch_bounds__(kGemmThreads) void dense_bwd_grouped_km_kernel(const GemmParams px0, const GemmParams pw0,
+                                                                            const int nx, const int tw, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];              // chain groups (common.h)
     const int b = (int)blockIdx.x;
 #ifdef GROUPED_ABL          // timing experiments only: 1 = the dX blocks return at once, 2 = the dW blocks do
     if ((GROUPED_ABL == 1) == (b < nx)) return;
 #endif
     if (b < nx) {
+        const GemmParams px = px0.at_chain(coff);
         gemm_block<OP_KCONTIG, OP_KCONTIG, 64, 64, BK, 0, true, 2, CMAP>(px, b, nx, 0);
     } else {
         const int c = b - nx;
-        kmajor_block<1, BK>(pw, c % tw, tw, c / tw);
+        const long long c4 = coff / 4;                      // (kmajor_block: offsets, not a shifted copy -- koff[] is indexed)
+        kmajor_block<1, BK>(pw0, c % tw, tw, c / tw, c4, c4, c4, c4);
     }
 }
 
@@ -294,7 +300,7 @@ static int launch_dense_bwd_grouped_km(const GemmParams& px, const GemmParams& p
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
     const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
-    hipLaunchKernelGGL(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
+    DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx + tw * splits_w), dim3(kGemmThreads), smem, s, px, pw, nx, tw);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
@@ -304,18 +310,20 @@ static int launch_dense_bwd_grouped_km(const GemmParams& px, const GemmParams& p
 // items of  dWeff_g = x_g^T . dout_g  in the k-major form, slabs left for the optimizer launch to fold.
 // Four launches of the pair (two dX, two dW) + two folds become one grid.
 template <int BK>
-__global__ __launch_bounds__(kGemmThreads) void cconv_bwd_grouped_km_kernel(const GemmParams px, const GroupStride gx,
-                                                                            const GemmParams pw, const GroupStride gw,
+__global__ __launch_bounds__(kGemmThreads) void cconv_bwd_grouped_km_kernel(const GemmParams px0, const GroupStride gx,
+                                                                            const GemmParams pw0, const GroupStride gw,
                                                                             const int nx, const int tw, const int splits,
-                                                                            const int groups) {
+                                                                            const int groups, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];              // chain groups (common.h)
     const int b = (int)blockIdx.x;
     if (b < nx * groups) {
-        const GemmParams q = group_params(px, gx, b / nx);
+        const GemmParams q = group_params(px0.at_chain(coff), gx, b / nx);
         gemm_block<OP_KCONTIG, OP_CCONV_WT, 64, 64, BK, 0, true>(q, b % nx, nx, 0);
     } else {
         const int c = b - nx * groups, per = tw * splits;
         const int g = c / per, i = c % per;
-        kmajor_block<1, BK>(pw, i % tw, tw, i / tw, g * gw.a, g * gw.b, g * gw.c, g * gw.colsum);
+        const long long c4 = coff / 4;
+        kmajor_block<1, BK>(pw0, i % tw, tw, i / tw, g * gw.a + c4, g * gw.b + c4, g * gw.c + c4, g * gw.colsum + c4);
     }
 }
 
@@ -328,8 +336,8 @@ static int launch_cconv_bwd_grouped_km(const GemmParams& px, const GroupStride& 
     DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), smem));
     const int nx = ceil_div(px.N, 64) * ceil_div(px.M, 64);
     const int tw = ceil_div(pw.N, 64) * ceil_div(pw.M, 64);
-    hipLaunchKernelGGL(kern, dim3((nx + tw * splits_w) * groups), dim3(kGemmThreads), smem, s, px, gx, pw, gw, nx, tw,
-                       splits_w, groups);
+    DCCN_LAUNCH_CHAINS_Z(kern, dim3((nx + tw * splits_w) * groups), dim3(kGemmThreads), smem, s, px, gx, pw, gw, nx, tw,
+                         splits_w, groups);
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }

@@ -217,6 +217,12 @@ struct NormVirtual {
     const double* ppart; int npart; double total; // partial sums of |y|^2, batch * T (complex samples)
     float* x_out;                                 // nullable: also store x (tx_ofdm) -- tests, iq dumps
     const double* npart_noise; int n_noise; float* npow_out;      // nullable: `noise_power:0` monitor, summed by block 0
+    __device__ __forceinline__ NormVirtual at_chain(const long long coff) const {        // chain groups (common.h)
+        NormVirtual q = *this;
+        q.y = chain_at(y, coff); q.noise = chain_at(noise, coff); q.ppart = chain_at(ppart, coff); q.x_out = chain_at(x_out, coff);
+        q.npart_noise = chain_at(npart_noise, coff); q.npow_out = chain_at(npow_out, coff);
+        return q;
+    }
 };
 __device__ __host__ inline NormVirtual norm_virtual_none() {
     NormVirtual v;
@@ -396,13 +402,16 @@ __device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, flo
 }
 
 template <int CG, int RPT>
-__global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int batch, int cols, float eps, float peak,
-                                                              double* __restrict__ power_partial,
-                                                              float* __restrict__ mean_out,
-                                                              float* __restrict__ var_out,
-                                                              dccn_adam_state* __restrict__ adam,
-                                                              dccn_adam_hparams hp) {
+__global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* x_, float* y_, int batch, int cols, float eps, float peak,
+                                                              double* power_partial_, float* mean_out_, float* var_out_,
+                                                              dccn_adam_state* adam_, dccn_adam_hparams hp, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ x = chain_at(x_, coff);
+    float* __restrict__ y = chain_at(y_, coff);
+    double* __restrict__ power_partial = chain_at(power_partial_, coff);
+    float* __restrict__ mean_out = chain_at(mean_out_, coff);
+    float* __restrict__ var_out = chain_at(var_out_, coff);
+    dccn_adam_state* __restrict__ adam = chain_at(adam_, coff);
     norm_fused_body<CG, RPT>(x, y, batch, cols, eps, peak, power_partial, mean_out, var_out, adam, hp, (int)blockIdx.x,
                              (int)gridDim.x);
 }

@@ -333,9 +333,16 @@ __device__ __forceinline__ void tail_block_reduce(TailLaneAcc<NB, BWD>& A, float
 
 template <int NB, bool BWD>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_kernel(
-    const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
-    float* __restrict__ prob, float* __restrict__ dz, long long cells,
-    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads) {
+    const float* z_, const int32_t* bits_, const float* tailp_, float* prob_, float* dz_, long long cells,
+    TailBlockMetrics* blk_metrics_, float* blk_grads_, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ z = chain_at(z_, coff);
+    const int32_t* __restrict__ bits = chain_at(bits_, coff);
+    const float* __restrict__ tailp = chain_at(tailp_, coff);
+    float* __restrict__ prob = chain_at(prob_, coff);
+    float* __restrict__ dz = chain_at(dz_, coff);
+    TailBlockMetrics* __restrict__ blk_metrics = chain_at(blk_metrics_, coff);
+    float* __restrict__ blk_grads = chain_at(blk_grads_, coff);
     constexpr int P = tail_param_count(NB);
     __shared__ __attribute__((aligned(8))) float sred[tail_reduce_lds_floats<NB, BWD>(kTailThreads)];
 
@@ -607,9 +614,16 @@ __device__ __forceinline__ void tail_quad4_block_reduce(TailQuad4Acc& A, float* 
 
 template <bool WRITE_PROB>
 __global__ __launch_bounds__(kTailThreads) void demod_tail_quad4_kernel(
-    const float* __restrict__ z, const int32_t* __restrict__ bits, const float* __restrict__ tailp,
-    float* __restrict__ prob, float* __restrict__ dz, long long cells,
-    TailBlockMetrics* __restrict__ blk_metrics, float* __restrict__ blk_grads, unsigned long long* stamp) {
+    const float* z_, const int32_t* bits_, const float* tailp_, float* prob_, float* dz_, long long cells,
+    TailBlockMetrics* blk_metrics_, float* blk_grads_, unsigned long long* stamp, const ChainOffs co) {
+    const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    const float* __restrict__ z = chain_at(z_, coff);
+    const int32_t* __restrict__ bits = chain_at(bits_, coff);
+    const float* __restrict__ tailp = chain_at(tailp_, coff);
+    float* __restrict__ prob = chain_at(prob_, coff);
+    float* __restrict__ dz = chain_at(dz_, coff);
+    TailBlockMetrics* __restrict__ blk_metrics = chain_at(blk_metrics_, coff);
+    float* __restrict__ blk_grads = chain_at(blk_grads_, coff);
     constexpr int NB = 4;
     stamp_mark(stamp, 0);
     __shared__ __attribute__((aligned(8))) float sred[tail_quad4_lds_floats(kTailThreads)];
@@ -671,6 +685,13 @@ struct TailFinalizeArgs {
     unsigned* zero_word;        // nullable: hand-off words of a later launch of the same step, reset here: the arrival
     unsigned* zero_flags;       // counter and n_zero_flags flag words at a stride of zero_stride (fresh or recycled
     int n_zero_flags, zero_stride;   // workspace memory may hold anything, including a stale epoch)
+    __device__ __forceinline__ TailFinalizeArgs at_chain(const long long coff) const {   // chain groups (common.h)
+        TailFinalizeArgs q = *this;
+        q.blk_metrics = chain_at(blk_metrics, coff); q.blk_grads = chain_at(blk_grads, coff); q.metrics = chain_at(metrics, coff);
+        q.dtailp = chain_at(dtailp, coff); q.power_partial = chain_at(power_partial, coff); q.power_out = chain_at(power_out, coff);
+        q.adam = chain_at(adam, coff); q.zero_word = chain_at(zero_word, coff); q.zero_flags = chain_at(zero_flags, coff);
+        return q;
+    }
 };
 static inline int tail_finalize_blocks(int P) { return (P + 3 + 3) / 4; }
 

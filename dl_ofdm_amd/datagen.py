@@ -249,35 +249,47 @@ class FusedStaticGen:
     trained batch instead of two or three calls and eight or nine launches; ``make_batch`` materialises x (one more launch)
     where a buffer is wanted.  Same Philox streams, draws and batch offsets as ``DeviceDataGen`` (it advances ``gen.offset``)."""
 
-    def __init__(self, gen: DeviceDataGen, n_frames: int, snr_db, want_noise_power: bool = False):
+    def __init__(self, gen: DeviceDataGen, n_frames: int, snr_db, want_noise_power: bool = False, arena=None):
         if not self.supported(gen):
             raise _lib.DccnError("FusedStaticGen: static N = 64 channels only (one profile, or the frame-interleaved profiles of "
                                  "mixRayleigh / mixAll without Doppler frames)")
+        from . import arena as A
         self.gen, self.n = gen, int(n_frames)
+        self.arena = arena
         dev, f32 = gen.device, dict(dtype=torch.float32, device=gen.device)
-        self.snr = torch.empty(self.n, **f32)
+        self.snr = A.empty(arena, self.n, **f32)
         self.set_snr(snr_db)
-        self.y = torch.empty(self.n, gen.S, gen.n_sc, 2, **f32)
-        self.noise = torch.empty(self.n, gen.S, gen.n_sc, 2, **f32)
+        self.y = A.empty(arena, self.n, gen.S, gen.n_sc, 2, **f32)
+        self.noise = A.empty(arena, self.n, gen.S, gen.n_sc, 2, **f32)
         npart = int(gen.lib.dccn_gen_static_partials(self.n))
-        self.ppart = torch.zeros(npart, dtype=torch.float64, device=dev)
-        self.npart = torch.zeros(npart, dtype=torch.float64, device=dev) if want_noise_power else None
-        self.npow = torch.zeros(2, 1, **f32) if want_noise_power else None       # one slot per label slot
+        self.ppart = A.zeros(arena, npart, dtype=torch.float64, device=dev)
+        self.npart = A.zeros(arena, npart, dtype=torch.float64, device=dev) if want_noise_power else None
+        self.npow = A.zeros(arena, 2, 1, **f32) if want_noise_power else None       # one slot per label slot
         p = DeviceDataGen._p
-        self.desc = _lib.GenStatic(0, p(gen.cell_map), p(gen.const_tab), float(gen.pilot.real), float(gen.pilot.imag),
-                                   p(gen.idft), p(gen.coeff), p(gen.alpha), gen.n_taps, gen.L, 1 if gen.identity else 0,
+        # (chain groups: the generator's tables travel with the chain -- copies inside its arena, the constellation set aside
+        # for 16-QAM)
+        self._tabs = [A.place(arena, gen.cell_map), A.place(arena, gen.const_tab, reserve=32), A.place(arena, gen.idft),
+                      A.place(arena, gen.coeff), A.place(arena, gen.alpha)]
+        self.desc = _lib.GenStatic(0, p(self._tabs[0]), p(self._tabs[1]), float(gen.pilot.real), float(gen.pilot.imag),
+                                   p(self._tabs[2]), p(self._tabs[3]), p(self._tabs[4]), gen.n_taps, gen.L, 1 if gen.identity else 0,
                                    p(self.snr), p(self.y), p(self.noise), p(self.ppart), p(self.npart), None, None,
                                    self.n, gen.S, gen.K, gen.CP, gen.D, gen.nbits, gen.seed, 0)
         if gen.mixed:
             # radio.py:438-452: frame f runs profile f % n_profiles; the launch-per-stage path draws 16 tap slots per frame
+            self._ptabs = [(A.place(arena, pr["coeff"]), A.place(arena, pr["alpha"])) for pr in gen.profiles]
             self._profiles = (_lib.GenProfile * len(gen.profiles))(*[
-                _lib.GenProfile(p(pr["coeff"]), p(pr["alpha"]), pr["n_taps"], pr["L"], 1 if pr["identity"] else 0, 0)
-                for pr in gen.profiles])
+                _lib.GenProfile(p(tc), p(ta), pr["n_taps"], pr["L"], 1 if pr["identity"] else 0, 0)
+                for pr, (tc, ta) in zip(gen.profiles, self._ptabs)])
             self.desc.n_profiles, self.desc.tap_stride = len(gen.profiles), 16
             self.desc.profiles = C.addressof(self._profiles)
 
     @staticmethod
-    def supported(gen: DeviceDataGen) -> bool:
+    def supported(gen: DeviceDataGen, eng=None) -> bool:
+        """``eng``: the training engine whose steps would take this generator as ``gen_next`` (train_step_generated): its batch
+        must be one the pipelined normalisation can form from the generator's output (dccn_rx_gen_next_supported: the batch grows
+        with falling BER in receiver.train and leaves that range beyond 1536 frames)"""
+        if eng is not None and not bool(gen.lib.dccn_rx_gen_next_supported(C.byref(eng.shape))):
+            return False
         if gen.doppler or gen.align_window or not bool(gen.lib.dccn_gen_static_supported(gen.S, gen.K, gen.CP)):
             return False
         if gen.mixed:                       # static frames only: no (profile, Doppler) pair in any frame plan

@@ -289,6 +289,7 @@ class RxEngine:
                 self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out
         self._prefetch_pending = not last
         if last:
+            self._gen_side_primed = False
             self._norm_ready = False
 
     def train_step_generated(self, fgen, slot: int = 0, last: bool = False, keep_x: bool = False, side=None):
@@ -304,6 +305,7 @@ class RxEngine:
         if not self._norm_ready:
             fgen.make_batch(self.x, self.label_slot(slot), slot)
             self.prime()
+            self._gen_side_primed = False       # the side stream must see these main-stream writers of y / noise / partials
         gen_ptr, ready = 0, 0
         if not last:
             d = fgen.arm(self.label_slot(slot ^ 1), slot ^ 1)

@@ -35,11 +35,14 @@ class _FusedPlan:
     """Resident buffers + captured hipGraphs of ``dccn_eq_train_step`` / ``dccn_eq_eval_step`` for one batch
     size (include/dccn.h: "the fused equaliser transfer-learning step")."""
 
-    def __init__(self, tr: "EqualizerTrainer", batch: int, twin_of: "Optional[_FusedPlan]" = None):
+    def __init__(self, tr: "EqualizerTrainer", batch: int, twin_of: "Optional[_FusedPlan]" = None, arena=None):
         """twin_of: a plan of the same batch size whose workspace and outputs this one shares -- only the input frames and
         labels are its own.  Two twins hold consecutive batches of a training loop: while one's step runs, the generator
-        fills the other's input, and the running step normalises it on its optimizer launch (``pipe_with``)."""
+        fills the other's input, and the running step normalises it on its optimizer launch (``pipe_with``).
+        arena: a :class:`~dl_ofdm_amd.arena.ChainArena` to place every buffer in (chain groups: equalizer_group.py)."""
+        from . import arena as A
         F, o, dev = tr.FLAGS, tr.ofdmobj, tr.device
+        self.arena = arena
         self.tr, self.batch = tr, int(batch)
         self.pipe_buffers: Dict[int, EqBuffers] = {}
         self.shape = EqShape(self.batch, F.nsymbol, o.K, o.CP, 1 if F.cp else 0, F.nfilter, o.frame_size, F.nbits, o.pilot_size,
@@ -49,20 +52,21 @@ class _FusedPlan:
         assert offs[20] == tr.arena_size and [offs[i] for i in range(20)] == [tr.layout[n][0] for n in tr.names]
         f32 = dict(dtype=torch.float32, device=dev)
         B, S, n_sc = self.batch, F.nsymbol, o.K + o.CP
-        self.x = torch.zeros(B, S, n_sc, 2, **f32)
-        self.bits = torch.zeros(B, o.frame_size, F.nbits, dtype=torch.int32, device=dev)
+        self.x = A.zeros(arena, B, S, n_sc, 2, **f32)
+        # (the label buffer is set aside for 16-QAM whatever this chain's modulation: the arena layout must not depend on it)
+        self.bits = A.zeros(arena, B, o.frame_size, F.nbits, dtype=torch.int32, device=dev, reserve=B * o.frame_size * 4)
         if twin_of is not None:
             assert twin_of.batch == self.batch
             for n in ("out_eq", "chest", "snr_db", "metrics_buf", "tx_power", "ws", "nws"):
                 setattr(self, n, getattr(twin_of, n))
         else:
-            self.out_eq = torch.empty(B, S, n_sc, 2, **f32)
-            self.chest = torch.empty(B, S, o.K, 2, **f32)
-            self.snr_db = torch.empty(B, 1, **f32)
-            self.metrics_buf = torch.zeros(_lib.METRICS_BYTES, dtype=torch.uint8, device=dev)
-            self.tx_power = torch.zeros(1, **f32)
+            self.out_eq = A.empty(arena, B, S, n_sc, 2, **f32)
+            self.chest = A.empty(arena, B, S, o.K, 2, **f32)
+            self.snr_db = A.empty(arena, B, 1, **f32)
+            self.metrics_buf = A.zeros(arena, _lib.METRICS_BYTES, dtype=torch.uint8, device=dev)
+            self.tx_power = A.zeros(arena, 1, **f32)
             self.nws = tr.lib.dccn_eq_workspace_size(C.byref(self.shape), 1)
-            self.ws = torch.empty(self.nws, dtype=torch.uint8, device=dev)
+            self.ws = A.empty(arena, self.nws, dtype=torch.uint8, device=dev)
         self.buffers = self._buffers()
         self._partner = None
         self.graphs: Dict[object, C.c_void_p] = {}
@@ -149,7 +153,11 @@ class EqualizerTrainer:
     [frames, n_sym, n_sc, 2] (host or device) and return a metrics dict."""
 
     def __init__(self, FLAGS, ofdmobj, rx_params: Dict[str, np.ndarray], device="cuda", seed: int = 1,
-                 lr0: Optional[float] = None):
+                 lr0: Optional[float] = None, arena=None):
+        """arena: a :class:`~dl_ofdm_amd.arena.ChainArena` that receives every device buffer the fused step reads or writes
+        (parameter / gradient / Adam arenas, the frozen receiver, pilot table): chain groups, equalizer_group.py."""
+        from . import arena as A
+        self.arena = arena
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -170,16 +178,16 @@ class EqualizerTrainer:
         self.names = [n for n in self.store.names() if n.startswith("Equalizer/")]
         self._flatten()
         self.hp = AdamHParams.default(float(lr0 if lr0 is not None else getattr(FLAGS, "init_learning", 1e-3)))
-        self.adam_state = torch.tensor([0.0, 0.9, 0.999, 0.0], dtype=torch.float32, device=self.device)
+        self.adam_state = A.place(arena, torch.tensor([0.0, 0.9, 0.999, 0.0], dtype=torch.float32, device=self.device))
         self.last: dict = {}
         # frozen receiver as one arena (dccn_rx_param_offsets layout) + pilot carriers for the fused step
         lay, total = param_layout(self.rx.dims())
-        self.rx_arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.rx_arena = A.zeros(arena, total, dtype=torch.float32, device=self.device, reserve=lay["demodulation/conv2d/kernel"][0] + 256)   # (room for the 200 tail weights of 16-QAM: one layout for every modulation)
         for n in PARAM_NAMES:
             o_, shp = lay[n]
             self.rx_arena[o_:o_ + int(np.prod(shp))] = torch.as_tensor(
                 np.asarray(rx_params[n], dtype=np.float32).reshape(-1)).to(self.device)
-        self.pilot_carriers = torch.as_tensor(np.asarray(ofdmobj.pilotCarriers, dtype=np.int32)).to(self.device)
+        self.pilot_carriers = A.place(arena, torch.as_tensor(np.asarray(ofdmobj.pilotCarriers, dtype=np.int32)).to(self.device))
         self.fused_ok = True
         self._plans: Dict[int, _FusedPlan] = {}
         self._rx_folded = None
@@ -189,7 +197,8 @@ class EqualizerTrainer:
         receiver's weights do not change while the equaliser trains (ofdmreceiver_np_mp.py:330)."""
         if self._rx_folded is None:
             n = int(self.lib.dccn_eq_rx_folded_floats(C.byref(shape)))
-            self._rx_folded = torch.empty(n, dtype=torch.float32, device=self.device)
+            from . import arena as A
+            self._rx_folded = A.empty(self.arena, n, dtype=torch.float32, device=self.device)
             check(self.lib.dccn_eq_rx_fold(C.byref(shape), self.rx_arena.data_ptr(), self._rx_folded.data_ptr(),
                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "dccn_eq_rx_fold")
         return self._rx_folded
@@ -202,9 +211,10 @@ class EqualizerTrainer:
         # every tensor starts on a 16-byte boundary of the arena (dccn_eq_param_offsets): vector loads for every layer
         total = int(sum((sz + 3) // 4 * 4 for sz in sizes))
         self.arena_size = total
-        self.params, self.grads = torch.zeros(total, **f32), torch.zeros(total, **f32)
-        self.adam_m, self.adam_v = torch.zeros(total, **f32), torch.zeros(total, **f32)
-        self.reg_coef = torch.zeros(total, **f32)
+        from . import arena as A
+        self.params, self.grads = A.zeros(self.arena, total, **f32), A.zeros(self.arena, total, **f32)
+        self.adam_m, self.adam_v = A.zeros(self.arena, total, **f32), A.zeros(self.arena, total, **f32)
+        self.reg_coef = A.zeros(self.arena, total, **f32)
         self.layout, o = {}, 0
         for n, sz in zip(self.names, sizes):
             p = self.store.tensor(n)

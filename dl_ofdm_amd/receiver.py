@@ -287,7 +287,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
             # ... and the generator runs on its own stream (datagen.SideStreamFeeder): batch i+1 is produced while the forward
             # and backward launches of step i run; the step's last launch waits for it
             from .datagen import FusedStaticGen, SideStreamFeeder
-            if FLAGS.cp and FusedStaticGen.supported(gen) and not eng._ride and not getattr(FLAGS, "no_fused_generator", False):
+            if FLAGS.cp and FusedStaticGen.supported(gen, eng) and not getattr(FLAGS, "no_fused_generator", False):
                 # round 5: static single-profile channels -- ONE C call per batch: the fused generator launch of the next batch
                 # + the four step launches, whose pipelined normalisation reads (y, noise, power partials) as its virtual
                 # input (include/dccn.h dccn_gen_static; datagen.FusedStaticGen).  Same batches as the loop below.

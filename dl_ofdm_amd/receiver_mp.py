@@ -281,19 +281,24 @@ class DeviceEpochLoop:
     step i normalises it on leading workgroups of its optimizer launch, so every step but the first of an epoch starts at
     the layer norm -- one launch (6 us) off a 21-launch chain.  Same kernels on the same data: bit-identical training."""
 
-    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int, overlap: bool = False, pipeline: Optional[bool] = None):
+    def __init__(self, FLAGS, ofdmobj, trainer, gen, pl, steps: int, overlap: bool = False, pipeline: Optional[bool] = None,
+                 arena=None):
+        """arena: the chain's :class:`~dl_ofdm_amd.arena.ChainArena` (chain groups, equalizer_group.py): every buffer a launch of
+        the loop touches is placed there"""
         import ctypes as C
         import torch
+        from . import arena as A
         from .equalizer import _FusedPlan
         self.C, self.torch = C, torch
         self.F, self.o, self.tr, self.gen, self.steps = FLAGS, ofdmobj, trainer, gen, int(steps)
+        self.arena = arena
         dev, B = trainer.device, pl.batch
         self.overlap = bool(overlap)
         if pipeline is None:
             pipeline = not self.overlap and bool(trainer.lib.dccn_eq_norm_rides(C.byref(pl.shape)))
         self.pipeline = bool(pipeline) and not self.overlap
         if self.pipeline:
-            self.pls = [pl, _FusedPlan(trainer, B, twin_of=pl)]
+            self.pls = [pl, _FusedPlan(trainer, B, twin_of=pl, arena=arena)]
             self.pls[0].pipe_with(self.pls[1], 0)
             self.pls[1].pipe_with(self.pls[0], 1)
         else:
@@ -302,10 +307,10 @@ class DeviceEpochLoop:
         self.per_symbol = 1 if (gen.doppler or gen.mixed) else 0
         hshape = (B, FLAGS.nsymbol, ofdmobj.K, 2) if self.per_symbol else (B, ofdmobj.K, 2)
         n = len(self.pls)
-        self.H = [torch.empty(*hshape, dtype=torch.float32, device=dev) for _ in range(n)]
-        self.npow = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(n)]
-        self.acc = torch.zeros(5, dtype=torch.float32, device=dev)
-        self.snr = torch.zeros(self.steps, B, dtype=torch.float32, device=dev)
+        self.H = [A.empty(arena, *hshape, dtype=torch.float32, device=dev) for _ in range(n)]
+        self.npow = [A.zeros(arena, 1, dtype=torch.float32, device=dev) for _ in range(n)]
+        self.acc = A.zeros(arena, 5, dtype=torch.float32, device=dev)
+        self.snr = A.zeros(arena, self.steps, B, dtype=torch.float32, device=dev)
         self.snr_rows = [self.snr[i] for i in range(self.steps)]
         # static channels (one profile, or mixRayleigh's frame-interleaved profiles without Doppler frames): the whole
         # generator chain of a batch is ONE launch + the launch that forms x (datagen.FusedStaticGen) instead of 5 to 12
@@ -313,7 +318,7 @@ class DeviceEpochLoop:
         if getattr(FLAGS, "fused_generator", True):
             from .datagen import FusedStaticGen
             if FusedStaticGen.supported(gen):
-                self.fg = FusedStaticGen(gen, B, 0.0, want_noise_power=gen.want_noise_power)
+                self.fg = FusedStaticGen(gen, B, 0.0, want_noise_power=gen.want_noise_power, arena=arena)
                 if self.fg.npow is not None:
                     self.npow = [self.fg.npow[k] for k in range(n)]
         # ... and in the pipelined loop the second of those launches goes too: the optimizer launch of step i reads batch i + 1
@@ -329,7 +334,7 @@ class DeviceEpochLoop:
             self.pls[0].pipe_with(self.pls[1], 0, virt=self.virt[0])
             self.pls[1].pipe_with(self.pls[0], 1, virt=self.virt[1])
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
-        self.ws = torch.zeros(self.nws, dtype=torch.uint8, device=dev)
+        self.ws = A.zeros(arena, self.nws, dtype=torch.uint8, device=dev)
         self.i = 0
         # the step as 21 eager launches per call (default) or as a hipGraph replay: 0.188 vs 0.196 ms per loop step (tools/eqloop.py
         # --graph 0 / 1; host issue 0.156 vs 0.125 ms) -- the replay costs the GPU 3-7 us per step, the eager calls cost the host 30
@@ -485,14 +490,16 @@ def _train_on_device(FLAGS, ofdmobj, trainer, batch_size, frame_cnt, verbose, ru
     best = BestSnapshot(trainer, os.path.join(FLAGS.save_dir, save_model_name(FLAGS)), FLAGS)
     try:
         for epoch in range(FLAGS.max_epoch_num):
-            np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))
+            # (a RandomState of its own -- the same values as np.random.seed + np.random.choice -- so that chains training in
+            # other threads of this process, config5.train_models, cannot interleave their draws with this one's)
+            rs = np.random.RandomState((FLAGS.seed + 1000003 * (epoch + 1)) & 0xFFFFFFFF)
             # :407 one draw for the epoch's frames (the same stream of values as `steps` draws of one batch each)
-            loop.begin_epoch(np.random.choice(TRAIN_SNR_GRID, [steps, batch_size], p=TRAIN_SNR_PROB))
+            loop.begin_epoch(rs.choice(TRAIN_SNR_GRID, [steps, batch_size], p=TRAIN_SNR_PROB))
             for i in range(steps):
                 loop.step()
             a = loop.epoch_means()
             train_loss_epoch = float(a[0])
-            snr = np.random.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)       # :438
+            snr = rs.choice(TRAIN_SNR_GRID, [FLAGS.eval_frames], p=TRAIN_SNR_PROB)              # :438
             tx, _ = gen.transmit(FLAGS.eval_frames, out_bits=ev.bits)
             gen.channel(tx, snr, out_x=ev.x)
             gen.offset += 1

@@ -37,7 +37,8 @@ typedef enum dccn_status {
     DCCN_ERR_WORKSPACE = -2,     /* workspace too small */
     DCCN_ERR_LAUNCH = -3,        /* hipLaunch / runtime error (see dccn_last_hip_error) */
     DCCN_ERR_NO_DEVICE = -4,     /* no gfx950 device visible */
-    DCCN_ERR_STATE = -5          /* plan used in the wrong state */
+    DCCN_ERR_STATE = -5,         /* plan used in the wrong state */
+    DCCN_ERR_UNSUPPORTED = -6    /* a grouped call (dccn_eq_*_grouped) reached a launch that cannot carry several chains */
 } dccn_status;
 
 const char* dccn_strerror(int status);
@@ -464,6 +465,11 @@ int dccn_rx_norm_rides_backward(const dccn_rx_shape* shape);
  * (large layers) and dccn_rx_buffers.prefetch_fwd moves the next batch's C-Conv forward next to that update; 0: prefetch_fwd
  * still works, but only reorders launches on one stream */
 int dccn_rx_prefetch_pays(const dccn_rx_shape* shape);
+/* 1: a training step of this shape takes dccn_rx_buffers.gen_next (the next batch formed from the fused generator's
+ * (y, noise, partials) by the pipelined R0 on the optimizer launch): single-buffer pipelining, batch <= 1536 frames, one power
+ * partial per generator block.  0: generate with dccn_gen_static_frames / _apply (or the launch-per-stage generator) and hand
+ * the batch over as x_next.  A step given gen_next for a shape answering 0 is refused BEFORE anything is launched. */
+int dccn_rx_gen_next_supported(const dccn_rx_shape* shape);
 /* The backward half of the basic receiver's training step as one launch (small layers, see the query above):
  *   dfft = dz . Wd^T                     (dev/py/model.py:1268-1275 backward; written only when dfft != NULL)
  *   dWd  = fft_out^T . dz, dbd = colsum  (k-major tiles, split-K slabs)
@@ -668,6 +674,42 @@ int dccn_eq_workspace_tensor(const dccn_eq_shape* shape, int train, const char* 
 int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream);
 int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_adam_hparams hp,
                        dccn_stream_t stream);
+/* ---- chain groups: several independent equaliser training chains carried by ONE launch sequence ------------------------
+ * The reference driver trains one (receiver -> equaliser) chain per modulation and per cp / longcp variant, each as an OS process
+ * of its own (dev/py/run_local_ofdm.py:61-118, locals.py:28-38; the loop is ofdmreceiver_np_mp.py:394-466).  A 73-frame
+ * equaliser step is a chain of ~21 dependent launches that keeps a few percent of an MI355X busy; here n_chains (<=
+ * dccn_chain_group_max() = 8) such chains of the SAME shape share every launch: the chain index is a grid dimension and
+ * every kernel adds that chain's arena offset to its pointer arguments.  The chains may differ in modulation (nbits): the
+ * demodulation tail of the frozen receiver -- the only stage whose kernels depend on it -- is launched once per distinct nbits.
+ *
+ * Layout contract (checked; DCCN_ERR_INVALID_ARG otherwise): for every pointer field f of dccn_eq_buffers (and of the
+ * dccn_gen_static behind x_next_virtual), bufs[g]->f - bufs[0]->f is the SAME byte offset off[g] for all fields, a multiple of
+ * 256: each chain keeps ALL its device buffers in one arena with chain 0's internal layout (dl_ofdm_amd/equalizer.py
+ * ChainArena).  `prob` must be NULL; rx_folded must be given.  Every chain computes exactly what dccn_eq_train_step would
+ * compute for it alone: same kernels, same blocks, same summation orders -- bitwise equal parameters, Adam slots and
+ * metrics (tests/test_gpu_chain_groups.py).  n_chains == 1 is dccn_eq_train_step.
+ * dccn_eq_group_supported: 1 for the shapes whose step consists of group-capable launches only (<= 96 frames: the few-row plan);
+ * a grouped call that would reach any other launch returns DCCN_ERR_UNSUPPORTED before issuing it. */
+int dccn_chain_group_max(void);
+int dccn_eq_group_supported(const dccn_eq_shape* shape);
+int dccn_eq_train_step_grouped(int n_chains, const dccn_eq_shape* const* shapes, const dccn_eq_buffers* const* bufs,
+                               dccn_adam_hparams hp, dccn_stream_t stream);
+/* the fused generator launch (dccn_gen_static_frames) / the launch that materialises x (dccn_gen_static_apply) for every chain of
+ * a group: per-chain seed, offset and nbits, same layout contract on the descriptors' pointers (x_out / noise_power included) */
+int dccn_gen_static_frames_grouped(int n_chains, const dccn_gen_static* const* g, dccn_stream_t stream);
+int dccn_gen_static_apply_grouped(int n_chains, const dccn_gen_static* const* g, float* const* x_out, float* const* noise_power,
+                                  dccn_stream_t stream);
+/* dccn_eq_monitor_accumulate for every chain of a group (arguments as that function's, one struct per chain) */
+typedef struct dccn_eq_monitor {
+    const float* chest; const float* chan;
+    int chan_per_symbol, B, S, K;
+    const dccn_metrics* metrics;
+    const float* tx_power; const float* noise_power;
+    float* acc5; float* rms_out;
+    void* workspace; size_t workspace_bytes;
+} dccn_eq_monitor;
+int dccn_eq_monitor_accumulate_grouped(int n_chains, const dccn_eq_monitor* const* m, dccn_stream_t stream);
+
 /* mode bit0: train.  The handle is a dccn_rx_graph: launch / destroy it with dccn_rx_graph_launch /
  * dccn_rx_graph_destroy. */
 int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,

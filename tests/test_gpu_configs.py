@@ -152,6 +152,34 @@ def test_bench_two_ranks_over_gloo_one_json_line():
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 * 8190 / (out["ms_per_step"] * 6e-3)) <= 1e-6 * out["value"]
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): the bench re-runs itself
+    under torch.distributed.run, two ranks (gloo here, so that both may share this box's GPU), one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env.update(DCCN_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-kernel-times", "--no-other-configs", "--no-e2e", "--sweep-frames", "1000"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["distributed"]["world"] == 2 and out["sweep"]["points_per_rank"] == [20, 20]
+    assert "NOT trained" in out["sweep"]["receiver"]
+
+
+def test_bench_watchdog_turns_a_hang_into_an_exit_code():
+    """a rendezvous that never completes (rank 1 of 2 never starts) ends with rc 3 and a message, not a hang"""
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE",)}
+    env.update(DCCN_BENCH_BACKEND="gloo", DCCN_BENCH_INIT_TIMEOUT="8", RANK="0", WORLD_SIZE="2", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "did not complete within" in r.stderr
+
+
 def _two_gpus():
     return torch.cuda.is_available() and torch.cuda.device_count() >= 2
 
@@ -223,6 +251,26 @@ def test_config5_sweep_tool_share_ranks_on_one_gpu(tmp_path):
     tj = json.load(open(str(tmp_path / "shared" / "config5_timing.json")))
     assert tj["world"] == 3 and tj["backend"] == "gloo" and tj["hw_queues_per_process"] == "1"
     assert json.load(open(str(tmp_path / "one" / "config5_timing.json")))["hw_queues_per_process"] == "runtime default"
+
+
+def test_config5_chains_on_streams_of_one_process_equal_the_serial_run(tmp_path):
+    """config 5's training chains next to each other in ONE process (a host thread + HIP stream per chain: the default) against
+    the same chains one after the other (--chain_streams 1), scaled down: every chain draws from generators of its own, so the
+    CSV -- 4 trained receiver + equaliser pairs evaluated on every point -- is the same bytes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DCCN_BENCH_BACKEND", "DCCN_DIST_BACKEND", "RANK", "WORLD_SIZE",
+                                                            "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    common = ["--frames", "1000", "--eq_epochs", "5", "--rx_epoch_scale", "0.01", "--classical_frames", "30",
+              "--snrs=-5,10,29", "--classical_every", "2"]
+    tool = os.path.join(ROOT, "tools", "config5_sweep.py")
+    runs = {}
+    for name, extra in (("streams", []), ("serial", ["--chain_streams", "1"])):
+        r = subprocess.run([sys.executable, tool, "--out", str(tmp_path / name)] + common + extra, cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[name] = open(str(tmp_path / name / "config5_ber.csv")).read()
+        tj = json.load(open(str(tmp_path / name / "config5_timing.json")))
+        assert tj["per_rank_seconds"][0]["chain_streams"] == (4 if name == "streams" else 1)
+    assert runs["streams"] == runs["serial"] and runs["serial"].count("\n") == 1 + 4 * 3 * 3
 
 
 def _c5_worker(rank, world, port, out_dir, q, kw, classical_every=2):

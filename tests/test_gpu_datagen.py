@@ -478,3 +478,40 @@ def test_generated_step_refuses_the_double_buffered_plan_and_apply_takes_no_nois
     _, _, npow = fg.make_batch(x, bits, slot=0)
     torch.cuda.synchronize()
     assert npow is None and torch.isfinite(x).all() and float(x.abs().max()) > 0
+
+
+def test_generated_step_beyond_the_single_pass_normalisation_is_refused_before_anything_runs():
+    """receiver.train grows its batch with falling BER (ideal_batch_size: 2045 frames once BER < ~3e-4 at BPSK); the pipelined
+    normalisation forms a batch from the fused generator's output for <= 1536 frames only.  The query says so
+    (dccn_rx_gen_next_supported, FusedStaticGen.supported(gen, eng)), a step handed gen_next anyway returns
+    DCCN_ERR_INVALID_ARG with NOTHING launched -- parameters, Adam slots and the step counter untouched -- and the harness's
+    loop trains such batches through the materialised path."""
+    import ctypes as C
+    from dl_ofdm_amd import ofdm, receiver as R
+    from dl_ofdm_amd.datagen import DeviceDataGen, FusedStaticGen
+    from dl_ofdm_amd.engine import RxEngine
+    F = flags(nbits=1, channel="AWGN")
+    o = ofdm.ofdm_tx(F)
+    dims = R.rx_dims(F, o)
+    small = RxEngine(dims, 1536, train=True, seed=1, want_prob=False, want_z=False)
+    big = RxEngine(dims, 2045, train=True, seed=1, want_prob=False, want_z=False)
+    gen = DeviceDataGen(F, o, seed=3)
+    assert FusedStaticGen.supported(gen) and FusedStaticGen.supported(gen, small) and not FusedStaticGen.supported(gen, big)
+    fg = FusedStaticGen(gen, 2045, 10.0)
+    fg.make_batch(big.x, big.label_slot(0), 0)
+    big.prime()
+    torch.cuda.synchronize()
+    before = [t.clone() for t in (big.params, big.adam_m, big.adam_v, big.adam_state)]
+    d = fg.arm(big.label_slot(1), 1)
+    bufs = big._pipe_buffers(0, False, 0, False, 1, 0, C.addressof(d), False)
+    rc = big.lib.dccn_rx_train_step(C.byref(big.shape), C.byref(bufs), big.hp, big._stream())
+    torch.cuda.synchronize()
+    assert rc == -1                                                 # DCCN_ERR_INVALID_ARG
+    for a, b in zip(before, (big.params, big.adam_m, big.adam_v, big.adam_state)):
+        assert torch.equal(a, b)
+    # the harness at a batch beyond the range: BPSK on AWGN at 10 dB reaches 2045 frames within a few epochs
+    Ft = R.Flags(nbits=1, nfilter=64, channel="AWGN", SNR=10.0, max_epoch_num=6, early_stop=200, token="big_batch",
+                 save_dir="/tmp/dccn_big_batch/", device_data=True, seed=1)
+    res = R.train(Ft, device="cuda", verbose=False, run_test=False)
+    assert len(res["history"]) == 6 and np.isfinite(res["history"][-1]["train_loss"])
+    assert max(h.get("batch_size", 0) for h in res["history"]) > 1536 or res["history"][-1]["test_ber"] > 3e-4

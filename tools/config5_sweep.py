@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--classical_every", type=int, default=3)
     ap.add_argument("--share", type=int, default=0, help="started as ONE process: re-launch as this many gloo ranks sharing the "
                                                           "visible GPU(s) (the four training chains run side by side)")
+    ap.add_argument("--chain_streams", type=int, default=-1,
+                    help="training chains a rank runs next to each other, each in a thread with a HIP stream of its own "
+                         "(default: all the chains the rank owns; 1: one after the other -- same results)")
     a = ap.parse_args()
     if a.share > 1 and "RANK" not in os.environ:
         import subprocess
@@ -51,7 +54,8 @@ def main():
     config5.run(a.out, a.frames, a.eq_epochs, a.classical_frames, a.rx_epoch_scale,
                 nbits_list=tuple(int(v) for v in a.nbits.split(",")), channels=tuple(a.channels.split(",")), snrs=snrs,
                 classical_every=a.classical_every, rank=rank, world=world,
-                device="cuda:%d" % local, ckpt_dir=a.ckpt_dir or tempfile.mkdtemp(prefix="dccn_c5_"))
+                device="cuda:%d" % local, ckpt_dir=a.ckpt_dir or tempfile.mkdtemp(prefix="dccn_c5_"),
+                chain_streams=None if a.chain_streams < 0 else a.chain_streams)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -54,7 +54,7 @@ def main():
 
     from dl_ofdm_amd.datagen import FusedStaticGen
     modes = [("device-generated, one stream", run), ("device-generated, generator on a side stream", run_overlapped)]
-    if FusedStaticGen.supported(gen) and not eng._ride:
+    if FusedStaticGen.supported(gen, eng):
         fg = FusedStaticGen(gen, a.frames, F.SNR)
         cnt = [0]
 

@@ -31,6 +31,47 @@ def step_flops(B, S=7, K=64, n_sc=80, F=64, D=320):
     return 2.0 * (3 * eq + 2 * rx)
 
 
+def bench_chains(a):
+    """wall time per lock-step training step of G chains (three C calls: fused generator, fused step, monitor) against the same
+    loop of ONE chain (receiver_mp.DeviceEpochLoop.step), same process; 73-frame batches, mixRayleigh"""
+    import time
+    from dl_ofdm_amd.equalizer_group import EqualizerChainGroup
+    B = 73
+    base = None
+    for G in ([] if a.only_group else [1]) + [g for g in a.chains if g > 1 or a.only_group]:
+        fl = [H.Flags(nbits=a.mods[i % len(a.mods)], nfilter=64, channel="mixRayleigh", device_data=True, seed=10 + i,
+                      token="eqb%d" % i, save_dir="/tmp/dccn_eqbench/") for i in range(G)]
+        rx = [glorot_init(rx_dims(F, ofdm.ofdm_tx(F)), 1 + i) for i, F in enumerate(fl)]
+        grp = EqualizerChainGroup(fl, rx)
+        act = grp.chains
+        steps = act[0].steps
+        for c in act:
+            c.begin_epoch()
+        if G == 1:
+            fn = lambda i: act[0].loop.step()        # noqa: E731  (the solo loop of receiver_mp._train_on_device)
+        else:
+            fn = lambda i: grp.step(act, i % steps)  # noqa: E731
+        for i in range(steps):                       # one whole epoch as warm-up (the loop's first step materialises its batch)
+            fn(i)
+        torch.cuda.synchronize()
+        n = steps * max(1, a.steps // steps)          # whole epochs
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        sym = G * n * B * 7 / wall
+        if G == 1:
+            base = sym
+        print(json.dumps(dict(path="epoch-loop", chains=G, mods=[F.nbits for F in fl], frames=B, steps=n,
+                              ms_per_group_step=round(wall / n * 1e3, 4), host_issue_ms_per_group_step=round(host / n * 1e3, 4),
+                              symbols_per_s=round(sym), vs_one_chain=round(sym / base, 3) if base else None,
+                              tflops=round(G * step_flops(B) * n / wall / 1e12, 2))), flush=True)
+        del grp, act
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, nargs="+", default=[73, 1170])
@@ -40,7 +81,14 @@ def main():
     ap.add_argument("--ab", default="", help="KEY=V1,V2,..: time the eager fused step under each value of a dccn_set_tuning "
                                              "key, alternating inside this process (boxes differ; only this decides)")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--chains", type=int, nargs="*", default=[],
+                    help="also time G chains per launch sequence (dccn_eq_train_step_grouped; modulations cycle through --mods): "
+                         "the training loop of dl_ofdm_amd.equalizer_group (generator + step + monitor), per group step")
+    ap.add_argument("--mods", type=int, nargs="+", default=[1, 2, 3, 4])
+    ap.add_argument("--only-group", action="store_true", help="--chains: skip the one-chain reference loop (profiles)")
     a = ap.parse_args()
+    if a.chains:
+        return bench_chains(a)
     F = H.Flags(nbits=2, nfilter=64, channel="EPA")
     tx = ofdm.ofdm_tx(F)
     tr = EqualizerTrainer(F, tx, glorot_init(rx_dims(F, tx), 1), seed=1)

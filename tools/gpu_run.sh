@@ -17,6 +17,7 @@
 #   eq | eqkt | eqab:<k=v0,v1>     equaliser step bench (73 / 1170 frames) | its kernel-trace summaries | A/B of a tuning key
 #   eqloop | e2e | conv            equaliser epoch loop | generate-and-train loop | general-k C-Conv bench
 #   config5[:args]                 tools/config5_sweep.py at full size -> config5/
+#   chains[:args]                  tools/chainbench.py (G equaliser chains on G streams of one process)
 #   sh:<command>                   any shell command (output -> sh_<n>.txt)
 #   smoke                          __graft_entry__.smoke()
 TAG=${1:-r05}; shift
@@ -87,6 +88,15 @@ for ln in sys.stdin:
     conv)   timeout 600 python tools/convbench.py 2>&1 | grep -v amdgpu.ids | tee $O/convbench.jsonl | cut -c1-220 ;;
     config5)
       timeout 2400 python tools/config5_sweep.py --out $O/config5 --eq_epochs 0 $(echo $arg | tr ',' ' ') > $O/config5_run.log 2>&1; tail -3 $O/config5_run.log; cat $O/config5/config5_timing.json | head -40 ;;
+    eqgkt)
+      # kernel-trace summaries of the equaliser epoch loop: one chain, and G chains per launch sequence (arg: G, default 4)
+      G=${arg:-4}
+      timeout 600 rocprofv3 --kernel-trace --stats -d $O/eqg1_kt -o kt -- python tools/eqbench.py --chains 1 --steps 400 > $O/eqg1_kt.log 2>&1
+      python tools/profile_summary.py $(find $O/eqg1_kt -name "*.db" | head -1) 30 > $O/eqloop1_kernel_stats.txt 2>&1; rm -rf $O/eqg1_kt
+      timeout 600 rocprofv3 --kernel-trace --stats -d $O/eqg_kt -o kt -- python tools/eqbench.py --chains $G --only-group --steps 400 > $O/eqg_kt.log 2>&1
+      python tools/profile_summary.py $(find $O/eqg_kt -name "*.db" | head -1) 30 > $O/eqloop${G}_kernel_stats.txt 2>&1; rm -rf $O/eqg_kt
+      head -34 $O/eqloop1_kernel_stats.txt | cut -c1-150; head -34 $O/eqloop${G}_kernel_stats.txt | cut -c1-150 ;;
+    chains) timeout 900 python tools/chainbench.py $(echo $arg | tr ',' ' ') 2>&1 | grep -v amdgpu.ids | tee -a $O/chainbench.jsonl | cut -c1-260 ;;
     sh)     timeout 900 bash -c "$arg" 2>&1 | grep -v amdgpu.ids | tee -a $O/sh_$n.txt | tail -12 ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt ;;
     *) echo "unknown section $name" ;;
