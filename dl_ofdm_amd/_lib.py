@@ -143,6 +143,7 @@ SIGNATURES = {
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
     "dccn_rx_prefetch_pays": (_i, [POINTER(RxShape)]),
     "dccn_rx_gen_next_supported": (_i, [POINTER(RxShape)]),
+    "dccn_step_monitor_add": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dccn_chain_group_max": (_i, []),
     "dccn_eq_group_supported": (_i, [POINTER(EqShape)]),
     "dccn_eq_train_step_grouped": (_i, [_i, _vp, _vp, AdamHParams, _vp]),

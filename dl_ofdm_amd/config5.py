@@ -104,7 +104,8 @@ def _broadcast(t, src: int, group=None):
 
 def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs: int, rx_epoch_scale: float = 1.0,
                  rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
-                 timing: Optional[dict] = None, ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None):
+                 timing: Optional[dict] = None, ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None,
+                 chain_priority: bool = True, chain_group: Optional[int] = None):
     """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
     eq_epochs <= 0: the reference driver's cap of 4000 * nbits epochs (run_local_ofdm.py:96; early stopping ends it sooner).
 
@@ -136,22 +137,57 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         if owners[nbits] == rank:
             mine.append(nbits)
 
-    def chain(nbits):
-        rf, hf = flags[nbits]
-        t1 = time.time()
-        res = R.train(rf, device=device, verbose=False, run_test=False)
+    def chain(unit):
+        """a unit = one chain, or several chains whose equaliser stages train as ONE chain group (equalizer_group.py: one launch
+        sequence for all of them, each bit for bit its solo self); their receivers train one after the other first"""
+        grouped = not isinstance(unit, int)
+        unit = list(unit) if grouped else [unit]
+        # the group unit holds the chains with slack (smallest epoch budgets): it starts once the single chains' receivers are
+        # trained, so the chains everybody waits for at the end have the GPU (and the interpreter) nearly to themselves for that
+        # stage -- a scheduling choice only, every chain computes what it computes
+        if grouped and rx_gate is not None:
+            rx_gate.wait()
+        rx_res, t_rx = {}, {}
+        for nbits in unit:
+            t1 = time.time()
+            try:
+                rx_res[nbits] = R.train(flags[nbits][0], device=device, verbose=False, run_test=False)
+            finally:
+                if not grouped and rx_gate is not None:
+                    with gate_lock:
+                        gate_left[0] -= 1
+                        if gate_left[0] <= 0:
+                            rx_gate.set()
+            t_rx[nbits] = time.time() - t1
         t2 = time.time()
-        out = H.train(hf, device=device, verbose=False, run_test=False, rx_params=res["params"])
-        H.load_checkpoint(out["best_path"], out["trainer"], with_optimizer=False)
-        trainers[nbits] = (hf, out["trainer"])
-        if timing is not None:
-            timing["train_rx_%d" % nbits] = t2 - t1
-            timing["train_eq_%d" % nbits] = time.time() - t2
-        if verbose:
-            print("rank %d nbits %d: receiver %d epochs %.0f s, equaliser %d epochs %.0f s"
-                  % (rank, nbits, len(res["history"]), t2 - t1, len(out["history"]), time.time() - t2), flush=True)
+        if len(unit) == 1:
+            outs = [H.train(flags[unit[0]][1], device=device, verbose=False, run_test=False, rx_params=rx_res[unit[0]]["params"])]
+        else:
+            from .equalizer_group import train_group
+            outs = train_group([flags[b][1] for b in unit], [rx_res[b]["params"] for b in unit], device=device)
+        for nbits, out in zip(unit, outs):
+            H.load_checkpoint(out["best_path"], out["trainer"], with_optimizer=False)
+            trainers[nbits] = (flags[nbits][1], out["trainer"])
+            if timing is not None:
+                timing["train_rx_%d" % nbits] = t_rx[nbits]
+                timing["train_eq_%d" % nbits] = time.time() - t2
+            if verbose:
+                print("rank %d nbits %d: receiver %d epochs %.0f s, equaliser %d epochs %.0f s%s"
+                      % (rank, nbits, len(rx_res[nbits]["history"]), t_rx[nbits], len(out["history"]), time.time() - t2,
+                         " (group of %d)" % len(unit) if len(unit) > 1 else ""), flush=True)
 
     n_streams = len(mine) if chain_streams is None else max(1, min(int(chain_streams), len(mine)))
+    # chain_group: this many chains -- the ones with the smallest epoch budgets, the end of `mine` -- share ONE stream as a chain
+    # group; the others keep a stream each.  Default: two of four or more chains.
+    n_group = (2 if len(mine) >= 4 and n_streams > 1 else 0) if chain_group is None else int(chain_group)
+    n_group = n_group if 2 <= n_group <= len(mine) else 0
+    rx_gate = None
+    if n_group:
+        mine = mine[:len(mine) - n_group] + [tuple(mine[len(mine) - n_group:])]
+        n_streams = min(n_streams, len(mine))
+        if n_streams == len(mine) and len(mine) > 1:          # (every unit has its own thread: the gate cannot deadlock)
+            import threading
+            rx_gate, gate_lock, gate_left = threading.Event(), threading.Lock(), [len(mine) - 1]
     if n_streams <= 1:
         for nbits in mine:
             chain(nbits)
@@ -164,15 +200,21 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         for nbits in mine:
             todo.put(nbits)
 
+        # stream priority: the chains with the larger epoch budgets (4000 * nbits epochs, run_local_ofdm.py:96) are the ones the
+        # others wait for at the end -- the upper half of `mine` issues to HIGH-priority streams (their launches are dispatched
+        # first whenever two chains have work ready), so the critical path runs near its solo speed and the shorter chains
+        # fill the gaps.  Priorities only order dispatch: results do not depend on them.
+        high = set(u for u in mine[:(len(mine) + 1) // 2] if isinstance(u, int)) if chain_priority else set()
+
         def worker():
-            st = torch.cuda.Stream(device=device)
             try:
-                with torch.cuda.stream(st):
-                    while True:
-                        try:
-                            nbits = todo.get_nowait()
-                        except queue.Empty:
-                            break
+                while True:
+                    try:
+                        nbits = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    st = torch.cuda.Stream(device=device, priority=-1 if nbits in high else 0)
+                    with torch.cuda.stream(st):
                         chain(nbits)
                         st.synchronize()
             except BaseException as e:                  # noqa: BLE001 -- handed to the caller's thread
@@ -190,6 +232,7 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
     if timing is not None:
         timing["train_total"] = time.time() - t0
         timing["chain_streams"] = n_streams
+        timing["chain_group"] = n_group
     if world > 1:
         t3 = time.time()
         for nbits in sorted(owners, reverse=True):
@@ -307,7 +350,7 @@ def classical_curves(nbits_list: Sequence[int], channels: Sequence[str], csnr: S
 def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frames: int = 1500, rx_epoch_scale: float = 1.0,
         nbits_list: Sequence[int] = (1, 2, 3, 4), channels: Sequence[str] = CHANNELS, snrs: Sequence[int] = SNRS,
         classical_every: int = 3, rank: int = 0, world: int = 1, device="cuda", verbose: bool = True,
-        ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None):
+        ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None, chain_group: Optional[int] = None):
     """Train (chains dealt to ranks), sweep (points dealt to ranks), classical curves (units dealt to ranks); rank 0
     writes ``<out_dir>/config5_ber.csv`` and ``config5_timing.json`` (wall time per stage and rank).  Returns
     (points, BER per point)."""
@@ -323,13 +366,34 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     workers = classical_workers(nbits_list, world)
     early = len(workers) < max(world, 1)
     ctab = None
+    side = None
     if early:
         tc = time.time()
         ctab = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device, workers=workers,
                                 reduce=False)
         timing["classical_early"] = time.time() - tc
+    elif world == 1 and device is not None and (chain_streams is None or chain_streams > 1):
+        # one process: the classical units need no trained model either -- a host thread with a stream of its own computes them
+        # while the chains train (they carry their own seeds: who computes them, and when, does not change a digit)
+        import threading
+        import torch
+        box = {}
+
+        def classical_side():
+            tc = time.time()
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                    box["tab"] = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device,
+                                                  workers=workers, reduce=False)
+                    torch.cuda.current_stream(device).synchronize()
+            except BaseException as e:                  # noqa: BLE001 -- re-raised by the caller's thread
+                box["err"] = e
+            box["t"] = time.time() - tc
+
+        side = threading.Thread(target=classical_side, name="c5-classical")
+        side.start()
     trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
-                            timing=timing, ckpt_dir=ckpt_dir, chain_streams=chain_streams)
+                            timing=timing, ckpt_dir=ckpt_dir, chain_streams=chain_streams, chain_group=chain_group)
     t1 = time.time()
     pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world)
     ber, _ = sweep.ber_loss(table)
@@ -337,6 +401,12 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
     if verbose and rank == 0:
         print("DCCN sweep done: %d points, %.0f s since start" % (len(pts), time.time() - t0), flush=True)
     t2 = time.time()
+    if side is not None:
+        side.join()
+        if "err" in box:
+            raise box["err"]
+        ctab = box["tab"]
+        timing["classical_beside_training"] = box["t"]
     classical = classical_curves(nbits_list, channels, csnr, classical_frames, rank, world, device=device, workers=workers,
                                  table=ctab)
     timing["classical"] = time.time() - t2

@@ -1793,6 +1793,25 @@ int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_strea
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
+// the training loop's per-step monitors (ofdmreceiver_np.py:222-229 fetches ce_mean, tx_power and the noise power of every step
+// and averages them per epoch): acc3 += {ce_mean, tx_power, noise_power} in ONE single-thread launch instead of three framework
+// launches -- same float32 additions in the same order
+__global__ void step_monitor_add_kernel(const dccn_metrics* __restrict__ m, const float* __restrict__ tx_power,
+                                        const float* __restrict__ noise_power, float* __restrict__ acc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        acc[0] += m->ce_mean;
+        if (tx_power) acc[1] += tx_power[0];
+        if (noise_power) acc[2] += noise_power[0];
+    }
+}
+int dccn_step_monitor_add(const dccn_metrics* metrics, const float* tx_power, const float* noise_power, float* acc3,
+                          dccn_stream_t stream) {
+    if (!metrics || !acc3) return DCCN_ERR_INVALID_ARG;
+    DCCN_NO_CHAINS();
+    hipLaunchKernelGGL(step_monitor_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, metrics, tx_power, noise_power, acc3);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
+}
 // row = the record (a one-point table: no clearing launch in front of it)
 __global__ void metrics_table_set_kernel(const dccn_metrics* __restrict__ m, double* __restrict__ row) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {

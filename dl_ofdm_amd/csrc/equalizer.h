@@ -257,10 +257,16 @@ __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0,
         s_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
+    if (!s_last) return;
+    // the last block to arrive sums the per-block partials in block order (fixed order => deterministic).  Its threads fetch
+    // them side by side first: thread 0 walking <= 256 dependent device-scope loads was 8 of this launch's 12 us
+    __shared__ double part[256];
     __threadfence();
+    if (threadIdx.x < gridDim.x) part[threadIdx.x] = __hip_atomic_load(a.partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double tot = 0.0;
-    for (unsigned i = 0; i < gridDim.x; ++i) tot += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned i = 0; i < gridDim.x; ++i) tot += part[i];
     const float rms = (float)(tot / ((double)cols * (double)a.S));
     if (a.rms_out) *a.rms_out = rms;
     if (a.acc) {

@@ -125,6 +125,47 @@ def save_checkpoint(path: str, eng, FLAGS: Flags):
     return path
 
 
+class BestSnapshot:
+    """The best-train-loss model of ofdmreceiver_np.py:268-272, kept on the DEVICE: the reference calls ``saver.save`` every time
+    the epoch loss improves; here an improvement is a device-to-device copy of the four arenas and the file is written when
+    training ends (also when it ends with an exception: the epoch loop flushes in a ``finally``) and, checked once per epoch,
+    every ``interval`` seconds in between.  Writing the file on every improvement is 25 blocking device-to-host copies and a
+    7 MB archive -- hundreds of times per run, a third of a BPSK receiver's training time, and (chains training in threads of
+    one process, config5.train_models) time spent holding the interpreter lock.  The file holds the same bytes either way."""
+    NAMES = ("params", "adam_m", "adam_v", "adam_state")
+
+    def __init__(self, path: str, FLAGS, interval: float = 60.0):
+        self.path, self.FLAGS, self.interval = path, FLAGS, float(interval)
+        self.bufs, self.dirty, self.written, self.t_last = None, False, False, time.time()
+
+    def take(self, eng):
+        import torch
+        if self.bufs is None:
+            self.bufs = {n: torch.empty_like(getattr(eng, n)) for n in self.NAMES}
+        for n, b in self.bufs.items():
+            b.copy_(getattr(eng, n))
+        self.dirty = True
+        self.maybe_flush(eng)
+
+    def maybe_flush(self, eng):
+        if self.dirty and time.time() - self.t_last > self.interval:
+            self.flush(eng)
+
+    def flush(self, eng) -> str:
+        """write the snapshot (not the engine's current state) to ``path``; the engine is left as it was"""
+        if self.dirty:
+            import torch
+            with torch.no_grad():
+                cur = {n: getattr(eng, n).clone() for n in self.NAMES}
+                for n, b in self.bufs.items():
+                    getattr(eng, n).copy_(b)
+                save_checkpoint(self.path, eng, self.FLAGS)
+                for n, c in cur.items():
+                    getattr(eng, n).copy_(c)
+            self.dirty, self.written, self.t_last = False, True, time.time()
+        return self.path if self.written else ""
+
+
 def read_checkpoint_file(path: str) -> Dict[str, np.ndarray]:
     """<path>.npz, or -- when only the TensorFlow bundle <path>.index/.data-* exists (a receiver trained by
     the reference) -- that, mapped to the engine's layouts."""
@@ -271,115 +312,132 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
     feed = None
     fused = {}                       # batch size -> datagen.FusedStaticGen
     import torch
-    for epoch in range(FLAGS.max_epoch_num):
-        np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))           # reference: int(time.time()) + epoch
-        train_snr = FLAGS.SNR + np.repeat(snr_seq, frame_cnt // 8, axis=0)
-        n_use = train_snr.shape[0]
-        losses, pwrs, berl = [], [], 0.5
-        if gen is not None:
-            # every step draws its own batch on the GPU into the engine's buffers; the per-step scalars the
-            # reference fetches are accumulated on the device and read once per epoch (no per-step sync)
-            mview = eng.metrics_buf.view(torch.float32)              # dccn_metrics: [12] ce_mean, [13] berlin
-            acc = torch.zeros(3, dtype=torch.float32, device=eng.device)
-            steps = n_use // batch_size
-            # R0 is software-pipelined across the steps (RxEngine.train_step_pipelined): batch i+1 is generated into
-            # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
-            # ... and the generator runs on its own stream (datagen.SideStreamFeeder): batch i+1 is produced while the forward
-            # and backward launches of step i run; the step's last launch waits for it
-            from .datagen import FusedStaticGen, SideStreamFeeder
-            if FLAGS.cp and FusedStaticGen.supported(gen, eng) and not getattr(FLAGS, "no_fused_generator", False):
-                # round 5: static single-profile channels -- ONE C call per batch: the fused generator launch of the next batch
-                # + the four step launches, whose pipelined normalisation reads (y, noise, power partials) as its virtual
-                # input (include/dccn.h dccn_gen_static; datagen.FusedStaticGen).  Same batches as the loop below.
-                fg = fused.get(batch_size)
-                if fg is None:
-                    fg = fused[batch_size] = FusedStaticGen(gen, batch_size, FLAGS.SNR, want_noise_power=True)
-                eng.drop_prefetch()
+    # device-generated runs keep the best model on the device and write it at the end (BestSnapshot); host-generated runs save
+    # on every improvement as before
+    best = BestSnapshot(os.path.join(FLAGS.save_dir, FLAGS.token), FLAGS) if gen is not None else None
+    try:
+        for epoch in range(FLAGS.max_epoch_num):
+            np.random.seed(FLAGS.seed + 1000003 * (epoch + 1))           # reference: int(time.time()) + epoch
+            train_snr = FLAGS.SNR + np.repeat(snr_seq, frame_cnt // 8, axis=0)
+            n_use = train_snr.shape[0]
+            losses, pwrs, berl = [], [], 0.5
+            if gen is not None:
+                # every step draws its own batch on the GPU into the engine's buffers; the per-step scalars the
+                # reference fetches are accumulated on the device and read once per epoch (no per-step sync)
+                mview = eng.metrics_buf.view(torch.float32)              # dccn_metrics: [12] ce_mean, [13] berlin
+                acc = torch.zeros(3, dtype=torch.float32, device=eng.device)
+                steps = n_use // batch_size
+                # R0 is software-pipelined across the steps (RxEngine.train_step_pipelined): batch i+1 is generated into
+                # eng.x / the other label slot before step i is issued, and normalised behind step i's Adam update
+                # ... and the generator runs on its own stream (datagen.SideStreamFeeder): batch i+1 is produced while the forward
+                # and backward launches of step i run; the step's last launch waits for it
+                from .datagen import FusedStaticGen, SideStreamFeeder
+                if FLAGS.cp and FusedStaticGen.supported(gen, eng) and not getattr(FLAGS, "no_fused_generator", False):
+                    # round 5: static single-profile channels -- ONE C call per batch: the fused generator launch of the next batch
+                    # + the four step launches, whose pipelined normalisation reads (y, noise, power partials) as its virtual
+                    # input (include/dccn.h dccn_gen_static; datagen.FusedStaticGen).  Same batches as the loop below.
+                    fg = fused.get(batch_size)
+                    if fg is None:
+                        fg = fused[batch_size] = FusedStaticGen(gen, batch_size, FLAGS.SNR, want_noise_power=True)
+                    eng.drop_prefetch()
+                    # (the three per-step monitors go onto the epoch accumulators in ONE stream-ordered library launch: three
+                    # framework calls per step kept the interpreter lock for longer than the step's own C call, which is what
+                    # several chains training in threads of one process -- config5.train_models -- then queue up behind)
+                    mon = (eng.metrics_buf.data_ptr(), eng.tx_power.data_ptr(), (fg.npow[0].data_ptr(), fg.npow[1].data_ptr()),
+                           acc.data_ptr())
+                    for i in range(steps):
+                        eng.train_step_generated(fg, slot=i & 1, last=(i + 1 == steps))
+                        _lib.check(eng.lib.dccn_step_monitor_add(mon[0], mon[1], mon[2][i & 1], mon[3], eng._stream()),
+                                   "dccn_step_monitor_add")
+                    a = acc.cpu().numpy() / max(steps, 1)
+                    losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
+                    berl = eng.metrics()["berlin"]
+                    steps = 0                                            # (the loop below has nothing left to do)
+
+                # the generator's noise-power monitor is reused per batch: each batch's value goes to one of two preallocated
+                # slots (allocated on the main stream, never handed back to the caching allocator while a step may read them)
+                noise_slots = torch.zeros(2, 1, dtype=torch.float32, device=eng.device)
+
+                def make(slot, eng=eng, bs=batch_size):
+                    npow = _gen_into(gen, eng, FLAGS, ofdmobj, bs, FLAGS.SNR, slot=slot)
+                    if npow is None:
+                        return None
+                    noise_slots[slot].copy_(npow.reshape(1))
+                    return noise_slots[slot]
+                if feed is None or feed.eng is not eng:                  # one side stream + event pair per engine, not per epoch
+                    feed = SideStreamFeeder(eng, make)
+                else:
+                    feed.rebind(make)
+                noise_t = None
+                if steps:
+                    noise_t = make(0)
+                    eng.prime()
                 for i in range(steps):
-                    eng.train_step_generated(fg, slot=i & 1, last=(i + 1 == steps))
-                    acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power)
-                    acc[2:3].add_(fg.npow[i & 1])
-                a = acc.cpu().numpy() / max(steps, 1)
-                losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
-                berl = eng.metrics()["berlin"]
-                steps = 0                                            # (the loop below has nothing left to do)
-
-            # the generator's noise-power monitor is reused per batch: each batch's value goes to one of two preallocated
-            # slots (allocated on the main stream, never handed back to the caching allocator while a step may read them)
-            noise_slots = torch.zeros(2, 1, dtype=torch.float32, device=eng.device)
-
-            def make(slot, eng=eng, bs=batch_size):
-                npow = _gen_into(gen, eng, FLAGS, ofdmobj, bs, FLAGS.SNR, slot=slot)
-                if npow is None:
-                    return None
-                noise_slots[slot].copy_(npow.reshape(1))
-                return noise_slots[slot]
-            if feed is None or feed.eng is not eng:                  # one side stream + event pair per engine, not per epoch
-                feed = SideStreamFeeder(eng, make)
+                    last = i + 1 == steps
+                    noise_next = None if last else feed.next((i + 1) & 1)
+                    eng.train_step_pipelined(slot=i & 1, last=last, x_ready=None if last else feed.ready)
+                    _lib.check(eng.lib.dccn_step_monitor_add(eng.metrics_buf.data_ptr(), eng.tx_power.data_ptr(),
+                                                             None if noise_t is None else noise_t.data_ptr(), acc.data_ptr(),
+                                                             eng._stream()), "dccn_step_monitor_add")
+                    feed.step_issued()            # (after the monitor reads: the generator may now overwrite slot i & 1's values)
+                    noise_t = noise_next
+                if steps:
+                    a = acc.cpu().numpy() / max(steps, 1)
+                    losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
+                    berl = eng.metrics()["berlin"]
             else:
-                feed.rebind(make)
-            noise_t = None
-            if steps:
-                noise_t = make(0)
-                eng.prime()
-            for i in range(steps):
-                last = i + 1 == steps
-                noise_next = None if last else feed.next((i + 1) & 1)
-                eng.train_step_pipelined(slot=i & 1, last=last, x_ready=None if last else feed.ready)
-                acc[0:1].add_(mview[12:13]); acc[1:2].add_(eng.tx_power)
-                if noise_t is not None:
-                    acc[2:3].add_(noise_t)
-                feed.step_issued()            # (after the monitor reads: the generator may now overwrite slot i & 1's values)
-                noise_t = noise_next
-            if steps:
-                a = acc.cpu().numpy() / max(steps, 1)
-                losses, pwrs, noise_pwr = [float(a[0])], [float(a[1])], float(a[2])
-                berl = eng.metrics()["berlin"]
-        else:
-            xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
-            nb = n_use // batch_size
-            for i in range(nb):
-                sl = slice(i * batch_size, (i + 1) * batch_size)
-                if i == 0:
-                    eng.prime(xs[sl])
-                last = i + 1 == nb
-                eng.train_step_pipelined(next_x=None if last else xs[(i + 1) * batch_size:(i + 2) * batch_size],
-                                         bits=ys[sl], last=last)
-                m = eng.metrics()
-                losses.append(m["ce_mean"]); pwrs.append(m["tx_power"]); berl = m["berlin"]
-        train_loss_epoch = float(np.mean(losses))
-        new_bs = max(batch_size, ideal_batch_size(berl, FLAGS.nbits))
-        new_bs = min(new_bs, n_use)
-        if new_bs != batch_size:
-            eng = engine_for(new_bs, eng)
-            batch_size = new_bs
-        # per-epoch evaluation on fresh frames (:249-262)
-        ev.params.copy_(eng.params)
-        if gen is not None:
-            _gen_into(gen, ev, FLAGS, ofdmobj, FLAGS.eval_frames, FLAGS.SNR)
-            ev.eval_step()
-        else:
-            txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
-            ev.eval_step(txs, tys)
-        em = ev.metrics()
-        if FLAGS.iq_dump:
-            # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:256,264-265): first 2048 IQ pairs,
-            # fp16.  The reference writes them into its working directory every epoch; here they go to save_dir, on request.
-            from .session import monitor_tensors
-            mon = monitor_tensors(ev, FLAGS.SNR * np.ones(FLAGS.eval_frames), FLAGS.seed, epoch + 1)
-            os.makedirs(FLAGS.save_dir, exist_ok=True)
-            np.savetxt(os.path.join(FLAGS.save_dir, "%s_txiq.csv" % FLAGS.token), mon["iq_tx"][:2048].cpu().numpy(), delimiter=",")
-            np.savetxt(os.path.join(FLAGS.save_dir, "%s_rxiq.csv" % FLAGS.token), mon["iq_rx"][:2048].cpu().numpy(), delimiter=",")
-        history.append(dict(epoch=epoch, train_loss=train_loss_epoch, test_loss=em["ce_mean"], test_ber=em["berlin"],
-                            batch_size=batch_size))
-        if verbose:
-            print("Epoch: %d  Train Loss: %f  Tx Power: %f  Noise Power: %f | Test Loss: %f  Test BER: %.8f  next batch %d"
-                  % (epoch, train_loss_epoch, float(np.mean(pwrs)), noise_pwr, em["ce_mean"], em["berlin"], batch_size))
-        if train_loss_epoch < loss_min:                                # :268-272 (train loss selects the checkpoint)
-            epoch_min, loss_min = epoch, train_loss_epoch
-            best_path = save_checkpoint(os.path.join(FLAGS.save_dir, FLAGS.token), eng, FLAGS)
-        if epoch - FLAGS.early_stop > epoch_min:
-            break
+                xs, ys, noise_pwr = make_batch(FLAGS, ofdmobj, fading, n_use, train_snr)
+                nb = n_use // batch_size
+                for i in range(nb):
+                    sl = slice(i * batch_size, (i + 1) * batch_size)
+                    if i == 0:
+                        eng.prime(xs[sl])
+                    last = i + 1 == nb
+                    eng.train_step_pipelined(next_x=None if last else xs[(i + 1) * batch_size:(i + 2) * batch_size],
+                                             bits=ys[sl], last=last)
+                    m = eng.metrics()
+                    losses.append(m["ce_mean"]); pwrs.append(m["tx_power"]); berl = m["berlin"]
+            train_loss_epoch = float(np.mean(losses))
+            new_bs = max(batch_size, ideal_batch_size(berl, FLAGS.nbits))
+            new_bs = min(new_bs, n_use)
+            if new_bs != batch_size:
+                eng = engine_for(new_bs, eng)
+                batch_size = new_bs
+            # per-epoch evaluation on fresh frames (:249-262)
+            ev.params.copy_(eng.params)
+            if gen is not None:
+                _gen_into(gen, ev, FLAGS, ofdmobj, FLAGS.eval_frames, FLAGS.SNR)
+                ev.eval_step()
+            else:
+                txs, tys, _ = make_batch(FLAGS, ofdmobj, fading, FLAGS.eval_frames, FLAGS.SNR)
+                ev.eval_step(txs, tys)
+            em = ev.metrics()
+            if FLAGS.iq_dump:
+                # constellation dumps of the graph's monitor branch (ofdmreceiver_np.py:256,264-265): first 2048 IQ pairs,
+                # fp16.  The reference writes them into its working directory every epoch; here they go to save_dir, on request.
+                from .session import monitor_tensors
+                mon = monitor_tensors(ev, FLAGS.SNR * np.ones(FLAGS.eval_frames), FLAGS.seed, epoch + 1)
+                os.makedirs(FLAGS.save_dir, exist_ok=True)
+                np.savetxt(os.path.join(FLAGS.save_dir, "%s_txiq.csv" % FLAGS.token), mon["iq_tx"][:2048].cpu().numpy(), delimiter=",")
+                np.savetxt(os.path.join(FLAGS.save_dir, "%s_rxiq.csv" % FLAGS.token), mon["iq_rx"][:2048].cpu().numpy(), delimiter=",")
+            history.append(dict(epoch=epoch, train_loss=train_loss_epoch, test_loss=em["ce_mean"], test_ber=em["berlin"],
+                                batch_size=batch_size))
+            if verbose:
+                print("Epoch: %d  Train Loss: %f  Tx Power: %f  Noise Power: %f | Test Loss: %f  Test BER: %.8f  next batch %d"
+                      % (epoch, train_loss_epoch, float(np.mean(pwrs)), noise_pwr, em["ce_mean"], em["berlin"], batch_size))
+            if train_loss_epoch < loss_min:                                # :268-272 (train loss selects the checkpoint)
+                epoch_min, loss_min = epoch, train_loss_epoch
+                if best is not None:
+                    best.take(eng)                                         # (device snapshot; the file is written below)
+                else:
+                    best_path = save_checkpoint(os.path.join(FLAGS.save_dir, FLAGS.token), eng, FLAGS)
+            elif best is not None:
+                best.maybe_flush(eng)
+            if epoch - FLAGS.early_stop > epoch_min:
+                break
+    finally:
+        if best is not None:
+            best_path = best.flush(eng)                                # also on exceptions / KeyboardInterrupt
     if verbose:
         print("Training Done!, Best model saved to\n%s" % best_path)
     result = dict(history=history, best_path=best_path, params=eng.get_params())

@@ -252,6 +252,10 @@ int dccn_classical_detect(const float* Y, const float* G, const int* dat, const 
 /* One row of the sweep table {c00,c01,c10,c11,ce_sum,count} (float64, device): row6 += the metrics record of the
  * last step, stream-ordered, no host round trip (dev/py/ofdmreceiver_np.py:80-85 accumulates the same on the host). */
 int dccn_metrics_table_add(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
+/* acc3[0] += metrics->ce_mean; acc3[1] += *tx_power; acc3[2] += *noise_power (each nullable): the per-step monitors of the
+ * training loop (dev/py/ofdmreceiver_np.py:222-229) accumulated on the device in one stream-ordered launch. */
+int dccn_step_monitor_add(const dccn_metrics* metrics, const float* tx_power, const float* noise_power, float* acc3,
+                          dccn_stream_t stream);
 /* row6 = the record (the one-point table of a single evaluation: no clearing launch needed in front of it) */
 int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
 

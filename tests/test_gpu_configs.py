@@ -263,14 +263,16 @@ def test_config5_chains_on_streams_of_one_process_equal_the_serial_run(tmp_path)
               "--snrs=-5,10,29", "--classical_every", "2"]
     tool = os.path.join(ROOT, "tools", "config5_sweep.py")
     runs = {}
-    for name, extra in (("streams", []), ("serial", ["--chain_streams", "1"])):
+    for name, extra in (("streams", []), ("nogroup", ["--chain_group", "0"]), ("serial", ["--chain_streams", "1"])):
         r = subprocess.run([sys.executable, tool, "--out", str(tmp_path / name)] + common + extra, cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stderr[-3000:]
         runs[name] = open(str(tmp_path / name / "config5_ber.csv")).read()
         tj = json.load(open(str(tmp_path / name / "config5_timing.json")))
-        assert tj["per_rank_seconds"][0]["chain_streams"] == (4 if name == "streams" else 1)
-    assert runs["streams"] == runs["serial"] and runs["serial"].count("\n") == 1 + 4 * 3 * 3
+        # default: the two chains with the largest epoch budgets on a stream each, the other two as one chain group on a third
+        assert tj["per_rank_seconds"][0]["chain_streams"] == {"streams": 3, "nogroup": 4, "serial": 1}[name]
+        assert tj["per_rank_seconds"][0]["chain_group"] == (2 if name == "streams" else 0)
+    assert runs["streams"] == runs["serial"] == runs["nogroup"] and runs["serial"].count("\n") == 1 + 4 * 3 * 3
 
 
 def _c5_worker(rank, world, port, out_dir, q, kw, classical_every=2):

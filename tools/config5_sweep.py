@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--chain_streams", type=int, default=-1,
                     help="training chains a rank runs next to each other, each in a thread with a HIP stream of its own "
                          "(default: all the chains the rank owns; 1: one after the other -- same results)")
+    ap.add_argument("--chain_group", type=int, default=-1,
+                    help="this many of a rank's chains (those with the smallest epoch budgets) train their equalisers as ONE chain "
+                         "group on one stream (default: 2 of >= 4 chains; 0: none -- same results)")
     a = ap.parse_args()
     if a.share > 1 and "RANK" not in os.environ:
         import subprocess
@@ -55,7 +58,8 @@ def main():
                 nbits_list=tuple(int(v) for v in a.nbits.split(",")), channels=tuple(a.channels.split(",")), snrs=snrs,
                 classical_every=a.classical_every, rank=rank, world=world,
                 device="cuda:%d" % local, ckpt_dir=a.ckpt_dir or tempfile.mkdtemp(prefix="dccn_c5_"),
-                chain_streams=None if a.chain_streams < 0 else a.chain_streams)
+                chain_streams=None if a.chain_streams < 0 else a.chain_streams,
+                chain_group=None if a.chain_group < 0 else a.chain_group)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
