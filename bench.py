@@ -48,11 +48,8 @@ CONFIGS = {
 
 
 def pipeline_plan(eng):
-    """what a pipelined step launches under the library's current plan (dccn_rx_norm_rides_backward: 0 / 1 / 2)"""
+    """what a pipelined step launches under the library's current plan (dccn_rx_norm_rides_backward: 0 / 1)"""
     ride = int(getattr(eng, "_ride", 0))
-    if ride == 2:
-        return ("3 launches per step: dense fwd + tail | fused backward + R0 of the next batch | "
-                "optimizer + C-Conv fwd of the next batch")
     if ride == 1:
         return "4 launches per step: C-Conv fwd | dense fwd + tail | fused backward + R0 of the next batch | optimizer"
     return "4 launches per step: C-Conv fwd | dense fwd + tail | fused backward | optimizer + R0 of the next batch"
@@ -405,6 +402,20 @@ def measure_e2e(dev, c, steps=200, warmup=30, channel="EPA", snr_db=10.0):
             "ce_mean_last": m["ce_mean"], "ber_last": m["berlin"]}
 
 
+def traffic_for(path: str, config: str, op: str, build_id: str):
+    """(HBM bytes per launch of `op` from the PMC passes kept in `path`, stale?, the file's build id): the counters are
+    collected by separate rocprofv3 --pmc runs (tools/gpu_run.sh pmc -> tools/pmc_summary.py) and stamped with the id of the
+    library they were collected on; they are reported only for THAT library -- for any other build the line says null + stale"""
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, False, None
+    file_id = rec.get("build_id")
+    if file_id != build_id:
+        return None, True, file_id
+    return rec.get(config, {}).get(op), False, file_id
+
+
 def launch_ranks(n: int) -> int:
     """Re-run this command line as `n` ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port); the
     children see WORLD_SIZE and take the normal path.  Returns the launcher's exit code."""
@@ -656,16 +667,12 @@ def main():
                 in_step = ("cconv_fwd", dfw, "dense_bwd_slabs", "cconv_bwd_w")
             gemm = {k: v for k, v in kt.items() if k in in_step}
             dom = max(gemm, key=lambda k: gemm[k]["ms"])
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
-                except Exception:
-                    traffic = None
+            traffic, stale, build = traffic_for(os.environ.get("DCCN_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "pmc_traffic.json")),
+                                                args.config, dom, lib.dccn_build_id().decode())
             result["roofline"] = {"bound": "mfma", "kernel": kt[dom]["kernel"], "op": dom,
                                   "achieved": kt[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": kt[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                                  "traffic_stale": stale, "traffic_build_id": build, "build_id": lib.dccn_build_id().decode(),
                                   "avg_launch_us": kt[dom]["ms"] * 1e3, "flops_per_launch": kt[dom]["flops"]}
         if world == 1 and args.config == "c2" and not args.no_other_configs:
             # the other BASELINE.json training configurations, measured in the same run (short: <= 20 steps each, hipGraph

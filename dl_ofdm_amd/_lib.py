@@ -52,7 +52,7 @@ class RxBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("x_norm_next", c_void_p), ("norm_slot", c_int),
                 ("keep_dense_grad", c_int), ("reg_uniform_dense", c_int), ("x_next_ready", c_void_p),
-                ("gen_next", c_void_p), ("prefetch_fwd", c_int)]
+                ("gen_next", c_void_p), ("tuning", c_void_p)]
 
 
 class GenStatic(C.Structure):
@@ -85,7 +85,8 @@ class EqBuffers(C.Structure):
                 ("rx_params", c_void_p), ("out_eq", c_void_p), ("chest", c_void_p), ("snr_db", c_void_p),
                 ("pilot_carriers", c_void_p), ("prob", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("reg_uniform", c_int), ("rx_folded", c_void_p),
-                ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int), ("x_next_virtual", c_void_p)]
+                ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int), ("x_next_virtual", c_void_p),
+                ("tuning", c_void_p)]
 
 
 class EqMonitor(C.Structure):
@@ -110,6 +111,7 @@ _vp, _i, _ll, _f, _sz = c_void_p, c_int, c_longlong, c_float, c_size_t
 SIGNATURES = {
     "dccn_strerror": (c_char_p, [_i]),
     "dccn_version": (_i, []),
+    "dccn_build_id": (c_char_p, []),
     "dccn_last_hip_error": (_i, []),
     "dccn_device_info": (_i, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, _i]),
     "dccn_batch_moment_norm_workspace_size": (_sz, [_i, _i]),
@@ -141,9 +143,10 @@ SIGNATURES = {
     "dccn_cconv_patch_supported": (_i, [_i] * 9),
     "dccn_cconv_patch_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "dccn_cconv_col2im": (_i, [_vp, _vp] + [_i] * 14 + [_vp]),
-    "dccn_rx_prefetch_pays": (_i, [POINTER(RxShape)]),
     "dccn_rx_gen_next_supported": (_i, [POINTER(RxShape)]),
     "dccn_step_monitor_add": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dccn_tuning_count": (_i, []),
+    "dccn_tuning_snapshot": (_i, [_vp, _i]),
     "dccn_chain_group_max": (_i, []),
     "dccn_eq_group_supported": (_i, [POINTER(EqShape)]),
     "dccn_eq_train_step_grouped": (_i, [_i, _vp, _vp, AdamHParams, _vp]),

@@ -46,7 +46,10 @@ static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) +
 // Kernel-configuration knobs (dccn_set_tuning): which tile configuration the GEMM-shaped operators launch.
 // 0 = the 32x32x2 family of gemm_f32_mfma.h, > 0 = a gemm16.h configuration (see the *_impl functions).
 enum TuneKey : int {
-    TUNE_DENSE_FWD = 0,         // fused dense forward + tail
+    // (keys 15, 16, 22, 23, 26 -- the optimizer launch that also ran the next C-Conv forward, Adam in the dW epilogue, non-temporal
+    // gradient loads, 160x64 / 128x64 dense + tail tiles, prefetch_fwd -- were built, measured without gain in rounds 3-5 and
+    // removed in round 6 together with their kernels; dccn_set_tuning refuses them)
+    TUNE_DENSE_FWD = 0,         // > 0: the dense forward runs with the demodulation tail in its epilogue (48x64 / 80x64 tiles)
     TUNE_DENSE_BWD = 1,         // grouped dX + dW
     TUNE_CCONV_FWD = 2,
     TUNE_CCONV_BWD_W = 3,
@@ -61,8 +64,6 @@ enum TuneKey : int {
     TUNE_BWD_PRIO = 12,         // s_setprio level (0-3) of the dX blocks of the fused backward launch
     TUNE_TAIL_FUSE_HI = 13,     // 8-QAM / 16-QAM tail inside the dense forward launch: bit 0 lane-per-cell forms, bit 1 quad-lane training
     TUNE_DW_GRADED = 14,        // > 0: graded k ranges for the dense dW items of the fused backward launch (preset number)
-    TUNE_FWD_PREFETCH = 15,     // 1: double-buffered pipelining also runs the next batch's C-Conv forward on the optimizer launch
-    TUNE_ADAM_IN_DW = 16,       // 1: large layers (unsplit dW tiles): the dense kernel's Adam update runs in the dW epilogue
     TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
     TUNE_NORM_ON_BWD = 18,      // 1 / 2: double-buffered pipelining: R0 of the next batch rides on the backward launch (leading / closing workgroups)
     TUNE_EQ_EPILOGUES = 19,     // equaliser step: tanh / tanh-gradient / gradient add in GEMM stores: 1 = the few-row GEMMs,
@@ -70,19 +71,23 @@ enum TuneKey : int {
     TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
                                 //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
     TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
-    TUNE_ADAM_NT = 22,          // 1: large arenas: the optimizer launch loads the gradient with non-temporal hints
-    TUNE_DENSE_FWD_BIG = 23,    // > 0: dense + tail variant of LARGE layers (14 / 15: 160x64 tiles, 16: 128x64) instead of 80x64
     TUNE_ADAM_OVERLAP = 25,     // 1: large layers: the dense kernel's Adam update runs on a second stream next to the C-Conv weight-gradient launch
                                 //    2: ... with non-temporal loads and stores (it must not displace the GEMM's operand panels)
     TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
-    TUNE_FWD_PREFETCH_BIG = 26, // 1: dccn_rx_prefetch_pays answers 1 for the shapes whose dense update runs on the second stream (off: no gain measured)
     TUNE_DENSE_RAGGED = 27,     // 1: large layers' fused dense + tail: a short last row tile (<= 32 rows) runs 32x64 blocks in the same grid
     TUNE_COUNT = 28
 };
-// (relaxed atomics: the knobs may be turned by one thread while another plans a launch)
+// The knobs are process-global DEFAULTS (relaxed atomics: one thread may turn them while another plans a launch); a call never
+// sees them change under it: every step / operator entry opens a TuneScope, which copies the table once -- from the plan's own
+// table when the caller captured one at plan creation (dccn_rx_buffers.tuning / dccn_eq_buffers.tuning, dccn_tuning_snapshot),
+// from the globals otherwise -- and everything the call plans reads that copy.
+thread_local int tl_whole_k = -1;
+thread_local int tl_tune_depth = 0;
+thread_local int tl_tune_vals[TUNE_COUNT];
 struct TuneTable {
     std::atomic<int> v[TUNE_COUNT];
-    int operator[](int k) const { return v[k].load(std::memory_order_relaxed); }
+    int operator[](int k) const { return tl_tune_depth > 0 ? tl_tune_vals[k] : v[k].load(std::memory_order_relaxed); }
+    int global(int k) const { return v[k].load(std::memory_order_relaxed); }
     void set(int k, int x) { v[k].store(x, std::memory_order_relaxed); }
 };
 // defaults = the fastest measured (A/B runs of tools/ab.py inside one process on one box, medians of 4-6 rounds of 300 steps;
@@ -98,11 +103,6 @@ struct TuneTable {
 //           steeper grading packs the grid's tail better although a fifth slab is written and summed -- backward launch
 //           33.1 -> 31.0 us in situ, optimizer 6.9 -> 7.2, step 74.4 -> 73.5 us ({8,5,3,2,1} 73.6, {9,5,3,2} 73.8, {10,5,3,1}
 //           73.7, six ranges 74.3-74.8, three ranges 76.3-77.4, two 80.8: gpurun_out/r05a, r05c-r05e);
-//   15 = 0  the optimizer launch that also runs the next batch's C-Conv forward (in-launch hand-off of the updated kernel,
-//           3 launches per step) is built and bitwise-tested but measured +1.4 us: poll + acquire + the serial fold -> tile
-//           chain (19.6 us) cost what the saved launch boundary gave (10.0 + 8.0 us as two launches);
-//   16 = 0  Adam in the dW epilogue of large layers: built, bitwise-tested, +4.7 % on the C4 step (5.21 vs 4.98 ms): the
-//           epilogue's per-row 128-byte accesses to p/m/v cost more than the 0.94 GB gradient round trip they save.
 //   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
 //   19 = 2  element-wise stages in GEMM stores: 73 frames 0.2688 -> 0.2663 ms (few-row tiles); 1170 frames 0.5276 -> 0.5247 ms
 //           (the stage costs the GEMM 8-10 us where the stand-alone launch cost 5: a small net gain);
@@ -110,13 +110,25 @@ struct TuneTable {
 //   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
 //           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
 //   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
-//   22 = 0  non-temporal gradient loads in the optimizer launch of large arenas: C4 step 4933 vs 4898 us -- slower, off;
-//   23 = 0  160x64 / 128x64 tiles for the fused dense + tail launch of large layers: C4 step 5012 / 5423 vs 4933 us with 80x64 -- off.
 //   24 = 1  equaliser step: Adam updates of dense_3 / dense_4 and the smoothing kernel's fold as riders of the bottleneck backward
 //           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
 //   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
 //           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
 static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}, {1}}};
+
+struct TuneScope {
+    explicit TuneScope(const int* plan = nullptr) {
+        if (tl_tune_depth++ == 0) {
+            for (int k = 0; k < TUNE_COUNT; ++k) tl_tune_vals[k] = plan ? plan[k] : g_tune.global(k);
+            tl_whole_k = tl_tune_vals[TUNE_WHOLE_K];
+        }
+    }
+    ~TuneScope() {
+        if (--tl_tune_depth == 0) tl_whole_k = -1;
+    }
+    TuneScope(const TuneScope&) = delete;
+    TuneScope& operator=(const TuneScope&) = delete;
+};
 
 // few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
 // the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
@@ -372,14 +384,6 @@ struct DeferredSlabs {
     const float* dw_slabs;
     const float* db_slabs;
     int splits;
-    bool adam_done = false;     // the dense kernel's optimizer update already ran in the dW epilogue
-};
-struct AdamEpi {               // what the dW epilogue needs to apply the update (arena pointers at the dense kernel)
-    float* p; float* m; float* v;
-    const float* reg; const float* gate;
-    const dccn_adam_state* state;
-    dccn_adam_hparams hp;
-    bool keep_grad;
 };
 static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
                             size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr, int ldx = 0) {
@@ -451,12 +455,11 @@ static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
 static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                   int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer,
-                                  const AdamEpi* ae = nullptr, int actx = 1, const float* aux = nullptr, bool* act_done = nullptr,
+                                  int actx = 1, const float* aux = nullptr, bool* act_done = nullptr,
                                   float* split_dst = nullptr, long long split_pairs_gc = 0, bool* split_done = nullptr) {
     if (act_done) *act_done = false;
     if (split_done) *split_done = false;
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
-    defer->adam_done = false;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
     GemmParams px = dense_bwd_x_params(dy, w, dx, M, K, N);
     GemmParams pw = gp_zero();                // dw[K,N] = x[M,K]^T . dy[M,N]
@@ -524,14 +527,6 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     if (vec && g_tune[TUNE_DENSE_BWD_BIG] && grouped_big_ok(px, pw, sp.splits)) {
         pw.ldc = N;
         if (sp.splits == 1) { pw.C = dw; pw.colsum = dbias; pw.slab = 0; }
-        if (sp.splits == 1 && ae != nullptr && g_tune[TUNE_ADAM_IN_DW]) {
-            // unsplit tiles hold the whole gradient: the optimizer update of the kernel happens in their epilogue
-            pw.ad_p = ae->p; pw.ad_m = ae->m; pw.ad_v = ae->v; pw.ad_reg = ae->reg; pw.ad_gate = ae->gate;
-            pw.ad_state = ae->state;
-            pw.ad_omb1 = 1.0f - ae->hp.beta1; pw.ad_omb2 = 1.0f - ae->hp.beta2; pw.ad_eps = ae->hp.eps;
-            if (!ae->keep_grad) pw.C = nullptr;
-            defer->adam_done = true;
-        }
         DCCN_TRY((launch_dense_bwd_grouped<true, 128, 128, 32>(px, pw, sp.splits, s)));
         defer->dw_slabs = sp.splits > 1 ? slabs : nullptr;
         defer->db_slabs = (sp.splits > 1 && dbias) ? cs : nullptr;
@@ -1013,9 +1008,7 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
 // ---------------------------------------------------------------------------------------
 static void dense_tail_tiles(int variant, int& bm, int& bn) {
     bn = 64;
-    bm = (variant == 5 || variant == 6) ? 64 : ((variant == 7 || variant == 8) ? 32 : (variant == 13 ? 80 : 48));
-    if (variant == 14 || variant == 15) bm = 160;
-    if (variant == 16) bm = 128;
+    bm = variant == 13 ? 80 : 48;
 }
 static int dense_tail_max_blocks(int M, int N) {
     const int b = ceil_div(M, 32) * ceil_div(N, 64);
@@ -1048,26 +1041,12 @@ static bool dense_tail_planned(int nbits, bool train, int M = 0, int N = 0) {
     return (nbits == 4 && train) ? (k & 2) != 0 : (k & 1) != 0;
 }
 
+// the two tile shapes the fused dense + tail launch runs: 48x64 with loads two k-tiles ahead (small layers), 80x64 (large layers)
 template <int NB, bool BWD>
 static int dense_tail_launch(int variant, const GemmParams& p, const TailEpiParams& tp, hipStream_t s) {
     const size_t sm = tune_smem_min();
-    switch (variant) {
-        case 1: return launch_dense_tail16<1, 4, 3, 1, 32, 1, NB, BWD>(p, tp, s, sm);     // 48x64
-        case 2: return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD>(p, tp, s, sm);
-        case 3: return launch_dense_tail16<1, 4, 3, 1, 64, 2, NB, BWD>(p, tp, s, sm);     // 8 waves: two k shares
-        case 4: return launch_dense_tail16<1, 4, 3, 1, 32, 2, NB, BWD>(p, tp, s, sm);
-        case 5: return launch_dense_tail16<2, 2, 2, 2, 32, 1, NB, BWD>(p, tp, s, sm);     // 64x64
-        case 6: return launch_dense_tail16<2, 2, 2, 2, 64, 2, NB, BWD>(p, tp, s, sm);
-        case 7: return launch_dense_tail16<2, 2, 1, 2, 32, 1, NB, BWD>(p, tp, s, sm);     // 32x64
-        case 8: return launch_dense_tail16<1, 4, 2, 1, 64, 2, NB, BWD>(p, tp, s, sm);
-        case 9: return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);  // 48x64, loads two k-tiles ahead
-        case 13: return launch_dense_tail16<1, 4, 5, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);    // 80x64 (large layers)
-        // large layers, two resident blocks per CU in ONE round: 585 rows = 4 row tiles of 160 x 125 column tiles = 500 blocks
-        case 14: return launch_dense_tail16<1, 4, 10, 1, 32, 1, NB, BWD, 2>(p, tp, s, sm);   // 160x64, 32-deep k-tiles
-        case 15: return launch_dense_tail16<1, 4, 10, 1, 32, 1, NB, BWD, 1>(p, tp, s, sm);
-        case 16: return launch_dense_tail16<1, 4, 8, 1, 32, 1, NB, BWD, 2>(p, tp, s, sm);    // 128x64
-        default: return DCCN_ERR_INVALID_ARG;
-    }
+    if (variant == 13) return launch_dense_tail16<1, 4, 5, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);    // 80x64 (large layers)
+    return launch_dense_tail16<1, 4, 3, 1, 64, 1, NB, BWD, 2>(p, tp, s, sm);                        // 48x64
 }
 
 // nbits >= 3: the two tile shapes the training / sweep steps use (every other variant number runs 48x64)
@@ -1088,12 +1067,9 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!dense_tail_ok(x, w, M, K, N, nbits)) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < dense_tail_ws_bytes(M, N, nbits)) return DCCN_ERR_WORKSPACE;
-    int variant = g_tune[TUNE_DENSE_FWD];
     // large layers (several rounds of 48x64 tiles): 80x64 tiles re-use the B tile for five row blocks instead of three
     // (C4: 1.42 -> 1.34 ms); the lane's ten cells go through the tail in two batches of five
-    if (variant == 9 && (long long)ceil_div(M, 48) * ceil_div(N, 64) >= 4LL * kCUs) variant = 13;
-    if (g_tune[TUNE_DENSE_FWD_BIG] && variant == 13 && nbits <= 2) variant = g_tune[TUNE_DENSE_FWD_BIG];
-    if (nbits >= 3 && variant != 13) variant = 9;
+    const int variant = ((long long)ceil_div(M, 48) * ceil_div(N, 64) >= 4LL * kCUs) ? 13 : 9;
     int bm, bn;
     dense_tail_tiles(variant, bm, bn);
     const int nblk = ceil_div(M, bm) * ceil_div(N, bn);
@@ -1352,6 +1328,7 @@ static bool rx_gen_next_shape_ok(int batch, int cols) {
 static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool train, dccn_adam_hparams hp,
                         hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (!shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
+    const TuneScope tune(b->tuning);
     if (!b->x || !b->bits || !b->params || !b->x_norm || !b->fft_out || !b->metrics) return DCCN_ERR_INVALID_ARG;
     if (train && (!b->grads || !b->adam_m || !b->adam_v || !b->adam || !b->dz)) return DCCN_ERR_INVALID_ARG;
     if (!b->workspace || b->workspace_bytes < rx_ws_bytes(sh, train ? 1 : 0)) return DCCN_ERR_WORKSPACE;
@@ -1361,7 +1338,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     void* ws_tail = c.take<char>(L.ws_tail);
     void* ws_dbw = train ? c.take<char>(L.ws_dense_bw) : nullptr;
     void* ws_cbw = train ? c.take<char>(L.ws_conv_bw) : nullptr;
-    unsigned* ws_sync = train ? reinterpret_cast<unsigned*>(c.take<char>(L.ws_sync)) : nullptr;
+    if (train) (void)c.take<char>(L.ws_sync);       // (reserved: keeps the workspace layout of earlier builds)
     float* P = b->params;
     float* G = b->grads;
     // step timeline (dccn_step_trace_enable): launch slots 1 C-Conv forward, 2 dense forward (+ tail), 3 tail (own launch),
@@ -1387,10 +1364,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             DCCN_TRY(gen_static_launch(b->gen_next, s));
         }
     }
-    // prefetch_fwd needs a batch normalised ahead by THIS call on the single-buffer pipelining (the double-buffered plan hands
-    // its forward over inside the optimizer launch: dccn_rx_norm_rides_backward == 2)
-    if (b->prefetch_fwd && (!train || (b->x_next == nullptr && b->gen_next == nullptr) || b->x_norm_next != nullptr))
-        return DCCN_ERR_INVALID_ARG;
     // R0 (+R8 partial sums) -- unless the previous call already normalised this batch behind its Adam update
     PowerPartials pp;
     const bool pre = train && b->x_prenormalised != 0;
@@ -1402,10 +1375,10 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(norm_impl(b->x, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &pp, sh->batch, L.cols, 1e-9f, 8.0f,
                            nullptr, hp, ws_norm, L.ws_norm, s, nslot));
     }
-    // R1 -- unless the previous call's optimizer launch already ran it on this batch (x_prenormalised == 2)
+    // R1
     trace.launch(1);
-    if (!(pre && b->x_prenormalised == 2))
-        DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
+    if (b->x_prenormalised != 0 && b->x_prenormalised != 1) return DCCN_ERR_INVALID_ARG;
+    DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
     TailFinalizeArgs fin;
     trace.launch(2);
     if (dense_tail_planned(sh->nbits, train, sh->batch, L.dN) &&
@@ -1461,9 +1434,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         memset(&nr, 0, sizeof(nr));
         if (ride_bw && wait_x) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
         if (ride_bw) {
-            // the update + prefetch launch of this step counts arrivals from zero and publishes into cleared flag words
-            fin.zero_word = ws_sync; fin.zero_flags = ws_sync + 64; fin.zero_stride = kFlagStride;
-            fin.n_zero_flags = ceil_div(L.rows, 64) * ceil_div(2 * sh->F, 64);
             PowerPartials np;
             norm_power_partials(sh->batch, L.cols, ws_norm, L.ws_norm, b->x_next, b->x_norm_next, &np, nslot ^ 1);
             nr.x = b->x_next; nr.y = b->x_norm_next; nr.power = b->tx_power ? const_cast<double*>(np.partial) : nullptr;
@@ -1484,40 +1454,26 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         DCCN_TRY(dense_bwd_x_impl(b->dz, P + L.o_dense_w, b->dfft, sh->batch, L.dK, L.dN, s));
     } else {
         // default: dense dX and dW/db in one grouped launch (independent GEMMs packed on the same grid)
-        // Large layers whose dW tiles are unsplit (N = 1024: 585 rows are one k range) apply the dense kernel's Adam update
-        // in the dW epilogue: the optimizer launch then skips 98 % of the arena and the 468 MB gradient never makes its
-        // round trip through HBM.  The update needs this step's alpha and BER gate, so the tail's slab reduction (which
-        // otherwise rides on the C-Conv weight-gradient launch further down) runs first, as a launch of its own.
-        AdamEpi ae;
-        const AdamEpi* aep = nullptr;
+        // Large layers whose dW tiles are unsplit (N = 1024: 585 rows are one k range): the dense kernel's Adam update runs as a
+        // launch of its own on the library's second stream next to the C-Conv weight-gradient launch.  It needs this step's
+        // alpha and BER gate, so the tail's slab reduction (which otherwise rides on the C-Conv weight-gradient launch further
+        // down) runs first, as a launch of its own.
         {
             const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
-            const long long bigx = (long long)ceil_div(sh->batch, 128) * ceil_div(L.dK, 128);
             const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
             // round 4: the same layers, the update as a launch of its own on the library's second stream, next to the C-Conv
             // weight-gradient launch (same precondition: alpha and the BER gate must exist before it starts)
-            if (g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
+            if (g_tune[TUNE_ADAM_OVERLAP] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
                 (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0 && overlap_streams(&ovs)) {
                 hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
                 DCCN_LAUNCH_CHECK();
                 fin.metrics = nullptr;
                 overlap = true;
             }
-            if (g_tune[TUNE_ADAM_IN_DW] && g_tune[TUNE_DENSE_BWD_BIG] && sp.splits == 1 && bigx >= 2 * kCUs && bigw >= 2 * kCUs &&
-                (L.o_dense_w % 4) == 0 && (((long long)L.dK * L.dN) % 4) == 0) {
-                hipLaunchKernelGGL(demod_tail_finalize_kernel, dim3(tail_finalize_blocks(fin.P)), dim3(256), 0, s, fin);
-                DCCN_LAUNCH_CHECK();
-                fin.metrics = nullptr;                       // the riding copy of this stage below becomes a no-op
-                ae.p = P + L.o_dense_w; ae.m = b->adam_m + L.o_dense_w; ae.v = b->adam_v + L.o_dense_w;
-                ae.reg = b->reg_coef ? b->reg_coef + L.o_dense_w : nullptr;
-                ae.gate = b->reg_coef ? &b->metrics->berlin : nullptr;
-                ae.state = b->adam; ae.hp = hp; ae.keep_grad = b->keep_dense_grad > 0;
-                aep = &ae;
-            }
         }
         DCCN_TRY(dense_bwd_grouped_impl(b->fft_out, b->dz, P + L.o_dense_w, b->dfft, G + L.o_dense_w, G + L.o_dense_b,
-                                        sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds, aep));
-        if (overlap && (ds.dw_slabs != nullptr || ds.adam_done)) overlap = false;
+                                        sh->batch, L.dK, L.dN, ws_dbw, L.ws_dense_bw, s, &ds));
+        if (overlap && ds.dw_slabs != nullptr) overlap = false;
         if (overlap) {
             // the optimizer kernel itself, restricted to the dense kernel's segment: same arithmetic, same results
             AdamRxArgs as;
@@ -1530,7 +1486,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             as.skip_lo = 0; as.skip_hi = as.o_dw;                 // (everything in front of the dense kernel stays with the main launch)
             as.splits = 1; as.neps = 1e-9f; as.npeak = 8.0f;
             as.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
-            as.nt = g_tune[TUNE_ADAM_OVERLAP] >= 2 ? 2 : ((g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0);
+            as.nt = g_tune[TUNE_ADAM_OVERLAP] >= 2 ? 2 : 0;
             long long sb = ceil_div_ll(ceil_div_ll(as.n, 4), 256);
             if (sb > 8 * kCUs) sb = 8 * kCUs;                     // (2, 4, 16 per CU measured within 0.5 % of this)
             DCCN_HIP(hipEventRecord(ovs.fork, s));
@@ -1549,8 +1505,7 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
                                   L.ws_conv_bw, s, &fin, can_defer ? &fd : nullptr));
     if (side) DCCN_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // (overlap: the dense kernel's update on the second stream is joined at the END of the call -- the optimizer launch below
-    // leaves that segment alone (skip_lo / skip_hi), reads the same read-only step state, and with prefetch_fwd the next batch's
-    // C-Conv forward runs next to the update as well)
+    // leaves that segment alone (skip_lo / skip_hi), reads the same read-only step state)
     // R7 (+ BER-gated L2 term of R6), fused with the split-K reduction of the dense gradient
     if (wait_x && !ride_bw) DCCN_HIP(hipStreamWaitEvent(s, (hipEvent_t)b->x_next_ready, 0));
     trace.launch(6);
@@ -1568,9 +1523,8 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     aa.skip_lo = aa.skip_hi = 0;
     aa.reg_uniform_dw = b->reg_uniform_dense != 0 ? 1 : 0;
     aa.skip_dw_grad = b->keep_dense_grad < 0 ? 1 : 0;          // the caller never reads the summed dense gradient
-    // large arenas (N = 1024: 0.47 GB of gradient, far beyond the 256 MB Infinity Cache) are pure streams
-    aa.nt = (g_tune[TUNE_ADAM_NT] && L.total > (1LL << 24)) ? 1 : 0;
-    if (ds.adam_done || overlap) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
+    aa.nt = 0;
+    if (overlap) { aa.skip_lo = L.o_dense_w; aa.skip_hi = L.o_dense_w + (long long)L.dK * L.dN; }
     aa.fold_blocks = fd.slabs ? ceil_div(sh->kin * sh->F + sh->F, fold_tilew > 0 ? kFoldLanesTiled : kRedLanes) : 0;
     long long blocks = ceil_div_ll(ceil_div_ll(L.total - (aa.fold_blocks ? aa.n_conv : 0), 4), 256);
     if (blocks > 8 * kCUs) blocks = 8 * kCUs;
@@ -1600,18 +1554,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
             aa.nv.npow_out = gen->noise_partial ? gen->noise_power_out : nullptr;
         }
     }
-    if (ride_bw && aa.fold_blocks > 0 && g_tune[TUNE_FWD_PREFETCH]) {
-        // the C-Conv forward of the batch the backward launch has just normalised rides on this launch (rx_bwd.h)
-        PrefetchFwdArgs f;
-        f.pc = gp_zero();
-        f.pc.A = b->x_norm_next; f.pc.B = P + L.o_conv_w; f.pc.C = b->fft_out; f.pc.bias = P + L.o_conv_b; f.pc.cbias = 1;
-        f.pc.M = L.rows; f.pc.N = 2 * sh->F; f.pc.K = 2 * sh->kin;
-        f.pc.lda = 2 * sh->kin; f.pc.ldb = 2 * sh->F; f.pc.ldc = 2 * sh->F;
-        f.pc.klen = round_k(2 * sh->kin); f.pc.cF = sh->F; f.pc.vecA = 1; f.pc.vecB = 1;
-        f.tiles = ceil_div(f.pc.M, 64) * ceil_div(f.pc.N, 64);
-        f.hw.counter = ws_sync; f.hw.flags = ws_sync + 64; f.hw.expected = (unsigned)aa.fold_blocks; f.hw.n_flags = f.tiles;
-        return launch_rx_update_prefetch(aa, hp, f, (int)(blocks - aa.fold_blocks), s);
-    }
     switch (ds.splits) {
         case 2: hipLaunchKernelGGL(adam_rx_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
         case 3: hipLaunchKernelGGL(adam_rx_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, aa, hp); break;
@@ -1627,13 +1569,6 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
         PowerPartials np;
         DCCN_TRY(norm_impl(b->x_next, b->x_norm, nullptr, nullptr, b->tx_power != nullptr, &np, sh->batch, L.cols, 1e-9f,
                            8.0f, nullptr, hp, ws_norm, L.ws_norm, s, nslot));
-    }
-    // prefetch_fwd: R1 of the batch just normalised into x_norm, with the C-Conv kernel just updated -- exactly the launch the
-    // next call would start with (it is told x_prenormalised = 2); fft_out is free: its last reader was the dense dW
-    if (b->prefetch_fwd) {
-        trace.launch(1);
-        DCCN_TRY(cconv_fwd_impl(b->x_norm, P + L.o_conv_w, P + L.o_conv_b, b->fft_out, L.rows, sh->kin, sh->F, s));
-        trace.none();
     }
     if (overlap) { ojoin.joined = true; DCCN_HIP(hipStreamWaitEvent(s, ovs.join, 0)); }
     return DCCN_OK;
@@ -1673,6 +1608,10 @@ const char* dccn_strerror(int status) {
 }
 
 int dccn_version(void) { return 100; }
+#ifndef DCCN_BUILD_ID
+#define DCCN_BUILD_ID "unknown"
+#endif
+const char* dccn_build_id(void) { return DCCN_BUILD_ID; }
 int dccn_last_hip_error(void) { return g_last_hip_error; }
 
 int dccn_device_info(int* cu_count, int* wavefront, size_t* hbm_bytes, char* arch, int arch_len) {
@@ -1827,13 +1766,22 @@ int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_strea
     return DCCN_OK;
 }
 
+static bool tune_key_live(int key) {
+    return key >= 0 && key < TUNE_COUNT && key != 15 && key != 16 && key != 22 && key != 23 && key != 26;
+}
 int dccn_set_tuning(int key, int value) {
-    if (key < 0 || key >= TUNE_COUNT || value < 0) return DCCN_ERR_INVALID_ARG;
+    if (!tune_key_live(key) || value < 0) return DCCN_ERR_INVALID_ARG;
     g_tune.set(key, value);
-    if (key == TUNE_WHOLE_K) g_whole_k = value;
+    if (key == TUNE_WHOLE_K) g_whole_k_global.store(value, std::memory_order_relaxed);
     return DCCN_OK;
 }
-int dccn_get_tuning(int key) { return (key < 0 || key >= TUNE_COUNT) ? DCCN_ERR_INVALID_ARG : g_tune[key]; }
+int dccn_get_tuning(int key) { return (key < 0 || key >= TUNE_COUNT) ? DCCN_ERR_INVALID_ARG : g_tune.global(key); }
+int dccn_tuning_count(void) { return TUNE_COUNT; }
+int dccn_tuning_snapshot(int* table, int n) {
+    if (!table || n < TUNE_COUNT) return DCCN_ERR_INVALID_ARG;
+    for (int k = 0; k < TUNE_COUNT; ++k) table[k] = g_tune.global(k);
+    return TUNE_COUNT;
+}
 
 size_t dccn_rx_backward_workspace_size(int batch, int S, int kin, int F, int D) {
     if (batch <= 0 || S <= 0 || kin <= 0 || F <= 0 || D <= 0) return 0;
@@ -1920,21 +1868,11 @@ int dccn_rx_norm_rides_backward(const dccn_rx_shape* sh) {
     const int cols = sh->S * sh->kin * 2;
     const bool ok = g_tune[TUNE_NORM_ON_BWD] && rx_bwd_fused_ok(sh->batch, sh->S, sh->kin, sh->F, sh->D, nullptr, nullptr, nullptr, nullptr) &&
                     kNormFusedCG == 2 && norm_fused_ok(nullptr, nullptr, sh->batch, cols);
-    return ok ? (g_tune[TUNE_FWD_PREFETCH] ? 2 : 1) : 0;
+    return ok ? 1 : 0;
 }
 int dccn_rx_gen_next_supported(const dccn_rx_shape* sh) {
     if (!shape_ok(sh) || dccn_rx_norm_rides_backward(sh) != 0) return 0;
     return rx_gen_next_shape_ok(sh->batch, sh->S * sh->kin * 2) ? 1 : 0;
-}
-int dccn_rx_prefetch_pays(const dccn_rx_shape* sh) {
-    if (!shape_ok(sh) || !g_tune[TUNE_FWD_PREFETCH_BIG]) return 0;
-    // the static part of rx_step_impl's `overlap` decision (the dense kernel's update on the second stream)
-    const RxLayout L = rx_layout(sh);
-    const SplitPlan sp = dense_dw_plan(sh->batch, L.dK, L.dN);
-    const long long bigw = (long long)ceil_div(L.dK, 128) * ceil_div(L.dN, 128);
-    const bool can_defer = L.o_conv_w == 0 && (L.o_dense_w % 4) == 0;
-    return (g_tune[TUNE_ADAM_OVERLAP] && !g_tune[TUNE_ADAM_IN_DW] && sp.splits == 1 && bigw >= 2 * kCUs && can_defer &&
-            (((long long)L.dK * L.dN) % 4) == 0) ? 1 : 0;
 }
 int dccn_rx_bwd_fused_supported(const dccn_rx_shape* sh) {
     if (!shape_ok(sh)) return 0;
@@ -2560,7 +2498,8 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
 }
 
 // ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
-static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208, "ctypes mirrors in dl_ofdm_amd/_lib.py");
+static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208 && sizeof(dccn_eq_buffers) == 192 &&
+              sizeof(dccn_eq_monitor) == 88, "ctypes mirrors in dl_ofdm_amd/_lib.py");
 int dccn_gen_static_supported(int S, int K, int CP) {
     return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
 }

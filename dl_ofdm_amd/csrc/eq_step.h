@@ -140,7 +140,7 @@ static int dense_bwd_full_impl(const float* x, const float* dy, const float* w, 
         DCCN_TRY(dense_bwd_w_impl(x, dy, dw, dbias, M, K, N, ws, ws_bytes, s, keep));
         return DCCN_OK;
     }
-    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds, nullptr, actx, aux, act_done,
+    DCCN_TRY(dense_bwd_grouped_impl(x, dy, w, dx, dw, dbias, M, K, N, ws, ws_bytes, s, &ds, actx, aux, act_done,
                                     split_dst, split_gc, split_done));
     if (keep) {
         *keep = ds;
@@ -171,6 +171,7 @@ static void eq_opt_dense(EqOptBuilder& ob, const EqDims& d, int i, const Deferre
 static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool train, dccn_adam_hparams hp,
                         hipStream_t s) {
     if (!eq_shape_ok(sh) || !b) return DCCN_ERR_INVALID_ARG;
+    const TuneScope tune(b->tuning);
     if (!b->x || !b->bits || !b->eq_params || !b->rx_params || !b->out_eq || !b->chest || !b->metrics)
         return DCCN_ERR_INVALID_ARG;
     if (train && (!b->eq_grads || !b->adam_m || !b->adam_v || !b->adam)) return DCCN_ERR_INVALID_ARG;

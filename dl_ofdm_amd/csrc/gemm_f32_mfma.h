@@ -74,19 +74,12 @@ struct GemmParams {
     // (graded ranges: long items first, short ones last, so that the grid's tail is made of short items)
     int nranges;
     int koff[9];
-    // optional optimizer epilogue (an UNSPLIT weight gradient of a large layer: the stored tile is the gradient of
-    // ad_p[row*ldc + col]): the TF-Adam update of norm_adam.h, same operations in the same order, applied to the tile while
-    // it is in registers -- the gradient needs no round trip through HBM and the optimizer launch skips the segment.
     // gemm16.h store epilogue with an element-wise stage (template parameter NB of EPI_STORE: 2 tanh, 3 v (1 - aux^2),
     // 4 v + aux): the other operand of stages 3 and 4, same shape and row stride as C
     const float* aux;
     float* out2; float* out3;   // gemm16.h EPI_STORE<5> (equalise stage): eq and corr next to C = h, aux = y
     long long gC;        // CMAP_SPLIT_PAIRS stores (gemm_store): elements between the two destination buffers
     PatchGeom pg;        // OP_KPATCH operand A
-    float* ad_p; float* ad_m; float* ad_v;
-    const float* ad_reg; const float* ad_gate;
-    const dccn_adam_state* ad_state;
-    float ad_omb1, ad_omb2, ad_eps;
     unsigned long long* stamp;   // step timeline stamps of this launch (common.h stamp_mark), nullptr = none
     // chain groups (common.h): the same launch for the chain whose arena lies `off` bytes behind chain 0's
     __device__ __forceinline__ GemmParams at_chain(const long long off) const {
@@ -94,8 +87,6 @@ struct GemmParams {
         q.A = chain_at(A, off); q.B = chain_at(B, off); q.C = chain_at(C, off);
         q.bias = chain_at(bias, off); q.colsum = chain_at(colsum, off);
         q.aux = chain_at(aux, off); q.out2 = chain_at(out2, off); q.out3 = chain_at(out3, off);
-        q.ad_p = chain_at(ad_p, off); q.ad_m = chain_at(ad_m, off); q.ad_v = chain_at(ad_v, off);
-        q.ad_reg = chain_at(ad_reg, off); q.ad_gate = chain_at(ad_gate, off); q.ad_state = chain_at(ad_state, off);
         return q;
     }
 };
@@ -342,7 +333,14 @@ __device__ __forceinline__ int xcd_tile(const int L, const int T) {
     const int xcd = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
-static std::atomic<int> g_whole_k{1};      // tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges
+// tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges.  A call that runs under a tuning snapshot
+// (dccn_abi.hip TuneScope: the plan's own table, or the globals as they stood when the call began) reads the snapshot's value
+static std::atomic<int> g_whole_k_global{1};
+extern thread_local int tl_whole_k;           // -1: no snapshot in force
+struct WholeK {
+    operator int() const { return tl_whole_k >= 0 ? tl_whole_k : g_whole_k_global.load(std::memory_order_relaxed); }
+};
+static const WholeK g_whole_k{};
 
 // The k-loop of one 64x64 / 128x128 output tile (block `L` of `T` tiles, split `z`) of C = A.B: leaves the tile in
 // `acc` (32x32 MFMA C layout per wave), its origin in (m0, n0) and the COLSUM partial in `cs`.  Ends with a block
@@ -546,25 +544,7 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const int z, con
                     bj = p.bias[col];
                 }
             }
-            if (p.ad_p != nullptr) {                           // (kernel argument: uniform) optimizer epilogue
-                const float alpha = p.ad_state->alpha;
-                const float gate = p.ad_gate ? p.ad_gate[0] : 1.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < p.M && col < p.N) {
-                        const size_t i = (size_t)row * p.ldc + col;
-                        const float g = acc[a][b][r] + bj;
-                        if (p.C != nullptr) Cz[i] = g;
-                        float pp = p.ad_p[i], mm = p.ad_m[i], vv = p.ad_v[i];
-                        const float ge = g + (gate * (p.ad_reg ? p.ad_reg[i] : 0.f)) * pp;
-                        mm += (ge - mm) * p.ad_omb1;
-                        vv += (ge * ge - vv) * p.ad_omb2;
-                        pp -= (mm * alpha) / (sqrtf(vv) + p.ad_eps);
-                        p.ad_p[i] = pp; p.ad_m[i] = mm; p.ad_v[i] = vv;
-                    }
-                }
-            } else if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
+            if (m0 + BM <= p.M && n0 + BN <= p.N) {            // interior tile (block-uniform): stores without exec masks
                 const size_t c0 = (size_t)(m0 + wm0 + a * 32 + 4 * h) * p.ldc + cmap_col<CMAP>(p, col);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -251,69 +251,6 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2,
     stamp_mark(px.stamp, 1);
 }
 
-// ---- optimizer launch that also runs the C-Conv forward of the NEXT batch -------------------------------------------
-// With R0 of the next batch done on the backward launch (above), the only thing its C-Conv forward still waits for is
-// the C-Conv kernel the optimizer is about to update: 10 368 parameters, produced by the first `fold_blocks` blocks of the
-// optimizer launch.  rx_update_prefetch_kernel runs both in ONE launch: the fold blocks publish their parameters
-// write-through and bump an arrival counter; each forward tile waits for the counter (one lane, relaxed poll), takes ONE
-// agent-scope acquire, and then runs the ordinary tile code with plain loads (cdna_hip_programming.md Guideline 16, recipe
-// R1: sc1 payload, every storing wave drains, one flag/counter word, one acquire per consumer block).  The rest of the
-// grid streams the dense / tail Adam update meanwhile.  A step is then three launches: dense forward + tail, backward,
-// update + next C-Conv forward.  Forward progress: the fold blocks have the lowest block indices and wait for nothing.
-struct PrefetchFwdArgs {
-    GemmParams pc;          // out[rows, 2F] = x_norm_next[rows, 2kin] . Weff (the updated kernel), bias pair
-    int tiles;
-    HandoffWords hw;        // counter zeroed by the backward launch of the same step; expected = fold_blocks; one flag per tile
-};
-
-template <int SPLITS>
-__global__ __launch_bounds__(256) void rx_update_prefetch_kernel(const AdamRxArgs a, const dccn_adam_hparams hp,
-                                                                 const PrefetchFwdArgs f) {
-    const int b = (int)blockIdx.x;
-    stamp_mark(a.stamp, 0);
-    if (b < a.fold_blocks) {
-        adam_fold_role<true>(a, hp, b, f.hw);
-        stamp_mark(a.stamp, 1);
-        return;
-    }
-    const int c = b - a.fold_blocks;
-    if (c < f.tiles) {
-        if (threadIdx.x == 0) {
-            // bounded spin (~1 s): a fold block that never arrives would mean a broken launch plan -- fail loudly, do not hang
-            const unsigned epoch = __builtin_bit_cast(unsigned, a.state->global_step);     // advanced by the backward launch
-            const unsigned* flag = f.hw.flags + (size_t)c * kFlagStride;                   // this block's own word
-            unsigned spins = 0;
-            __builtin_amdgcn_s_sleep(64);                          // the fold takes a couple of microseconds at least
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1u << 21)) __builtin_trap();
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        gemm_block<OP_KCONTIG, OP_CCONV_W, 64, 64, 32, 0, true>(f.pc, c, f.tiles, 0);
-        stamp_mark(a.stamp, 1);
-        return;
-    }
-    adam_stream_role<SPLITS>(a, hp, c - f.tiles, (int)gridDim.x - a.fold_blocks - f.tiles);
-    stamp_mark(a.stamp, 1);
-}
-
-static int launch_rx_update_prefetch(const AdamRxArgs& a, dccn_adam_hparams hp, const PrefetchFwdArgs& f, int stream_blocks,
-                                     hipStream_t s) {
-    constexpr size_t smem = gemm_smem_bytes<OP_KCONTIG, OP_CCONV_W, 64, 64, 32>();
-    const dim3 grid((unsigned)(a.fold_blocks + f.tiles + stream_blocks));
-    switch (a.splits) {
-        case 2: hipLaunchKernelGGL(rx_update_prefetch_kernel<2>, grid, dim3(256), smem, s, a, hp, f); break;
-        case 3: hipLaunchKernelGGL(rx_update_prefetch_kernel<3>, grid, dim3(256), smem, s, a, hp, f); break;
-        case 4: hipLaunchKernelGGL(rx_update_prefetch_kernel<4>, grid, dim3(256), smem, s, a, hp, f); break;
-        case 5: hipLaunchKernelGGL(rx_update_prefetch_kernel<5>, grid, dim3(256), smem, s, a, hp, f); break;
-        default: hipLaunchKernelGGL(rx_update_prefetch_kernel<0>, grid, dim3(256), smem, s, a, hp, f); break;
-    }
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
 template <int NU>
 static int launch_rx_bwd_fused(const GemmParams& px, const GemmParams& pw, const DweffArgs& de, int splits_w,
                                const NormRideArgs& nr, const TailFinalizeArgs& fin, dccn_adam_hparams hp, hipStream_t s) {

@@ -144,11 +144,7 @@ class RxEngine:
         # the backward launch (dccn.h: x_norm_next / norm_slot); `x_norm` stays the buffer plain steps use (parity 0)
         self._norm_bufs = [self.x_norm, None]
         self._norm_parity = 0
-        self._fwd_prefetched = False         # fft_out already holds the C-Conv forward of the prefetched batch
         self._ride = int(self.lib.dccn_rx_norm_rides_backward(C.byref(self.shape))) if train else 0
-        # large layers: the pipelined step also runs the NEXT batch's C-Conv forward, next to the dense kernel's update on the
-        # library's second stream (dccn_rx_buffers.prefetch_fwd)
-        self._prefetch_big = bool(self.lib.dccn_rx_prefetch_pays(C.byref(self.shape))) if train else False
         if self._ride:
             self._norm_bufs[1] = torch.empty_like(self.x_norm)
         # the same buffers in the pipelined mode (dccn.h: x_next / x_prenormalised), built on demand per (label slot, last)
@@ -185,10 +181,20 @@ class RxEngine:
             raise _lib.DccnError("%s while a prefetched batch is pending on this engine: finish the pipeline with "
                                  "train_step_pipelined(last=True) or discard it with drop_prefetch()" % what)
 
+    def pin_tuning(self):
+        """Capture the library's tuning table NOW as this engine's own (dccn_rx_buffers.tuning): later ``dccn_set_tuning`` calls
+        -- another thread's experiment, another plan's preference -- no longer reach this engine's steps."""
+        n = int(self.lib.dccn_tuning_count())
+        self._tune = (C.c_int * n)()
+        check(self.lib.dccn_tuning_snapshot(self._tune, n) - n, "dccn_tuning_snapshot")
+        self.buffers.tuning = C.addressof(self._tune)
+        self._pipe_bufs.clear()
+        self.close_graph()
+        return self
+
     def drop_prefetch(self):
         """Forget the batch a pipelined call has normalised ahead (the next pipelined call primes itself again)."""
         self._prefetch_pending = False
-        self._fwd_prefetched = False
         self._norm_ready = False
 
     def set_batch(self, x, bits):
@@ -217,7 +223,6 @@ class RxEngine:
         check(self.lib.dccn_rx_normalise(C.byref(self.shape), C.byref(self.buffers), self._stream()), "dccn_rx_normalise")
         self._norm_ready = True
         self._prefetch_pending = False
-        self._fwd_prefetched = False
         self._norm_parity = 0                # self.buffers names x_norm buffer 0 / partial-sum slot 0
 
     def label_slot(self, slot: int) -> torch.Tensor:
@@ -229,8 +234,8 @@ class RxEngine:
         return self.bits_alt
 
     def _pipe_buffers(self, slot: int, last: bool, parity: int = 0, double: bool = False, pre: int = 1,
-                      ready: int = 0, gen: int = 0, keep_x: bool = True, prefetch: bool = False) -> RxBuffers:
-        key = (slot, last, parity, double, pre, ready, gen, keep_x, prefetch)
+                      ready: int = 0, gen: int = 0, keep_x: bool = True) -> RxBuffers:
+        key = (slot, last, parity, double, pre, ready, gen, keep_x)
         if key not in self._pipe_bufs:
             vals = {f: getattr(self.buffers, f) for f, _ in RxBuffers._fields_}
             vals["bits"] = self.label_slot(slot).data_ptr()
@@ -241,7 +246,6 @@ class RxEngine:
             vals["norm_slot"] = parity
             vals["x_norm_next"] = self._norm_bufs[parity ^ 1].data_ptr() if (double and not last) else 0
             vals["x_next_ready"] = 0 if last else ready
-            vals["prefetch_fwd"] = 1 if (prefetch and not last) else 0
             self._pipe_bufs[key] = RxBuffers(*[vals[f] for f, _ in RxBuffers._fields_])
         return self._pipe_bufs[key]
 
@@ -272,21 +276,16 @@ class RxEngine:
             # a captured step replays fixed buffers: it keeps the batch in whichever x_norm buffer holds it now and
             # normalises the next one into the same buffer on its optimizer launch (the single-buffer form)
             self._launch_graph(1 | 4 | (8 if self._norm_parity else 0))
-            self._fwd_prefetched = False
         else:
             ready = 0
             if x_ready is not None and not last:
                 ready = int(x_ready.cuda_event)
                 if not ready:
                     raise _lib.DccnError("x_ready must be an event that has been recorded")
-            pf = self._prefetch_big and not double and not last
-            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 2 if self._fwd_prefetched else 1, ready,
-                                      prefetch=pf)
+            bufs = self._pipe_buffers(slot, last, self._norm_parity, double, 1, ready)
             check(self.lib.dccn_rx_train_step(C.byref(self.shape), C.byref(bufs), self.hp, self._stream()), "dccn_rx_train_step")
-            self._fwd_prefetched = pf              # fft_out holds the C-Conv forward of the batch just normalised
             if double and not last:
-                self._norm_parity ^= 1           # the prefetched batch sits in the other buffer ...
-                self._fwd_prefetched = self._ride == 2      # ... and its C-Conv forward in fft_out
+                self._norm_parity ^= 1           # the prefetched batch sits in the other buffer
         self._prefetch_pending = not last
         if last:
             self._gen_side_primed = False

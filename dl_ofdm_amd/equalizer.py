@@ -78,7 +78,8 @@ class _FusedPlan:
                          p(tr.reg_coef), p(tr.adam_state), p(tr.rx_arena), p(self.out_eq), p(self.chest),
                          p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
                          p(self.ws), self.nws, 1, p(tr.rx_folded(self.shape)),        # reg_uniform: _flatten() fills one value per dense tensor
-                         None if x_next is None else p(x_next), int(pre), int(slot), (virt or None) if x_next is not None else None)
+                         None if x_next is None else p(x_next), int(pre), int(slot), (virt or None) if x_next is not None else None,
+                         C.addressof(tr._tune) if getattr(tr, "_tune", None) is not None else None)
 
     def pipe_with(self, other: "_FusedPlan", slot: int, virt=None):
         """Training steps of this plan normalise `other`'s input on their optimizer launch (include/dccn.h
@@ -191,6 +192,16 @@ class EqualizerTrainer:
         self.fused_ok = True
         self._plans: Dict[int, _FusedPlan] = {}
         self._rx_folded = None
+
+    def pin_tuning(self):
+        """Capture the library's tuning table NOW for every plan built from here on (dccn_eq_buffers.tuning): later
+        ``dccn_set_tuning`` calls no longer reach this trainer's steps.  Call before the first plan is created."""
+        if self._plans:
+            raise _lib.DccnError("pin_tuning() after plans were built: their buffers hold the old (global) table")
+        n = int(self.lib.dccn_tuning_count())
+        self._tune = (C.c_int * n)()
+        check(self.lib.dccn_tuning_snapshot(self._tune, n) - n, "dccn_tuning_snapshot")
+        return self
 
     def rx_folded(self, shape) -> torch.Tensor:
         """The frozen receiver's C-Conv + dense layer as one matrix (include/dccn.h dccn_eq_rx_fold): built once -- the

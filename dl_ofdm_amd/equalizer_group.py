@@ -43,7 +43,7 @@ class _Chain:
         self.o = ofdm.ofdm_tx(FLAGS)
         self.arena = ChainArena(arena_bytes, device)
         np.random.seed(FLAGS.seed)                                          # as receiver_mp.train does (nothing draws from it here)
-        self.tr = EqualizerTrainer(FLAGS, self.o, rx_params, device=device, seed=FLAGS.seed, arena=self.arena)
+        self.tr = EqualizerTrainer(FLAGS, self.o, rx_params, device=device, seed=FLAGS.seed, arena=self.arena).pin_tuning()
         self.B = FLAGS.batch_size // FLAGS.nsymbol
         self.steps = (FLAGS.msg_length // FLAGS.nsymbol) // self.B
         self.gen = DeviceDataGen(FLAGS, self.o, device=self.tr.device, seed=FLAGS.seed, mobile=FLAGS.mobile, mix=FLAGS.mobile)

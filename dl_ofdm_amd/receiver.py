@@ -295,7 +295,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
         size only ever grows with the falling BER (:232-236), so the previous engine is released as soon as its state
         has been copied: one training engine is alive at a time."""
         if bs not in engines:
-            engines[bs] = RxEngine(dims, bs, device=device, train=True, seed=FLAGS.seed, want_prob=False)
+            engines[bs] = RxEngine(dims, bs, device=device, train=True, seed=FLAGS.seed, want_prob=False).pin_tuning()
         e = engines[bs]
         if src is not None and src is not e:
             e.params.copy_(src.params); e.adam_m.copy_(src.adam_m); e.adam_v.copy_(src.adam_v)
@@ -305,7 +305,7 @@ def train(FLAGS: Flags, device="cuda", verbose: bool = True, run_test: bool = Tr
         return e
 
     eng = engine_for(batch_size, None)
-    ev = RxEngine(dims, FLAGS.eval_frames, device=device, train=False, want_prob=False)
+    ev = RxEngine(dims, FLAGS.eval_frames, device=device, train=False, want_prob=False).pin_tuning()
     loss_min, epoch_min, best_path = 100.0, 0, ""
     history = []
     gen = _device_gen(FLAGS, ofdmobj, device) if FLAGS.device_data else None

@@ -216,7 +216,7 @@ def train(FLAGS, device="cuda", verbose: bool = True, run_test: bool = True, rx_
     frame_cnt = FLAGS.msg_length // FLAGS.nsymbol
     np.random.seed(FLAGS.seed)
     rx_params = rx_params if rx_params is not None else load_rx_params(FLAGS)
-    trainer = EqualizerTrainer(FLAGS, ofdmobj, rx_params, device=device, seed=FLAGS.seed)
+    trainer = EqualizerTrainer(FLAGS, ofdmobj, rx_params, device=device, seed=FLAGS.seed).pin_tuning()
     batch_size = FLAGS.batch_size // FLAGS.nsymbol                     # :341
     fading0 = RayleighChanParallel(FLAGS, ofdmobj.Fs, mobile=False)    # :389
     fading1 = RayleighChanParallel(FLAGS, ofdmobj.Fs, mobile=True, mix=True) if FLAGS.mobile else None

@@ -42,7 +42,10 @@ typedef enum dccn_status {
 } dccn_status;
 
 const char* dccn_strerror(int status);
-int dccn_version(void);                              /* 100*major + minor */
+int dccn_version(void);
+/* 16 hex digits: hash of the sources this library was built from (csrc/Makefile).  Measurements that are kept next to the code
+ * (profiles/pmc_traffic.json) carry it, so a reader can tell whether they describe the library that is loaded. */
+const char* dccn_build_id(void);                              /* 100*major + minor */
 int dccn_last_hip_error(void);                       /* hipError_t of the last failure */
 /* host out-params; returns DCCN_ERR_NO_DEVICE when no GPU is visible */
 int dccn_device_info(int* cu_count, int* wavefront, size_t* hbm_bytes, char* arch, int arch_len);
@@ -259,32 +262,35 @@ int dccn_step_monitor_add(const dccn_metrics* metrics, const float* tx_power, co
 /* row6 = the record (the one-point table of a single evaluation: no clearing launch needed in front of it) */
 int dccn_metrics_table_set(const dccn_metrics* metrics, double* row6, dccn_stream_t stream);
 
-/* Kernel-configuration knobs for experiments and profiling (process-wide; individually atomic, but a change
- * while another thread plans a launch may be seen half-way through that plan): key 0 dense forward+tail, 1 grouped dense backward, 2 C-Conv forward, 3 C-Conv weight gradient
- * (0 = 32x32x2 tile family, >0 = a 16x16x4 configuration), 4/5 split-K counts of the two weight gradients
- * (0 = automatic), 6 minimum LDS per block in KiB, 7 single-tile launches for short k ranges (default 1),
- * 8 skinny dispatch, 9 grouped backward of large layers, 10 gemm16 tiles for the un-fused dense forward,
- * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1), 12 wave priority of those tiles,
- * 13 fused dense+tail launch for 8-QAM / 16-QAM steps (bit 0 lane-per-cell forms, bit 1 quad-lane training form),
- * 14 graded k ranges of the dense weight-gradient items in the fused backward launch (preset number, 0 = uniform),
- * 15 C-Conv forward of the next batch on the optimizer launch of double-buffered pipelined steps (default 0: measured
- * slower), 16 large layers: optimizer update of the dense kernel in the epilogue of its unsplit weight-gradient tiles
- * (default 0: measured slower), 17 few-row dense backward as one grid (default 1), 18 R0 of the next batch on the
- * backward launch of double-buffered pipelined steps (default 0), 19 equaliser step: element-wise stages in GEMM
- * stores (1 few-row tiles, 2 = default: also larger batches), 20 equaliser step: grouped corr/eq C-Conv launches, concat / split in GEMM stores, merged
- * element-wise launches and ONE job-table optimizer launch (default 1; 0 = the launch-per-stage plan of round 2, 3 = the re-plan without the fused pilot bottleneck),
- * 21 few-row GEMMs (<= 96 rows) on one-latency 16x16 tiles (default 1), 22 non-temporal gradient loads in the optimizer launch of large
- * arenas (default 0), 23 tile shape of the fused dense + tail launch of large layers (default 0 = 80x64), 24 equaliser step: the Adam
- * updates of dense_3 / dense_4 and the smoothing kernel's gradient fold ride behind the pilot bottleneck's backward launch (default 1),
- * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream next to the C-Conv weight-gradient launch
- * (0 off, 1 on, 2 = default: with non-temporal loads and stores), 26 (default 0: measured 4725 vs 4724 us per N = 1024 step) dccn_rx_prefetch_pays answers 1 for those
- * layers (the pipelined caller then moves the next batch's C-Conv forward next to that update: dccn_rx_buffers.prefetch_fwd).
- * 27 (default 1) large layers' fused dense + tail: a short last row tile (<= 32 of 80 rows) runs as 32x64 blocks in the same grid.
- * Key 2: 7 (default) = the staged whole-k C-Conv forward, 8-11 its other store slots / 32x128
- * tiles; key 14: presets 1-24, default 14 = ranges of {9,5,2,2,1}/19 of the batch.
- * Set them before workspaces are sized. */
+/* Kernel-configuration knobs for experiments and profiling.  The table is a process-wide set of DEFAULTS; a call copies it once
+ * when it begins (never mid-plan), and a plan that captured its own table (dccn_tuning_snapshot -> dccn_rx_buffers.tuning /
+ * dccn_eq_buffers.tuning) is not affected by later changes at all.
+ *  0 dense forward with the tail in its epilogue (> 0 on; 0: separate launches)      1 grouped dense backward (7 = k-major dW)
+ *  2 C-Conv forward (7 = staged whole-k tile, default; 8-11 its other store slots / 32x128 tiles; 1-6 gemm16 tiles; 0 = 32x32x2)
+ *  3 C-Conv weight gradient (7 = k-major)      4 / 5 split-K counts of the two weight gradients (0 = automatic)
+ *  6 minimum LDS per block in KiB      7 single-tile launches for short k ranges (default 1)      8 skinny dispatch
+ *  9 grouped backward of large layers      10 gemm16 tiles for the un-fused dense forward
+ * 11 C-Conv weight gradient in the epilogue of the dense dX tiles (default 1)      12 wave priority of those tiles
+ * 13 fused dense + tail launch for 8-QAM / 16-QAM steps (bit 0 lane-per-cell forms, bit 1 quad-lane training form)
+ * 14 graded k ranges of the dense weight-gradient items in the fused backward launch (presets 1-24, default 14 = {9,5,2,2,1}/19)
+ * 17 few-row dense backward as one grid (default 1)
+ * 18 R0 of the next batch on the backward launch of double-buffered pipelined steps (default 0)
+ * 19 equaliser step: element-wise stages in GEMM stores (1 few-row tiles, 2 = default: also larger batches)
+ * 20 equaliser step plan (1 = default: grouped corr/eq C-Convs, concat / split in GEMM stores, ONE job-table optimizer launch;
+ *    0 = launch per stage; 3 = plan 1 without the fused pilot bottleneck)
+ * 21 few-row GEMMs (<= 96 rows) on one-latency 16x16 tiles (default 1)
+ * 24 equaliser step: Adam updates of dense_3 / dense_4 and the smoothing kernel's fold ride behind the bottleneck backward launch
+ * 25 large layers: the dense kernel's optimizer update on the library's own low-priority stream (0 off, 1 on, 2 = default: with
+ *    non-temporal loads and stores)
+ * 27 (default 1) large layers' fused dense + tail: a short last row tile (<= 32 of 80 rows) runs as 32x64 blocks in the same grid
+ * Keys 15, 16, 22, 23, 26 were removed in round 6 (alternatives that were built, measured without gain and deleted): setting
+ * them returns DCCN_ERR_INVALID_ARG.  Set knobs before workspaces are sized. */
 int dccn_set_tuning(int key, int value);
 int dccn_get_tuning(int key);
+/* the knobs as a table (n >= dccn_tuning_count() ints; returns the count): what a plan captures to be immune to later
+ * dccn_set_tuning calls -- see dccn_rx_buffers.tuning */
+int dccn_tuning_count(void);
+int dccn_tuning_snapshot(int* table, int n);
 
 /* Plan queries: which launch plan the library will take for a shape under the current knobs, so that callers size
  * their buffers from the library's own rule instead of restating it.
@@ -412,8 +418,7 @@ typedef struct dccn_rx_buffers {
        x_next != NULL  the step also normalises x_next into x_norm behind its Adam update (the leading blocks of the
                        optimizer launch; x_norm is dead by then), for the following call;
        x_prenormalised x_norm (and the R8 partial sums in the workspace) already hold this step's batch -- written
-                       by the previous call through x_next -- so the step starts at R1; 2: fft_out holds it as well
-                       (dccn_rx_norm_rides_backward == 2), the step starts at R2.
+                       by the previous call through x_next -- so the step starts at R1.
        x itself is only read by R0: with both set, x and x_next may be the same buffer, refilled between calls.
        The workspace must be the same memory in both calls. */
     const float* x_next;
@@ -445,14 +450,10 @@ typedef struct dccn_rx_buffers {
        calls on the single-buffer pipelining only (dccn_rx_norm_rides_backward(shape) == 0); one C call per generated-and-
        trained batch. */
     const dccn_gen_static* gen_next;
-    /* Round 5: prefetch_fwd != 0 (training calls that normalise a next batch -- x_next or gen_next -- on the single-buffer
-       pipelining): the call also runs the C-Conv forward (R1) of THAT batch into fft_out as its last launch, after the C-Conv
-       kernel's own update; the following call is told so with x_prenormalised = 2 and starts at R2.  Same kernels on the same
-       data in the same order per stream: bit-identical training.  Meant for the steps whose optimizer is split over two streams
-       (dccn_rx_prefetch_pays: large layers, N = 1024): the 0.3-ms matrix launch then runs NEXT TO the dense kernel's
-       HBM-bound update instead of behind it -- measured: no gain (the update and the matrix launches already share the
-       memory system; 4725 vs 4724 us per step), so no caller requests it by default (tuning key 26). */
-    int prefetch_fwd;
+    /* nullable: the plan's OWN tuning table (dccn_tuning_count() ints, captured with dccn_tuning_snapshot when the plan was
+       built): the call plans its launches from it instead of the process-global knobs, so dccn_set_tuning on another thread
+       cannot change this plan.  NULL: the globals as they stand when the call begins (copied once: never mid-call). */
+    const int* tuning;
 } dccn_rx_buffers;
 
 int dccn_rx_param_offsets(const dccn_rx_shape* shape, long long offsets[6]);
@@ -461,14 +462,8 @@ int dccn_rx_bwd_fused_supported(const dccn_rx_shape* shape);
  * with the demodulation tail in its epilogue -- and `z` may be NULL.  (8-QAM / 16-QAM: the tile is staged through LDS and
  * walked a lane or a quad of lanes per cell; which of those steps take the fused launch is tuning knob 13.) */
 int dccn_rx_dense_tail_fused(const dccn_rx_shape* shape, int train);
-/* > 0: a training step given x_next + x_norm_next normalises the next batch on its backward launch (see dccn_rx_buffers);
- * 2: its optimizer launch then also runs the C-Conv forward of that batch (into fft_out, after the C-Conv kernel's own
- * update, handed over inside the launch), and the following call is told so with x_prenormalised = 2 */
+/* 1: a training step given x_next + x_norm_next normalises the next batch on its backward launch (see dccn_rx_buffers) */
 int dccn_rx_norm_rides_backward(const dccn_rx_shape* shape);
-/* 1 (only with tuning key 26 set): for this shape a training step updates the dense kernel on the library's second stream
- * (large layers) and dccn_rx_buffers.prefetch_fwd moves the next batch's C-Conv forward next to that update; 0: prefetch_fwd
- * still works, but only reorders launches on one stream */
-int dccn_rx_prefetch_pays(const dccn_rx_shape* shape);
 /* 1: a training step of this shape takes dccn_rx_buffers.gen_next (the next batch formed from the fused generator's
  * (y, noise, partials) by the pipelined R0 on the optimizer launch): single-buffer pipelining, batch <= 1536 frames, one power
  * partial per generator block.  0: generate with dccn_gen_static_frames / _apply (or the launch-per-stage generator) and hand
@@ -644,6 +639,7 @@ typedef struct dccn_eq_buffers {
        for that batch on the same stream before this call (the step itself launches nothing for it: the call stays
        graph-capturable, the generator's per-batch arguments stay outside the graph).  Honoured like x_next. */
     const dccn_gen_static* x_next_virtual;
+    const int* tuning;            /* nullable: the plan's own tuning table, as dccn_rx_buffers.tuning */
 } dccn_eq_buffers;
 /* 1: dccn_eq_train_step honours dccn_eq_buffers.x_next for this shape */
 int dccn_eq_norm_rides(const dccn_eq_shape* shape);

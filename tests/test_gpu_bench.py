@@ -54,8 +54,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # once the step was past 0.40.  One box of the pool ran the SAME build at 0.366-0.371 -- its HBM-bound launches 50 % longer
     # in situ (optimizer 10.5 vs 7.0 us) while every same-kernel loop matched -- so the bar is 0.36 on a box whose device-to-
     # device copy runs at speed and the round-4 bar of 0.33 on one where it does not: the guard is for the build, not the box.)
-    floor = 0.36 if copy_tbs >= 4.3 else 0.33
-    assert st["mfma_frac"] >= floor, "C2 step below %.0f %%%% of the fp32 MFMA peak (copy %.2f TB/s): %s" % (100 * floor, copy_tbs, diag)
+    # (round 6, ADVICE r05: ONE bar for the build -- 0.37 -- checked at the end of this test; a box whose copy runs below 4.3 TB/s
+    # and whose step lands in [0.33, 0.37) is reported as an expected failure OF THE BOX, by name, instead of silently passing)
     assert d["distributed"]["world"] == 1 and d["distributed"]["points_per_rank"] == [40]
     bd = st["boundaries"]
     names = [l["name"] for l in bd["launches"]]
@@ -75,7 +75,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0
-    assert r["traffic"] is None or r["traffic"] > 1e6
+    # HBM traffic of the dominant kernel: only from counters stamped with THIS library's build id, else null + stale
+    assert len(r["build_id"]) == 16 and int(r["build_id"], 16) >= 0
+    if r["traffic_stale"]:
+        assert r["traffic"] is None and r["traffic_build_id"] != r["build_id"]
+    else:
+        assert r["traffic"] is None or (r["traffic"] > 1e6 and r["traffic_build_id"] == r["build_id"])
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "OFDM symbols/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 20 * c["value"]
@@ -95,4 +100,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # the training loop with the device-side generator (configs[1]: QPSK on Rayleigh EPA), timed by the same run
     e = d["e2e"]
     assert e["symbols_per_s"] > 1e7 and e["symbols_per_s"] < d["value"] * 1.001 and 0.0 < e["ber_last"] < 0.5
-
+    if st["mfma_frac"] < 0.37:
+        if copy_tbs < 4.3 and st["mfma_frac"] >= 0.33:
+            pytest.xfail("slow-HBM box (device-to-device copy %.2f TB/s < 4.3): C2 step at %.1f %% of the fp32 MFMA peak; "
+                         "the build's bar is 37 %% on a box whose copy runs at speed" % (copy_tbs, 100 * st["mfma_frac"]))
+        raise AssertionError("C2 step below 37 %% of the fp32 MFMA peak (copy %.2f TB/s): %s" % (copy_tbs, diag))

@@ -40,7 +40,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.AdamHParams) == 24
     assert C.sizeof(_lib.RxShape) == 24
     # 18 pointers/sizes + x_next + x_prenormalised (padded) + x_norm_next + (norm_slot, keep_dense_grad) + reg_uniform_dense (padded)
-    assert C.sizeof(_lib.RxBuffers) == 26 * 8          # ... + x_next_ready + gen_next + prefetch_fwd (padded)
+    assert C.sizeof(_lib.RxBuffers) == 26 * 8          # ... + x_next_ready + gen_next + tuning
     assert C.sizeof(_lib.GenStatic) == 200             # (static_assert'ed against the C struct in csrc/dccn_abi.hip)
     assert C.sizeof(_lib.GenProfile) == 32
 
@@ -97,3 +97,25 @@ def test_ops_refuse_cpu_tensors():
     from dl_ofdm_amd.engine import RxDims, RxEngine
     with pytest.raises(_lib.DccnError):
         RxEngine(RxDims(7, 80, 64, 320, 2), 4, device="cpu")
+
+
+def test_bench_reports_traffic_only_for_the_build_it_was_measured_on(tmp_path):
+    """bench.traffic_for: the PMC counters kept in profiles/pmc_traffic.json are stamped with the id of the library they were
+    collected on (dccn_build_id); for any other build the bench line carries null + traffic_stale instead of an old number."""
+    import json
+    import sys
+    ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ROOT_ not in sys.path:
+        sys.path.insert(0, ROOT_)
+    import bench
+    from dl_ofdm_amd import _lib
+    bid = _lib.load().dccn_build_id().decode()
+    assert len(bid) == 16 and int(bid, 16) >= 0
+    f = tmp_path / "pmc_traffic.json"
+    f.write_text(json.dumps({"c2": {"rx_backward": 7.0e7}, "build_id": bid}))
+    assert bench.traffic_for(str(f), "c2", "rx_backward", bid) == (7.0e7, False, bid)
+    f.write_text(json.dumps({"c2": {"rx_backward": 7.0e7}, "build_id": "0123456789abcdef"}))
+    assert bench.traffic_for(str(f), "c2", "rx_backward", bid) == (None, True, "0123456789abcdef")
+    f.write_text(json.dumps({"c2": {"rx_backward": 7.0e7}}))                      # a file from before the stamp existed
+    assert bench.traffic_for(str(f), "c2", "rx_backward", bid) == (None, True, None)
+    assert bench.traffic_for(str(tmp_path / "missing.json"), "c2", "rx_backward", bid) == (None, False, None)

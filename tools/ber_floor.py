@@ -63,7 +63,7 @@ def main():
         for h in hist[:: max(1, len(hist) // 200)]:
             w.writerow([h["epoch"], "%.6f" % h["train_loss"], "%.6f" % h.get("test_loss", float("nan")),
                         "%.6g" % h.get("test_ber", float("nan"))])
-    snrs = [0, 5, 10, 15, 20, 25, 30, 40, 60]
+    snrs = [0, 5, 10, 15, 20, 25, 29, 30, 40, 60]
     chans = ("EPA", "EVA", "ETU")
     rows = []
     o = ofdm.ofdm_tx(rf)

@@ -67,6 +67,14 @@ def main(root, out_txt, out_json):
                 fb, wb = v["FETCH_SIZE"] * 1024.0 * 2.0, v["WRITE_SIZE"] * 1024.0
                 res["c2"][op] = fb + wb
                 res["detail"][op] = dict(kernel=k, fetch_bytes=fb, write_bytes=wb, hbm_bytes=fb + wb)
+    # which library these counters describe (include/dccn.h dccn_build_id): bench.py reports roofline.traffic only for that build
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from dl_ofdm_amd import _lib
+        res["build_id"] = _lib.load().dccn_build_id().decode()
+    except Exception as e:                                   # noqa: BLE001
+        res["build_id"] = None
+        res["build_id_error"] = repr(e)
     json.dump(res, open(out_json, "w"), indent=1)
     print("\n".join(lines[:6]))
     print(json.dumps(res["c2"]))
