@@ -111,6 +111,9 @@ def check_stages(v, P, G, ecfg, lit_rx, bits, st):
     eq, corr = v["eq"].reshape(B, S, K, 2), v["corr"].reshape(B, S, K, 2)
     habs = np.sqrt((h ** 2).sum(-1))
     ok = habs >= 0.02 * np.median(habs)                   # stated margin: cells next to the 1/|h| pole
+    # (how many cells the margin leaves out: printed so that the number is on record -- DESIGN.md section 4 quotes it)
+    print("equalise margin: %d of %d cells (%.4f %%) below 2 %% of the median |h| left out [B=%d]"
+          % (int((~ok).sum()), ok.size, 100.0 * float((~ok).mean()), B))
     assert ok.mean() > 0.97
     eq_ref, corr_ref = E.equalize(y, h)
     st.check(":431-436 equalise", eq[ok], eq_ref[ok])
