@@ -86,7 +86,7 @@ class EqBuffers(C.Structure):
                 ("pilot_carriers", c_void_p), ("prob", c_void_p), ("metrics", c_void_p), ("tx_power", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("reg_uniform", c_int), ("rx_folded", c_void_p),
                 ("x_next", c_void_p), ("x_prenormalised", c_int), ("norm_slot", c_int), ("x_next_virtual", c_void_p),
-                ("tuning", c_void_p)]
+                ("tuning", c_void_p), ("gen_next_rides", c_int), ("monitor", c_void_p)]
 
 
 class EqMonitor(C.Structure):

@@ -127,6 +127,10 @@ struct ChainCtx {
     int G;                              // chains carried by the launches issued from this thread right now (1 = no group)
     ChainOffs co;
     int nbits[kMaxChains];              // per-chain modulation (the frozen receiver's tail is the only nbits-dependent stage)
+    // the fused generator's per-chain scalars, when its workgroups ride on a launch of the group's step (eq_step.h)
+    unsigned long long gen_seed[kMaxChains];
+    unsigned gen_offset[kMaxChains];
+    int gen_nbits[kMaxChains];
 };
 extern thread_local ChainCtx tl_chain;
 struct ChainScope {                     // RAII: a (sub-)group for the launches of a scope

@@ -309,8 +309,9 @@ struct GenStaticArgs {
         GenStaticArgs q = *this;
         q.bits_out = chain_at(bits_out, coff); q.cell_map = chain_at(cell_map, coff); q.const_tab = chain_at(const_tab, coff);
         q.idft = chain_at(idft, coff);
-        // (prof[] is indexed by the frame number: the kernel reads the profile it needs from the argument segment and rebases
-        // that one -- a rebased copy of the table would live in scratch memory)
+        // (prof[] is NOT rebased here: the kernel reads the two profiles a workgroup needs from the kernel-argument segment by
+        // index and rebases those -- an indexed COPY of the table lives in scratch memory, and the compiler turns a compare chain
+        // over literal indices back into an index)
         q.H = chain_at(H, coff); q.snr_db = chain_at(snr_db, coff); q.y = chain_at(y, coff); q.noise = chain_at(noise, coff);
         q.power_partial = chain_at(power_partial, coff); q.noise_partial = chain_at(noise_partial, coff); q.tx_out = chain_at(tx_out, coff);
         return q;
@@ -332,11 +333,24 @@ constexpr int kGenFirPad = 64;             // >= the longest channel response th
 // are INDEPENDENT chains (Philox -> Box-Muller -> store; cell map -> Philox -> constellation table) whose latencies then
 // overlap instead of adding up (the first version walked them one after the other with run-time divisions: 26.8 us per launch;
 // profiles/r05_e2e_kernel_stats.txt has this one)
+// The body is a device function so that the generator's workgroups can also RIDE on another launch (round 6: behind the
+// equaliser step's bottleneck backward launch, eq_bottleneck.h): a = the launch's argument block as gen_args_of_chain
+// prepared it for this chain, block = this workgroup's index among the generator's; the body uses gen_static_smem_bytes() of
+// dynamic LDS.
+// The launch's argument block for one chain (arena offset applied, per-chain scalars taken), written out where the KERNEL
+// PARAMETERS are in scope: handing them to a helper by reference takes their address, which turns the by-value kernel
+// arguments into a private copy -- and the per-chain index into a scratch access.
+#define DCCN_GEN_ARGS_OF_CHAIN(a, P0, P1, a0, gc, coff, chain, block)                                         \
+    GenStaticArgs a = (a0).at_chain(coff);                                                                     \
+    if ((gc).n > 0) { a.nbits = (gc).nbits[chain]; a.offset = (gc).offset[chain]; a.seed = (gc).seed[chain]; } \
+    /* the profiles of the block's two frames (block-uniform; frame 1 of a one-frame block repeats frame 0) */  \
+    GenProfile P0 = (a0).prof[((block) * kGenFramesPerBlock) % (a0).n_prof];                                    \
+    GenProfile P1 = (a0).prof[((block) * kGenFramesPerBlock + (((a0).frames - (block) * kGenFramesPerBlock) > 1 ? 1 : 0)) % (a0).n_prof]; \
+    P0.coeff = chain_at(P0.coeff, coff); P0.alpha = chain_at(P0.alpha, coff);                                   \
+    P1.coeff = chain_at(P1.coeff, coff); P1.alpha = chain_at(P1.alpha, coff);
 template <int S, int K, int CP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a0, const GenChainScalars gc,
-                                                                                                           const ChainOffs co) {
-    GenStaticArgs a = a0.at_chain(co.off[blockIdx.z]);
-    if (gc.n > 0) { a.nbits = gc.nbits[blockIdx.z]; a.offset = gc.offset[blockIdx.z]; a.seed = gc.seed[blockIdx.z]; }
+__device__ __forceinline__ void gen_static_frames_body(const GenStaticArgs a, const GenProfile P0, const GenProfile P1, const int block) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int K2 = 2 * K, N2 = 2 * (K + CP), T = S * (K + CP), LDG = K2 + 4;
     // the cyclic-prefix columns of the ifft matrix are bitwise copies of its last 2 CP columns (t = (t' - CP) mod K,
     // datagen.py idft_cp_matrix): only the K2 / 16 tiles behind the prefix are multiplied, the prefix is stored twice
@@ -345,7 +359,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int NSMP = (kGenFramesPerBlock * T + 255) / 256;          // samples per thread (5)
     constexpr int NCELL = 16 * K / 256;                                  // grid cells per thread (4)
     static_assert(kGenFramesPerBlock * S <= 16 && K2 % 16 == 0 && N2 % 16 == 0 && (16 * K) % 256 == 0, "generator tile shape");
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
     // the time-domain frames sit between two runs of kGenFirPad zeros: the 'same' FIR then reads its out-of-range neighbours
     // as zeros instead of branching around them (adding +-0 leaves every partial sum as it was: same bits as the skipped form)
     constexpr int TP = T + 2 * kGenFirPad;
@@ -356,16 +369,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float2 tw[K];                           // (cos, sin) of -2 pi m / K: the frequency response's twiddles
     __shared__ double sh[2][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int f0 = (int)blockIdx.x * kGenFramesPerBlock;
+    const int f0 = block * kGenFramesPerBlock;
     const int nfr = min(kGenFramesPerBlock, a.frames - f0);
-    // the profiles of the block's two frames (block-uniform; frame 1 of a one-frame block repeats frame 0)
-    GenProfile P0 = a0.prof[f0 % a.n_prof];
-    GenProfile P1 = a0.prof[(f0 + (nfr > 1 ? 1 : 0)) % a.n_prof];
-    {
-        const long long coff = co.off[blockIdx.z];
-        P0.coeff = chain_at(P0.coeff, coff); P0.alpha = chain_at(P0.alpha, coff);
-        P1.coeff = chain_at(P1.coeff, coff); P1.alpha = chain_at(P1.alpha, coff);
-    }
     const int L0 = P0.identity ? 1 : P0.L, L1 = P1.identity ? 1 : P1.L;
     if (a.H != nullptr && tid < K) {
         float sn, cs;
@@ -554,9 +559,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (lane == 0) { sh[0][w] = pw; sh[1][w] = nw; }
     __syncthreads();
     if (tid == 0) {
-        a.power_partial[blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        if (a.noise_partial != nullptr) a.noise_partial[blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        a.power_partial[block] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        if (a.noise_partial != nullptr) a.noise_partial[block] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
+}
+template <int S, int K, int CP>
+constexpr size_t gen_static_smem_bytes() {
+    return (size_t)16 * (2 * K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * (S * (K + CP) + 2 * kGenFirPad) * sizeof(float2);
+}
+template <int S, int K, int CP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gen_static_frames_kernel(const GenStaticArgs a0, const GenChainScalars gc,
+                                                                                                           const ChainOffs co) {
+    DCCN_GEN_ARGS_OF_CHAIN(a, P0, P1, a0, gc, co.off[blockIdx.z], blockIdx.z, (int)blockIdx.x)
+    gen_static_frames_body<S, K, CP>(a, P0, P1, (int)blockIdx.x);
 }
 // x = y / sqrt(mean |y|^2) + noise where a buffer is wanted (the first batch of a pipelined loop, tests, iq dumps): the
 // expression of awgn_kernel on the generator's y and noise.  grid: any; 256 threads.

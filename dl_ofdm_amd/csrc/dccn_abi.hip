@@ -23,7 +23,7 @@
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
-thread_local ChainCtx tl_chain = {1, {{0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
+thread_local ChainCtx tl_chain = {1, {{0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
 StepTraceState g_step_trace;
 thread_local unsigned long long* tl_stamp = nullptr;
 
@@ -991,7 +991,7 @@ static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float*
     fa.blk_metrics = bm; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
-    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0; fa.mon_acc = nullptr; fa.mon_noise = nullptr;
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -1113,7 +1113,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
         fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = nrag; fa.P = P; fa.count = cells * nbits;
         fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
         fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
-        fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
+        fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0; fa.mon_acc = nullptr; fa.mon_noise = nullptr;
         if (defer) {
             *defer = fa;
             return DCCN_OK;
@@ -1135,7 +1135,7 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
     fa.blk_metrics = bmx; fa.blk_grads = bwd ? bg : nullptr; fa.nblocks = few ? few_tiles : nblk; fa.P = P; fa.count = cells * nbits;
     fa.metrics = metrics; fa.dtailp = bwd ? dtailp : nullptr; fa.power_partial = pw ? pp->partial : nullptr;
     fa.n_power = pw ? pp->n : 0; fa.power_denom = pw ? pp->denom : 1.0; fa.power_out = pw ? power_out : nullptr;
-    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0;
+    fa.adam = nullptr; memset(&fa.hp, 0, sizeof(fa.hp)); fa.zero_word = nullptr; fa.zero_flags = nullptr; fa.n_zero_flags = 0; fa.zero_stride = 0; fa.mon_acc = nullptr; fa.mon_noise = nullptr;
     if (defer) {
         *defer = fa;
         return DCCN_OK;
@@ -1271,10 +1271,12 @@ static bool gen_static_ok(const dccn_gen_static* g) {
     // the instantiated shape: the reference's N = 64 frame with the long cyclic prefix, 7 symbols x (64 + 16) samples
     return g->S == 7 && g->K == 64 && g->CP == 16 && aligned16(g->y) && aligned16(g->noise);
 }
-static int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenChainScalars* chains = nullptr) {
+// the generator launch's argument block from its descriptor (also used by launches that carry the generator's workgroups as
+// riders: eq_step.h)
+static int gen_static_args(const dccn_gen_static* g, GenStaticArgs* out) {
     if (!gen_static_ok(g)) return DCCN_ERR_INVALID_ARG;
     if (ceil_div(g->frames, kGenFramesPerBlock) > kChanPartials) return DCCN_ERR_INVALID_ARG;
-    GenStaticArgs a;
+    GenStaticArgs& a = *out;
     a.bits_out = g->bits_out; a.cell_map = g->cell_map; a.const_tab = reinterpret_cast<const float2*>(g->const_tab);
     a.pilot = make_float2(g->pilot_re, g->pilot_im); a.idft = g->idft;
     memset(a.prof, 0, sizeof(a.prof));
@@ -1304,8 +1306,12 @@ static int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenC
 #else
     a.abl = 0;              // (the ablation switches of tools/genbench.py exist in `make ablation` builds only)
 #endif
-    const int T = g->S * (g->K + g->CP);
-    const size_t smem = (size_t)16 * (2 * g->K + 4) * sizeof(float) + (size_t)kGenFramesPerBlock * (T + 2 * kGenFirPad) * sizeof(float2);
+    return DCCN_OK;
+}
+static int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenChainScalars* chains = nullptr) {
+    GenStaticArgs a;
+    DCCN_TRY(gen_static_args(g, &a));
+    const size_t smem = gen_static_smem_bytes<7, 64, 16>();
     const int blocks = ceil_div(g->frames, kGenFramesPerBlock);
     GenChainScalars gc;
     if (chains) gc = *chains;
@@ -1574,6 +1580,11 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     return DCCN_OK;
 }
 
+static int eq_monitor_blocks(int B, int K) {
+    long long n = ceil_div_ll((long long)B * K * 2, 256);
+    if (n > 256) n = 256;
+    return (int)(n < 1 ? 1 : n);
+}
 #include "eq_step.h"
 
 }  // namespace dccn
@@ -2207,10 +2218,41 @@ int dccn_eq_train_step_grouped(int n_chains, const dccn_eq_shape* const* shapes,
         CHAIN_FIELD(chk, gv, n_chains, y); CHAIN_FIELD(chk, gv, n_chains, noise); CHAIN_FIELD(chk, gv, n_chains, power_partial);
         CHAIN_FIELD(chk, gv, n_chains, noise_partial); CHAIN_FIELD(chk, gv, n_chains, noise_power_out);
     }
+    for (int i = 0; i < n_chains; ++i)
+        if ((bufs[i]->monitor == nullptr) != (bufs[0]->monitor == nullptr)) return DCCN_ERR_INVALID_ARG;
+    if (bufs[0]->monitor != nullptr) {
+        const dccn_eq_monitor* mm[kMaxChains];
+        for (int i = 0; i < n_chains; ++i) {
+            mm[i] = bufs[i]->monitor;
+            if (mm[i]->chan_per_symbol != mm[0]->chan_per_symbol || mm[i]->workspace_bytes != mm[0]->workspace_bytes)
+                return DCCN_ERR_INVALID_ARG;
+        }
+        CHAIN_FIELD(chk, mm, n_chains, chest); CHAIN_FIELD(chk, mm, n_chains, chan); CHAIN_FIELD(chk, mm, n_chains, metrics);
+        CHAIN_FIELD(chk, mm, n_chains, tx_power); CHAIN_FIELD(chk, mm, n_chains, noise_power); CHAIN_FIELD(chk, mm, n_chains, acc5);
+        CHAIN_FIELD(chk, mm, n_chains, rms_out); CHAIN_FIELD(chk, mm, n_chains, workspace);
+    }
     ChainCtx ctx;
     if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
     if (bufs[0]->rx_folded == nullptr) return DCCN_ERR_UNSUPPORTED;
-    for (int i = 0; i < n_chains; ++i) ctx.nbits[i] = shapes[i]->nbits;
+    for (int i = 0; i < n_chains; ++i) {
+        ctx.nbits[i] = shapes[i]->nbits;
+        if (bufs[i]->gen_next_rides != bufs[0]->gen_next_rides) return DCCN_ERR_INVALID_ARG;
+        if (bufs[0]->gen_next_rides) {                     // (the generator's per-chain scalars travel with the group)
+            const dccn_gen_static* gv = bufs[i]->x_next_virtual;
+            if (!gv) return DCCN_ERR_INVALID_ARG;
+            ctx.gen_seed[i] = gv->seed; ctx.gen_offset[i] = gv->offset; ctx.gen_nbits[i] = gv->nbits;
+        }
+    }
+    if (bufs[0]->gen_next_rides) {
+        const dccn_gen_static* gv[kMaxChains];
+        for (int i = 0; i < n_chains; ++i) gv[i] = bufs[i]->x_next_virtual;
+        ChainOffsetCheck chk2(n_chains);
+        gen_static_chain_fields(chk2, gv, n_chains);
+        ChainCtx same;
+        if (!chk2.finish(&same)) return DCCN_ERR_INVALID_ARG;
+        for (int i = 0; i < n_chains; ++i)
+            if (same.co.off[i] != ctx.co.off[i]) return DCCN_ERR_INVALID_ARG;
+    }
     ChainScope scope(ctx);
     return eq_step_impl(shapes[0], bufs[0], true, hp, (hipStream_t)stream);
 }
@@ -2498,7 +2540,7 @@ int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff,
 }
 
 // ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
-static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208 && sizeof(dccn_eq_buffers) == 192 &&
+static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208 && sizeof(dccn_eq_buffers) == 208 &&
               sizeof(dccn_eq_monitor) == 88, "ctypes mirrors in dl_ofdm_amd/_lib.py");
 int dccn_gen_static_supported(int S, int K, int CP) {
     return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
@@ -2719,11 +2761,6 @@ int dccn_classical_detect(const float* Y, const float* G, const int* dat, const 
 }
 
 // ---- per-step monitors of the equaliser harness in one launch (equalizer.h eq_monitor_kernel) --------------------
-static int eq_monitor_blocks(int B, int K) {
-    long long n = ceil_div_ll((long long)B * K * 2, 256);
-    if (n > 256) n = 256;
-    return (int)(n < 1 ? 1 : n);
-}
 size_t dccn_eq_monitor_workspace_size(int B, int S, int K) {
     if (B <= 0 || S <= 0 || K <= 0) return 0;
     return align_up(256 + (size_t)eq_monitor_blocks(B, K) * sizeof(double), 256);
@@ -2779,8 +2816,12 @@ int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, co
     memset(&no_ride, 0, sizeof(no_ride));
     dccn_adam_hparams no_hp;
     memset(&no_hp, 0, sizeof(no_hp));
+    GenStaticArgs no_gen;
+    GenChainScalars no_gc;
+    memset(&no_gen, 0, sizeof(no_gen));
+    memset(&no_gc, 0, sizeof(no_gc));
     DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
-                         pw1, pb1, B, SK2, q, tiles, no_ride, no_hp);
+                         pw1, pb1, B, SK2, q, tiles, no_ride, no_hp, 0, 0, no_gen, no_gc);
     DCCN_LAUNCH_CHECK();
     // (the fused equaliser step leaves these sums to its optimizer launch)
     DCCN_TRY(launch_splitk_reduce2(pw2, tiles, (long long)P * SK2, dW2, (long long)P * SK2, pb2, (long long)SK2, db2, (long long)SK2, s));

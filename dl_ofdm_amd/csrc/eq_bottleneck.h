@@ -15,6 +15,7 @@
 // MFMAs (step e uses the k set {16 g + 4 kq + e}); the other operand follows the same k sets.
 #pragma once
 #include "common.h"
+#include "datagen.h"
 
 namespace dccn {
 
@@ -140,13 +141,26 @@ __global__ __launch_bounds__(256) void eq_bottleneck_fwd_kernel(const float* y_,
 }
 
 // slabs of block t: pW2 + t*P*SK2 ([P][SK2]), pb2 + t*SK2, pW1 + t*SK2*P ([SK2][P]), pb1 + t*P
+// gen_rows > 0 (round 6): the FIRST grid rows are workgroups of the fused static-channel generator (datagen.h
+// gen_static_frames_body) producing the NEXT batch of the training loop -- 15 us of integer / transcendental VALU work on 37
+// workgroups that depends on nothing of this step and used to be a launch of its own in front of it; here it runs beside the
+// bottleneck's MFMA tiles and the riders' HBM streams (dispatched first: it is the longest work item of the launch).
 template <int NP>
-__global__ __launch_bounds__(256) void eq_bottleneck_bwd_kernel(const float* dd2_, const float* d1_, const float* y_, const float* W1_,
-                                                                const float* W2_, const float* dy_in_, float* dy_out_, float* pW2_,
-                                                                float* pb2_, float* pW1_, float* pb1_, const int B, const int SK2,
-                                                                const int q, const int row_tiles, const EqRideArgs ride0,
-                                                                const dccn_adam_hparams hp, const ChainOffs co) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void eq_bottleneck_bwd_kernel(const float* dd2_, const float* d1_, const float* y_, const float* W1_, const float* W2_, const float* dy_in_,
+                              float* dy_out_, float* pW2_, float* pb2_, float* pW1_, float* pb1_, const int B, const int SK2, const int q,
+                              const int row_tiles, const EqRideArgs ride0, const dccn_adam_hparams hp, const int gen_rows,
+                              const int gen_blocks, const GenStaticArgs gen_args, const GenChainScalars gen_sc, const ChainOffs co) {
     const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
+    if ((int)blockIdx.y < gen_rows) {
+        const int gb = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (gb < gen_blocks) {
+            DCCN_GEN_ARGS_OF_CHAIN(a, P0, P1, gen_args, gen_sc, coff, blockIdx.z, gb)
+            gen_static_frames_body<7, 64, 16>(a, P0, P1, gb);
+        }
+        return;
+    }
+    const int by = (int)blockIdx.y - gen_rows;
     const float* __restrict__ dd2 = chain_at(dd2_, coff);
     const float* __restrict__ d1 = chain_at(d1_, coff);
     const float* __restrict__ y = chain_at(y_, coff);
@@ -161,14 +175,14 @@ __global__ __launch_bounds__(256) void eq_bottleneck_bwd_kernel(const float* dd2
     constexpr int P = 16 * NP;
     // grid rows behind the batch's row tiles: optimizer riders (eq_opt.h EqRideArgs), dispatched after every block of the
     // launch's own work
-    if ((int)blockIdx.y >= row_tiles) {
-        eq_ride_body(ride0, hp, ((int)blockIdx.y - row_tiles) * (int)gridDim.x + (int)blockIdx.x, coff);
+    if (by >= row_tiles) {
+        eq_ride_body(ride0, hp, (by - row_tiles) * (int)gridDim.x + (int)blockIdx.x, coff);
         return;
     }
     __shared__ float part[4][16][P + 1];
     __shared__ float g1[16][P + 1];                       // dd1 tile (rows past the batch are zero)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
-    const int m0 = (int)blockIdx.y * 16, t = (int)blockIdx.y;
+    const int m0 = by * 16, t = by;
     const int ct0 = (int)blockIdx.x * q, ct1 = min(ct0 + q, SK2 / 16);
     bn_f32x4 acc[NP];
     bn_long_k<true, NP>(dd2, W2, m0, B, SK2, wave, c, kq, acc);

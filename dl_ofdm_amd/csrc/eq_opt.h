@@ -18,7 +18,7 @@
 namespace dccn {
 
 enum EqOptKind : int { EQJ_SUM = 0, EQJ_CCONV_FOLD = 1, EQJ_CONV2D_FOLD = 2, EQJ_TAIL_FINALIZE = 3, EQJ_PILOT_SNR = 4,
-                        EQJ_NORM_NEXT = 5 };
+                        EQJ_NORM_NEXT = 5, EQJ_MONITOR = 6 };
 struct EqOptJob {
     int kind, block0, blocks, splits;
     long long off, n;        // arena segment of the (first) variable
@@ -60,6 +60,9 @@ struct EqOptArgs : EqOptPtrs {
     const float* nx; float* ny; double* npower;
     int nbatch, ncols;
     NormVirtual nv;               // nx as (y, noise, power partials) of the fused generator (dccn_eq_buffers.x_next_virtual)
+    // EQJ_MONITOR: the training loop's chan_rms monitor (equalizer.h eq_monitor_body) as a job of this launch: it reads the
+    // step's channel estimate and the generator's truth, both long complete; the scalar monitors are added by the finalize job
+    EqMonitorArgs mon;
 };
 static_assert(sizeof(EqOptArgs) + sizeof(dccn_adam_hparams) + sizeof(ChainOffs) <= 4096, "kernel argument block");
 
@@ -306,6 +309,11 @@ __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a0, const d
         demod_tail_finalize_body(a0.fin[a0.fin_class[chain]].at_chain(coff), bx);
         return;
     }
+    if (J.kind == EQJ_MONITOR) {
+        const EqMonitorArgs m = a0.mon.at_chain(coff);
+        eq_monitor_body(m, (unsigned)bx, (unsigned)J.blocks, false);
+        return;
+    }
     if (J.kind == EQJ_PILOT_SNR) {
         const int frame = bx * 4 + (int)(threadIdx.x >> 6);
         if (frame < a0.ps_frames)
@@ -403,6 +411,10 @@ struct EqOptBuilder {
                    const NormVirtual nv = norm_virtual_none()) {
         EqOptJob* J = add(EQJ_NORM_NEXT, nblocks);
         if (J) { a.nx = x; a.ny = y; a.nbatch = batch; a.ncols = cols; a.npower = power_partial; a.nv = nv; }
+    }
+    void monitor(const EqMonitorArgs& m, int nblocks) {
+        EqOptJob* J = add(EQJ_MONITOR, nblocks);
+        if (J) a.mon = m;
     }
     void tail_finalize(const TailFinalizeArgs* fin, int n_class, const int* fin_class) {
         int blocks_ = 0;

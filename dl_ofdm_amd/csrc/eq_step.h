@@ -204,6 +204,17 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
     const bool pair = replan && cconv_pair_ok(w.eq, P + d.o[16], w.cat, R, K, K, g_in, g_w, 2) && aligned16(w.corr) &&
                       (g_b % 2 == 0);
 
+    // the next batch's generator as a rider of this step (dccn_eq_buffers.gen_next_rides): on the bottleneck backward launch
+    // when the plan has it, else as a launch of its own right here (same batch either way)
+    bool gen_done = false;
+    const bool gen_wanted = train && b->gen_next_rides != 0;
+    if (gen_wanted && b->x_next_virtual == nullptr) return DCCN_ERR_INVALID_ARG;
+    const bool gen_rides = gen_wanted && bn && gen_static_ok(b->x_next_virtual);
+    if (gen_wanted && !gen_rides) {
+        if (tl_chain.G > 1) return DCCN_ERR_UNSUPPORTED;
+        DCCN_TRY(gen_static_launch(b->x_next_virtual, s));
+        gen_done = true;
+    }
     // `input:0` (ofdmreceiver_np.py:128-137) + tx_power partials
     PowerPartials pp;
     // (training: the optimizer's per-step bookkeeping rides on this first launch)
@@ -485,9 +496,29 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
                 rode[li] = true;
             }
         }
-        DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx, bn_tiles + ceil_div(ride.blocks, nx)), dim3(256), 0, s, (const float*)w.dd2,
-                             (const float*)w.d1, (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy, w.dflat, bn_w2, bn_b2,
-                             bn_w1, bn_b1, B, SK2, q, bn_tiles, ride, hp);
+        // the NEXT batch's generator rides here as well (dccn_eq_buffers.gen_next_rides): its workgroups are the first grid rows
+        GenStaticArgs ga;
+        GenChainScalars gc;
+        memset(&ga, 0, sizeof(ga));
+        memset(&gc, 0, sizeof(gc));
+        int gen_rows = 0, gen_blocks = 0;
+        size_t gen_smem = 0;
+        if (gen_rides) {
+            DCCN_TRY(gen_static_args(b->x_next_virtual, &ga));
+            gen_blocks = ceil_div(b->x_next_virtual->frames, kGenFramesPerBlock);
+            gen_rows = ceil_div(gen_blocks, nx);
+            gen_smem = gen_static_smem_bytes<7, 64, 16>();
+            if (tl_chain.G > 1) {
+                gc.n = tl_chain.G;
+                for (int g = 0; g < tl_chain.G; ++g) {
+                    gc.nbits[g] = tl_chain.gen_nbits[g]; gc.offset[g] = tl_chain.gen_offset[g]; gc.seed[g] = tl_chain.gen_seed[g];
+                }
+            }
+            gen_done = true;
+        }
+        DCCN_LAUNCH_CHAINS_Z(kern, dim3(nx, gen_rows + bn_tiles + ceil_div(ride.blocks, nx)), dim3(256), gen_smem, s,
+                             (const float*)w.dd2, (const float*)w.d1, (const float*)w.y, P + d.o[4], P + d.o[6], (const float*)w.dy,
+                             w.dflat, bn_w2, bn_b2, bn_w1, bn_b1, B, SK2, q, bn_tiles, ride, hp, gen_rows, gen_blocks, ga, gc);
         DCCN_LAUNCH_CHECK();
         dy_sum = w.dflat;
     } else {
@@ -567,7 +598,23 @@ static int eq_step_impl(const dccn_eq_shape* sh, const dccn_eq_buffers* b, bool 
         else { ob.plain(d.o[i], d.sz[i]); ob.plain(d.o[i + 1], d.sz[i + 1]); }
     }
     eq_opt_dense(ob, d, 18, ds5, N2, uni);
+    // the training loop's per-step monitors (dccn_eq_monitor_accumulate) as part of this launch: dccn_eq_buffers.monitor
+    if (b->monitor != nullptr) {
+        const dccn_eq_monitor* m = b->monitor;
+        if (!fin_deferred || !m->chan || !m->acc5 || m->chest != b->chest || m->metrics != b->metrics || m->B != B || m->S != d.S ||
+            m->K != K || !m->workspace || m->workspace_bytes < dccn_eq_monitor_workspace_size(B, d.S, K))
+            return DCCN_ERR_INVALID_ARG;
+        EqMonitorArgs ma;
+        ma.chest = m->chest; ma.chan = m->chan; ma.gt_per_symbol = m->chan_per_symbol ? 1 : 0; ma.B = B; ma.S = d.S; ma.K = K;
+        ma.metrics = m->metrics; ma.tx_power = m->tx_power; ma.noise_power = m->noise_power; ma.acc = m->acc5; ma.rms_out = m->rms_out;
+        ma.counter = static_cast<unsigned*>(m->workspace);
+        ma.partial = reinterpret_cast<double*>(static_cast<char*>(m->workspace) + 256);
+        ob.monitor(ma, eq_monitor_blocks(B, K));
+        for (int c = 0; c < n_class; ++c) { fin[c].mon_acc = m->acc5; fin[c].mon_noise = m->noise_power; }
+        if (m->tx_power != b->tx_power) return DCCN_ERR_INVALID_ARG;
+    }
     if (fin_deferred) ob.tail_finalize(fin, n_class, fin_class);
     if (snr_pending) ob.pilot_snr(w.eq, b->pilot_carriers, b->snr_db, B, d.S, K, sh->P);
+    if (gen_wanted && !gen_done) return DCCN_ERR_STATE;
     return launch_eq_opt(ob, hp, s);
 }

@@ -222,14 +222,15 @@ struct EqMonitorArgs {
         return q;
     }
 };
-__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0, const ChainOffs co) {
-    const EqMonitorArgs a = a0.at_chain(co.off[blockIdx.z]);
+// block of nblocks; scalars: also add {ce_mean, berlin, tx_power, noise_power} onto acc (the stand-alone launch; as a job of the
+// optimizer launch those are added by the waves that produce them, tail.h demod_tail_finalize_body)
+__device__ __forceinline__ void eq_monitor_body(const EqMonitorArgs& a, const unsigned block, const unsigned nblocks, const bool scalars) {
     __shared__ double red[4];
     __shared__ unsigned s_last;
     const long long cols = (long long)a.B * a.K * 2;
     const int K2 = a.K * 2;
     double sum = 0.0;
-    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+    for (long long c = (long long)block * 256 + threadIdx.x; c < cols; c += (long long)nblocks * 256) {
         const int b = (int)(c / K2), r = (int)(c % K2);
         const float* pe = a.chest + (size_t)b * a.S * K2 + r;
         const float* pg = a.gt_per_symbol ? a.chan + (size_t)b * a.S * K2 + r : a.chan + (size_t)b * K2 + r;
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        a.partial[block] = (red[0] + red[1]) + (red[2] + red[3]);
         __threadfence();                                            // the partial is visible before the arrival is
-        s_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+        s_last = atomicAdd(a.counter, 1u) == nblocks - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
@@ -262,21 +263,27 @@ __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0,
     // them side by side first: thread 0 walking <= 256 dependent device-scope loads was 8 of this launch's 12 us
     __shared__ double part[256];
     __threadfence();
-    if (threadIdx.x < gridDim.x) part[threadIdx.x] = __hip_atomic_load(a.partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < nblocks) part[threadIdx.x] = __hip_atomic_load(a.partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x != 0) return;
     double tot = 0.0;
-    for (unsigned i = 0; i < gridDim.x; ++i) tot += part[i];
+    for (unsigned i = 0; i < nblocks; ++i) tot += part[i];
     const float rms = (float)(tot / ((double)cols * (double)a.S));
     if (a.rms_out) *a.rms_out = rms;
     if (a.acc) {
-        a.acc[0] += a.metrics->ce_mean;
-        a.acc[1] += a.metrics->berlin;
-        if (a.tx_power) a.acc[2] += *a.tx_power;
-        if (a.noise_power) a.acc[3] += *a.noise_power;
+        if (scalars) {
+            a.acc[0] += a.metrics->ce_mean;
+            a.acc[1] += a.metrics->berlin;
+            if (a.tx_power) a.acc[2] += *a.tx_power;
+            if (a.noise_power) a.acc[3] += *a.noise_power;
+        }
         a.acc[4] += rms;
     }
     *a.counter = 0u;
+}
+__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0, const ChainOffs co) {
+    const EqMonitorArgs a = a0.at_chain(co.off[blockIdx.z]);
+    eq_monitor_body(a, blockIdx.x, gridDim.x, true);
 }
 
 // ---- the FROZEN receiver's two linear layers as one matrix (equaliser training, ofdmreceiver_np_mp.py:264-330) -------------

@@ -685,8 +685,13 @@ struct TailFinalizeArgs {
     unsigned* zero_word;        // nullable: hand-off words of a later launch of the same step, reset here: the arrival
     unsigned* zero_flags;       // counter and n_zero_flags flag words at a stride of zero_stride (fresh or recycled
     int n_zero_flags, zero_stride;   // workspace memory may hold anything, including a stale epoch)
+    // nullable: the training loop's epoch accumulators acc5 = {ce_mean, berlin, tx_power, noise_power, chan_rms} (equalizer.h
+    // EqMonitorArgs): the wave that writes a scalar adds it on (round 6: the monitor rides on the optimizer launch)
+    float* mon_acc;
+    const float* mon_noise;     // nullable: this batch's noise power, added by the metrics wave
     __device__ __forceinline__ TailFinalizeArgs at_chain(const long long coff) const {   // chain groups (common.h)
         TailFinalizeArgs q = *this;
+        q.mon_acc = chain_at(mon_acc, coff); q.mon_noise = chain_at(mon_noise, coff);
         q.blk_metrics = chain_at(blk_metrics, coff); q.blk_grads = chain_at(blk_grads, coff); q.metrics = chain_at(metrics, coff);
         q.dtailp = chain_at(dtailp, coff); q.power_partial = chain_at(power_partial, coff); q.power_out = chain_at(power_out, coff);
         q.adam = chain_at(adam, coff); q.zero_word = chain_at(zero_word, coff); q.zero_flags = chain_at(zero_flags, coff);
@@ -743,12 +748,20 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailFinalizeArgs&
             metrics->berlin = (float)ber;
             metrics->log_ber = (float)log(ber);
             metrics->reserved = 0.f;
+            if (a.mon_acc != nullptr) {
+                a.mon_acc[0] += metrics->ce_mean;
+                a.mon_acc[1] += metrics->berlin;
+                if (a.mon_noise != nullptr) a.mon_acc[3] += a.mon_noise[0];
+            }
         }
     } else if (g == P + 1 && power_out != nullptr) {
         double s = 0.0;
         for (int i = lane; i < n_power; i += 64) s += power_partial[i];
         s = wave_sum(s);
-        if (lane == 0) power_out[0] = (float)(s / power_denom);
+        if (lane == 0) {
+            power_out[0] = (float)(s / power_denom);
+            if (a.mon_acc != nullptr) a.mon_acc[2] += power_out[0];
+        }
     } else if (g == P + 2 && a.adam != nullptr && lane == 0) {
         dccn_adam_state* st = a.adam;
         const float lr = a.hp.lr0 * powf(a.hp.decay_rate, floorf(st->global_step / a.hp.decay_steps));

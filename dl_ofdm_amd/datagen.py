@@ -304,11 +304,13 @@ class FusedStaticGen:
                            else snr_db.reshape(-1).to(torch.float32))
 
     def arm(self, out_bits: torch.Tensor, slot: int = 0, tx_out: Optional[torch.Tensor] = None,
-            out_H: Optional[torch.Tensor] = None, snr: Optional[torch.Tensor] = None) -> "_lib.GenStatic":
+            out_H: Optional[torch.Tensor] = None, snr: Optional[torch.Tensor] = None, into=None) -> "_lib.GenStatic":
         """the descriptor for the NEXT launch: labels go to ``out_bits``, the batch offset is the generator's current one (which
         is advanced: call once per batch).  ``out_H`` float32 [n, K, 2] or [n, S, K, 2]: the frequency response per frame (per
         symbol); ``snr``: a float32 device tensor of n per-frame SNRs to read instead of the generator's own copy."""
-        g, d = self.gen, self.desc
+        # ``into``: a copy of the descriptor to arm instead of the generator's own (the one a step's buffers point to when the
+        # step produces the batch itself: dccn_eq_buffers.gen_next_rides)
+        g, d = self.gen, (self.desc if into is None else into)
         d.bits_out = out_bits.data_ptr()
         if out_H is not None:
             per = (self.n, g.S, g.K, 2)

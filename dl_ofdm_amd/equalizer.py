@@ -71,7 +71,7 @@ class _FusedPlan:
         self._partner = None
         self.graphs: Dict[object, C.c_void_p] = {}
 
-    def _buffers(self, x_next=None, pre: int = 0, slot: int = 0, virt: int = 0) -> EqBuffers:
+    def _buffers(self, x_next=None, pre: int = 0, slot: int = 0, virt: int = 0, gen_rides: bool = False, monitor: int = 0) -> EqBuffers:
         tr = self.tr
         p = lambda t: t.data_ptr()          # noqa: E731
         return EqBuffers(p(self.x), p(self.bits), p(tr.params), p(tr.grads), p(tr.adam_m), p(tr.adam_v),
@@ -79,9 +79,10 @@ class _FusedPlan:
                          p(self.snr_db), p(tr.pilot_carriers), None, p(self.metrics_buf), p(self.tx_power),
                          p(self.ws), self.nws, 1, p(tr.rx_folded(self.shape)),        # reg_uniform: _flatten() fills one value per dense tensor
                          None if x_next is None else p(x_next), int(pre), int(slot), (virt or None) if x_next is not None else None,
-                         C.addressof(tr._tune) if getattr(tr, "_tune", None) is not None else None)
+                         C.addressof(tr._tune) if getattr(tr, "_tune", None) is not None else None,
+                         1 if (gen_rides and virt and x_next is not None) else 0, monitor or None)
 
-    def pipe_with(self, other: "_FusedPlan", slot: int, virt=None):
+    def pipe_with(self, other: "_FusedPlan", slot: int, virt=None, gen_rides: bool = False, monitor=None):
         """Training steps of this plan normalise `other`'s input on their optimizer launch (include/dccn.h
         dccn_eq_buffers.x_next); run(True, pipe=0) starts a chain (own normalisation), pipe=1 continues one.
         ``virt`` (a ``_lib.GenStatic`` the caller keeps alive): that input is never written -- the launch reads the fused
@@ -95,8 +96,14 @@ class _FusedPlan:
         # 0 starts a chain, 1 continues it, 2 ends it (consumes the batch normalised ahead, normalises nothing: the last
         # step of an epoch), 3 = a one-step chain is the plain step
         va = C.addressof(virt) if virt is not None else 0
-        self.pipe_buffers = {0: self._buffers(other.x, 0, slot, va), 1: self._buffers(other.x, 1, slot, va),
-                             2: self._buffers(None, 1, slot), 3: self._buffers(None, 0, slot)}
+        # gen_rides: the steps that normalise the next batch also PRODUCE it (dccn_eq_buffers.gen_next_rides; the caller arms
+        # `virt` per batch instead of launching the generator)
+        # monitor (a ``_lib.EqMonitor`` the caller keeps alive): the loop's per-step monitors ride on the optimizer launch
+        # (dccn_eq_buffers.monitor) instead of following the step as a launch of their own
+        self._monitor = monitor
+        ma = C.addressof(monitor) if monitor is not None else 0
+        self.pipe_buffers = {0: self._buffers(other.x, 0, slot, va, gen_rides, ma), 1: self._buffers(other.x, 1, slot, va, gen_rides, ma),
+                             2: self._buffers(None, 1, slot, monitor=ma), 3: self._buffers(None, 0, slot, monitor=ma)}
         self._partner = other
 
     def _ahead(self) -> dict:

@@ -4,8 +4,8 @@ The reference driver runs one (receiver -> equaliser) chain per modulation and p
 (dev/py/run_local_ofdm.py:61-118; the loop is dev/py/ofdmreceiver_np_mp.py:394-466).  On an MI355X such a chain is a sequence of
 73-frame steps of ~21 dependent launches that keeps a few percent of the chip busy, and the host spends as long issuing a step
 as the GPU spends running it.  Here G chains of the same shape share every launch (include/dccn.h "chain groups": the chain
-index is a grid dimension): per group step THREE C calls -- the fused generator, the fused step, the monitor -- carry all G
-chains' batches.  Every chain keeps its own seeds, draws, early stopping and best-model snapshot: the trained model of a chain
+index is a grid dimension): per group step ONE C call carries all G chains' batches -- the step, with the next batch's generator
+riding on its bottleneck backward launch and the loop's monitors on its optimizer launch (three calls without those riders).  Every chain keeps its own seeds, draws, early stopping and best-model snapshot: the trained model of a chain
 is bit for bit the one :func:`dl_ofdm_amd.receiver_mp.train` produces for it alone (tests/test_gpu_chain_groups.py).
 
     results = train_group([flags_bpsk, flags_qpsk, ...], [rx_params_bpsk, rx_params_qpsk, ...])
@@ -159,7 +159,14 @@ class EqualizerChainGroup:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _generate(self, act, t, i: int, q: int, materialise: bool):
-        """batch i of the epoch for every chain: ONE fused generator launch (+ one that forms x for an epoch's first batch)"""
+        """batch i of the epoch for every chain: ONE fused generator launch (+ one that forms x for an epoch's first batch) -- or
+        none at all: the group step that normalises the batch produces it too (dccn_eq_buffers.gen_next_rides), the descriptors
+        its buffers hold are armed here"""
+        if not materialise and all(getattr(c.loop, "ride_gen", False) for c in act):
+            for c in act:
+                lp = c.loop
+                lp.fg.arm(lp.pls[q].bits, q, None, lp.H[q], lp.snr_rows[i], into=lp.virt[q ^ 1])
+            return
         for c in act:
             lp = c.loop
             lp.fg.arm(lp.pls[q].bits, q, None, lp.H[q], lp.snr_rows[i])                    # (advances the chain's gen.offset)
@@ -185,7 +192,8 @@ class EqualizerChainGroup:
         st = self._stream()
         check(self.lib.dccn_eq_train_step_grouped(t["n"], t["shapes"][q], t["bufs"][(pipe, q)], self.hp, st),
               "dccn_eq_train_step_grouped")
-        check(self.lib.dccn_eq_monitor_accumulate_grouped(t["n"], t["mon"][q], st), "dccn_eq_monitor_accumulate_grouped")
+        if not all(c.loop.mon is not None for c in act):             # (else the step's optimizer launch carried the monitors)
+            check(self.lib.dccn_eq_monitor_accumulate_grouped(t["n"], t["mon"][q], st), "dccn_eq_monitor_accumulate_grouped")
 
     # ---- the epoch loop of receiver_mp._train_on_device for all chains ---------------------------------------------------------
     def train(self, verbose: bool = False) -> List[dict]:

@@ -78,6 +78,8 @@ class Flags:
     overlap_generator: bool = False  # device_data: generate batch i+1 on a second stream while step i runs (same results, not faster)
     step_graph: bool = False         # device_data: replay the equaliser step as a hipGraph instead of 21 eager launches (same results)
     virtual_next: bool = True        # ... and the pipelined loop never writes x for any batch but an epoch's first (x_next_virtual)
+    monitor_rides: bool = True       # device_data, pipelined loop: the per-step monitors are a job of the step's optimizer launch
+    generator_rides: bool = True     # ... and that launch's workgroups ride on the step that normalises the batch (no launch of its own)
     fused_generator: bool = True     # device_data, static channels: one generator launch per batch (datagen.FusedStaticGen; same
                                      # draws, transmitted frames equal to rounding) instead of the launch-per-stage chain
     tf_checkpoint: bool = False     # also write the tf.train.Saver bundle (.index/.data-00000-of-00001)
@@ -331,10 +333,29 @@ class DeviceEpochLoop:
                 d = _lib.GenStatic.from_buffer_copy(self.fg.desc)
                 d.noise_power_out = self.fg.npow[q ^ 1].data_ptr() if self.fg.npow is not None else None
                 self.virt.append(d)
-            self.pls[0].pipe_with(self.pls[1], 0, virt=self.virt[0])
-            self.pls[1].pipe_with(self.pls[0], 1, virt=self.virt[1])
+            # round 6: ... and the generator launch goes as well -- its workgroups ride on the step's bottleneck backward launch
+            # (dccn_eq_buffers.gen_next_rides): the loop only ARMS the descriptor the step reads (labels, SNR row, batch offset)
+            # (not under hipGraph replay of the step: the generator's per-batch arguments must stay outside a captured graph)
+            self.ride_gen = bool(getattr(FLAGS, "generator_rides", True)) and not bool(getattr(FLAGS, "step_graph", False))
+            self.pls[0].pipe_with(self.pls[1], 0, virt=self.virt[0], gen_rides=self.ride_gen)
+            self.pls[1].pipe_with(self.pls[0], 1, virt=self.virt[1], gen_rides=self.ride_gen)
         self.nws = int(trainer.lib.dccn_eq_monitor_workspace_size(B, FLAGS.nsymbol, ofdmobj.K))
         self.ws = A.zeros(arena, self.nws, dtype=torch.uint8, device=dev)
+        # round 6: in the pipelined loop the monitors are a job of the step's own optimizer launch (dccn_eq_buffers.monitor)
+        self.mon = None
+        if self.pipeline and getattr(FLAGS, "monitor_rides", True):
+            from . import _lib as L_
+            self.mon = []
+            for q in range(2):
+                plq = self.pls[q]
+                npw = self.npow[q] if gen.want_noise_power else None
+                self.mon.append(L_.EqMonitor(plq.chest.data_ptr(), self.H[q].data_ptr(), self.per_symbol, B, FLAGS.nsymbol, ofdmobj.K,
+                                             plq.metrics_buf.data_ptr(), plq.tx_power.data_ptr(),
+                                             None if npw is None else npw.data_ptr(), self.acc.data_ptr(), None,
+                                             self.ws.data_ptr(), self.nws))
+            kw = [dict(virt=self.virt[q], gen_rides=self.ride_gen) if self.virt is not None else {} for q in range(2)]
+            self.pls[0].pipe_with(self.pls[1], 0, monitor=self.mon[0], **kw[0])
+            self.pls[1].pipe_with(self.pls[0], 1, monitor=self.mon[1], **kw[1])
         self.i = 0
         # the step as 21 eager launches per call (default) or as a hipGraph replay: 0.188 vs 0.196 ms per loop step (tools/eqloop.py
         # --graph 0 / 1; host issue 0.156 vs 0.125 ms) -- the replay costs the GPU 3-7 us per step, the eager calls cost the host 30
@@ -352,6 +373,9 @@ class DeviceEpochLoop:
         pl, gen = self.pls[q], self.gen
         if self.fg is not None:
             if self.virt is not None and i > 0:                      # frames only: the running step forms x in registers
+                if getattr(self, "ride_gen", False):                 # ... and produces them: arm the descriptor ITS buffers hold
+                    self.fg.arm(pl.bits, q, None, self.H[q], self.snr_rows[i], into=self.virt[q ^ 1])
+                    return
                 d = self.fg.arm(pl.bits, q, None, self.H[q], self.snr_rows[i])
                 check(gen.lib.dccn_gen_static_frames(self.C.byref(d), gen._stream()), "dccn_gen_static_frames")
             else:
@@ -412,6 +436,8 @@ class DeviceEpochLoop:
             self.torch.cuda.current_stream(tr.device).wait_event(self.ready[q])
         pl = self.pls[q]
         pl.run(True, pipe=pipe, graph=self.step_graph)
+        if self.mon is not None and pipe is not None:
+            return                                                   # (the step's optimizer launch carried the monitors)
         npow = self.npow[q] if self.gen.want_noise_power else None
         check(tr.lib.dccn_eq_monitor_accumulate(pl.chest.data_ptr(), self.H[q].data_ptr(), self.per_symbol, pl.batch,
                                                 self.F.nsymbol, self.o.K, pl.metrics_buf.data_ptr(), pl.tx_power.data_ptr(),

@@ -594,6 +594,7 @@ typedef struct dccn_eq_shape {
     int pilot_size, P;            /* pilot cells per frame (model.py:359), pilot carriers per symbol */
 } dccn_eq_shape;
 
+struct dccn_eq_monitor;
 typedef struct dccn_eq_buffers {
     const float* x;               /* [batch,S,n_sc,2] raw `tx_ofdm` */
     const int32_t* bits;          /* [batch,D,nbits] */
@@ -640,6 +641,16 @@ typedef struct dccn_eq_buffers {
        graph-capturable, the generator's per-batch arguments stay outside the graph).  Honoured like x_next. */
     const dccn_gen_static* x_next_virtual;
     const int* tuning;            /* nullable: the plan's own tuning table, as dccn_rx_buffers.tuning */
+    /* Round 6: 1 = the step ALSO produces the batch x_next_virtual describes (the descriptor fully armed: bits_out, snr_db,
+       offset, seed, H_out ...): the generator's workgroups ride on the step's pilot-bottleneck backward launch (15 us of VALU
+       work beside MFMA tiles and HBM streams instead of a launch of its own in front of the step; a launch of its own when the
+       plan has no such launch).  The caller no longer issues dccn_gen_static_frames for that batch.  Same draws, same bits. */
+    int gen_next_rides;
+    /* Round 6, nullable: the training loop's per-step monitors (dccn_eq_monitor_accumulate: chan_rms of THIS step's channel
+       estimate against `chan`, and {ce_mean, berlin, tx_power, noise_power, chan_rms} added onto acc5) as part of the step's
+       optimizer launch instead of a launch of their own behind the step.  chest / metrics / tx_power must be the step's own.
+       Same additions of the same values: the accumulators keep their bits. */
+    const struct dccn_eq_monitor* monitor;
 } dccn_eq_buffers;
 /* 1: dccn_eq_train_step honours dccn_eq_buffers.x_next for this shape */
 int dccn_eq_norm_rides(const dccn_eq_shape* shape);
