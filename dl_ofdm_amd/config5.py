@@ -105,7 +105,7 @@ def _broadcast(t, src: int, group=None):
 def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs: int, rx_epoch_scale: float = 1.0,
                  rank: int = 0, device="cuda", verbose: bool = False, world: int = 1, group=None,
                  timing: Optional[dict] = None, ckpt_dir: Optional[str] = None, chain_streams: Optional[int] = None,
-                 chain_priority: bool = True, chain_group: Optional[int] = None):
+                 chain_priority: bool = True, chain_group: Optional[int] = None, sweep_plan: Optional[dict] = None):
     """nbits -> (equaliser flags, EqualizerTrainer with the best checkpoint loaded), on every rank.
     eq_epochs <= 0: the reference driver's cap of 4000 * nbits epochs (run_local_ofdm.py:96; early stopping ends it sooner).
 
@@ -168,6 +168,13 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
         for nbits, out in zip(unit, outs):
             H.load_checkpoint(out["best_path"], out["trainer"], with_optimizer=False)
             trainers[nbits] = (flags[nbits][1], out["trainer"])
+            if sweep_plan is not None and world == 1:
+                # this chain's own sweep points right away, on this chain's stream: the other chains are still training, so
+                # the sweep leaves the end of the job (the points carry their seeds: who evaluates them, and when, changes nothing)
+                ev = point_evaluator({nbits: trainers[nbits]}, sweep_plan["frames"])
+                for p_ in sweep_plan["points"]:
+                    if p_.nbits == nbits:
+                        sweep_plan["rows"][p_.index] = ev(p_)
             if timing is not None:
                 timing["train_rx_%d" % nbits] = t_rx[nbits]
                 timing["train_eq_%d" % nbits] = time.time() - t2
@@ -262,20 +269,18 @@ def train_models(out_dir: str, nbits_list: Sequence[int], frames: int, eq_epochs
     return trainers
 
 
-def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str], snrs: Sequence[float], frames: int,
-               rank: int = 0, world: int = 1, group=None, base_seed: int = 77):
-    """The sharded DCCN sweep: returns (points, float64 table [points, 6]) on every rank."""
-    import torch
-    from . import ofdm, sweep
+def point_evaluator(trainers: Dict, frames: int):
+    """evaluate(point) -> the six table values of one (modulation, channel, SNR) point on its own device-generated batch"""
+    import copy as _copy
+    from . import ofdm
     from .datagen import DeviceDataGen
-    pts = sweep.make_points(list(nbits_list), list(channels), list(snrs), base_seed=base_seed)
     gens = {}
 
     def evaluate(p):
         hf, tr = trainers[p.nbits]
         key = (p.nbits, p.channel)
         if key not in gens:
-            fl = copy.deepcopy(hf)
+            fl = _copy.deepcopy(hf)
             fl.channel = p.channel
             gens[key] = DeviceDataGen(fl, ofdm.ofdm_tx(fl), device=tr.device, seed=p.seed)
             gens[key].want_noise_power = False
@@ -286,6 +291,22 @@ def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str
         m = tr._metrics(pl.metrics_buf, pl.tx_power)
         c = m["conf"]
         return [c[0][0], c[0][1], c[1][0], c[1][1], m["ce_sum"], m["count"]]
+
+    return evaluate
+
+
+def sweep_dccn(trainers: Dict, nbits_list: Sequence[int], channels: Sequence[str], snrs: Sequence[float], frames: int,
+               rank: int = 0, world: int = 1, group=None, base_seed: int = 77, done_rows: Optional[dict] = None):
+    """The sharded DCCN sweep: returns (points, float64 table [points, 6]) on every rank.  ``done_rows`` (world 1): rows some
+    points already have (point index -> six values: a chain's own points, evaluated by its thread as soon as it was trained)."""
+    import torch
+    from . import sweep
+    pts = sweep.make_points(list(nbits_list), list(channels), list(snrs), base_seed=base_seed)
+    ev = point_evaluator(trainers, frames)
+    done_rows = done_rows if (done_rows and world == 1) else {}
+
+    def evaluate(p):
+        return done_rows[p.index] if p.index in done_rows else ev(p)
 
     dev = next(iter(trainers.values()))[1].device
     table = sweep.run_sweep(pts, evaluate, rank, world, device=torch.device(dev), group=group)
@@ -392,10 +413,14 @@ def run(out_dir: str, frames: int = 20000, eq_epochs: int = 600, classical_frame
 
         side = threading.Thread(target=classical_side, name="c5-classical")
         side.start()
+    splan = None
+    if world == 1 and (chain_streams is None or chain_streams > 1):
+        from . import sweep as _sw
+        splan = dict(frames=frames, rows={}, points=_sw.make_points(list(nbits_list), list(channels), list(snrs), base_seed=77))
     trainers = train_models(out_dir, nbits_list, frames, eq_epochs, rx_epoch_scale, rank, device, verbose, world=world,
-                            timing=timing, ckpt_dir=ckpt_dir, chain_streams=chain_streams, chain_group=chain_group)
+                            timing=timing, ckpt_dir=ckpt_dir, chain_streams=chain_streams, chain_group=chain_group, sweep_plan=splan)
     t1 = time.time()
-    pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world)
+    pts, table = sweep_dccn(trainers, nbits_list, channels, snrs, frames, rank, world, done_rows=splan["rows"] if splan else None)
     ber, _ = sweep.ber_loss(table)
     timing["sweep"] = time.time() - t1
     if verbose and rank == 0:
