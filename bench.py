@@ -235,13 +235,13 @@ def prewarm(step, dev, seconds=0.5):
         torch.cuda.synchronize(dev)
 
 
-def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True):
+def measure_config(name, dev, steps=20, warmup=5, graph=False, pipeline=True, want_prob=False):
     """ms per training step of another BASELINE configuration (same engine and launch mode, HIP-event timing)."""
     import torch
     from dl_ofdm_amd.engine import HipTimer, RxDims, RxEngine
     c = CONFIGS[name]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
-    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False,
+    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=want_prob, want_tx_power=True, want_z=False,
                    want_dfft=False, want_grads=False)
     g = torch.Generator(device=dev)
     g.manual_seed(4321)
@@ -471,6 +471,8 @@ def main():
     ap.add_argument("--regions", type=int, default=7,
                     help="how many times the timed K-step region is run back to back (each bracketed by barrier + synchronize); "
                          "`value` is the MEDIAN region, all of them are listed in step.regions_ms")
+    ap.add_argument("--store-prob", action="store_true",
+                    help="also write `output:0` (the per-bit probabilities) to HBM in every training step; the reference's step does not fetch it")
     ap.add_argument("--no-boundaries", action="store_true", help="skip the in-situ step timeline (step.boundaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
@@ -520,9 +522,13 @@ def main():
     c = CONFIGS[args.config]
     S, kin = 7, c["nfft"] + c["cp"]
     dims = RxDims(S=S, kin=kin, F=c["F"], D=c["D"], nbits=c["nbits"])
-    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1 + rank, want_prob=True, want_tx_power=True,
-                   want_z=False, want_dfft=False, want_grads=False)   # z / dfft are consumed inside the launches that produce them (fused
-    #                                                  dense+tail forward, fused backward) whenever the library's plan allows
+    # The step is the reference's `session.run([train_op, power_tx, ce_mean, berlin], ...)` (dev/py/ofdmreceiver_np.py:234): it
+    # fetches the update, the TX power, the loss and the BER -- not `output:0`.  The probabilities are therefore formed and
+    # consumed in registers (loss, decisions, backward) and not written to HBM, as the harness's own loop runs it
+    # (dl_ofdm_amd/receiver.py); `--store-prob` also materialises them (6 MB per C2 step, round 1-5 lines did).  z / dfft are
+    # consumed inside the launches that produce them (fused dense + tail forward, fused backward) whenever the plan allows.
+    eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1 + rank, want_prob=args.store_prob, want_tx_power=True,
+                   want_z=False, want_dfft=False, want_grads=False)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     eng.x.copy_(torch.randn(eng.x.shape, generator=g, device=dev))
@@ -679,7 +685,7 @@ def main():
             # replay, HIP events on the launch stream): C3 = config[2] shape (16-QAM), C4 = config[3] (N=1024, MFMA-bound)
             eng = None
             torch.cuda.empty_cache()
-            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph, pipeline=pipeline) for k in ("c3", "c4")}
+            result["configs"] = {k: measure_config(k, dev, steps=20, warmup=5, graph=use_graph, pipeline=pipeline, want_prob=args.store_prob) for k in ("c3", "c4")}
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_e2e:
         eng = None
         torch.cuda.empty_cache()

@@ -171,12 +171,12 @@ __global__ __launch_bounds__(kGemmThreads) void cconv_fwd_staged_kernel(const Ge
     float* Cp = p.C + (size_t)(m0 + wm0 + 4 * h) * p.ldc + col;
     if (m0 + BM <= p.M && n0 + BN <= p.N) {                       // interior tile (block-uniform): stores without exec masks
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[r] + bj;
+        for (int r = 0; r < 16; ++r) out_store<0>(Cp + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[r] + bj);
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < p.M && col < p.N) Cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[r] + bj;
+            if (row < p.M && col < p.N) out_store<0>(Cp + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[r] + bj);
         }
     }
     stamp_mark(p.stamp, 1);

@@ -164,6 +164,47 @@ __device__ __forceinline__ T* chain_at(T* p, const long long off) {
         if (::dccn::tl_chain.G != 1 || ::dccn::tl_chain.co.off[0] != 0) return DCCN_ERR_UNSUPPORTED; \
     } while (0)
 
+// ---- output stores of a step's launches: plain (write-back) or agent-scope (`sc1`: written through the XCD's L2) -------------
+// A launch boundary drains every L2 of its dirty lines before the next launch starts: tools/gapdirty.hip measures the boundary
+// at 1.05 us + 0.12 us per MB the finished kernel left dirty (profiles/r06_gapdirty.txt).  A stream written with agent-scope
+// stores is written through while the kernel still computes and leaves nothing to drain.  DCCN_WT_STORES = bit mask of the
+// streams written that way (build option; the stream index is the template argument):
+//   0 C-Conv forward output   1 dz of the fused dense + tail   2 dense dW slabs, dWeff partials, column sums of the backward
+//   3 x_norm of the optimizer launch's R0 blocks   4 parameters / Adam slots of the optimizer launch
+// Measured per stream on the C2 step (tools/wtscan.sh, in-situ timeline, profiles/r06_wt_stores.txt): 0: boundary in front of the
+// dense launch 1.73 -> 1.36 us for +0.1 us of C-Conv forward; 2: boundary in front of the optimizer launch 2.37 -> 1.50 us, the
+// backward launch unchanged (its blocks end at different times: the write-through overlaps the launch's own tail); 1: the
+// boundary gains 0.36 us but the dense launch loses 1.3 (every block stores at the very end); 3 / 4: the boundary in front of
+// the next C-Conv forward 2.5 -> 1.6-2.0 us but the bandwidth-bound optimizer launch loses 0.4-1.0.  Shipped: streams 0 and 2
+// (step 72.2 -> 71.4 us); the values stored are the same either way.
+#ifndef DCCN_WT_STORES
+#define DCCN_WT_STORES 5
+#endif
+template <int STREAM>
+__device__ __forceinline__ void out_store(float* p, const float v) {
+    if constexpr ((DCCN_WT_STORES >> STREAM) & 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int STREAM>
+__device__ __forceinline__ void out_store2(float* p, const float x, const float y) {      // p 8-byte aligned
+    if constexpr ((DCCN_WT_STORES >> STREAM) & 1) {
+        const unsigned long long b = ((unsigned long long)__builtin_bit_cast(unsigned, y) << 32) | __builtin_bit_cast(unsigned, x);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<float2*>(p) = make_float2(x, y);
+    }
+}
+template <int STREAM>
+__device__ __forceinline__ void out_store4(float* p, const float x, const float y, const float z, const float w) {   // 16-byte aligned
+    if constexpr ((DCCN_WT_STORES >> STREAM) & 1) {
+        typedef float wt_f32x4 __attribute__((ext_vector_type(4)));
+        const wt_f32x4 v = {x, y, z, w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w);
+    }
+}
+
 // ---- wave reductions (wave64) on the DPP crossbar: no LDS round trips ------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror sums each 16-lane row
 // (fixed order => deterministic), then the four row sums are combined through v_readlane.

@@ -19,6 +19,7 @@
 #include "eq_bottleneck.h"
 #include "datagen.h"
 #include "im2col.h"
+#include "cconv_dx_narrow.h"
 #include "classical.h"
 
 namespace dccn {
@@ -2879,14 +2880,17 @@ int dccn_cconv_patch_bwd_supported(int B, int L, int Wd, int C, int Lo, int Wo, 
     if (!dccn_cconv_patch_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, F)) return 0;
     if (sL <= 0 || sW <= 0) return 0;
     if ((long long)B * Lo * Wo * F * 2 >= (1LL << 31)) return 0;          // 32-bit element offsets into dout
-    int mode = 1;                                                          // bit 0: weight gradient
-    if (sL == 1 && sW == 1) {
-        mode |= 2;                                                         // bit 1: input gradient qualifies
-        // bit 2: ... and is expected to beat GEMM + col2im: its GEMM multiplies ceil(2C/64) column tiles by ntl*ntw*2F deep
-        // rows where the other route multiplies ceil(2kin/64) tiles by 2F -- few channels (2C << 64) leave most of every tile
-        // empty ntl*ntw times over, which costs more than the [rows, kin, 2] round trip saves
-        const long long imp = (long long)ceil_div(2 * C, 64) * ntl * ntw, col = (long long)ceil_div(2 * ntl * ntw * C, 64);
-        if (imp <= 2 * col) mode |= 4;
+    int mode = 1 | 2;                  // bit 0: weight gradient; bit 1: input gradient as an implicit GEMM (any stride, round 6)
+    // bit 2: ... and it is expected to beat GEMM + col2im.  Cost per INPUT position in units of 16 tile columns x 2F deep rows:
+    //   few channels (2C <= 32, cconv_dx_narrow.h): ceil(2C/16) columns x the taps of the position's stride phase (ntl*ntw / (sL*sW));
+    //   otherwise (64-wide tiles, inverse-stride gather): 4 ceil(2C/64) columns x ALL ntl*ntw taps (zeros where the stride skips);
+    //   GEMM + col2im: 4 ceil(2 kin/64) columns per OUTPUT position (sL*sW times fewer) plus the [rows, kin, 2] round trip and the
+    //   scatter launch -- which is why the implicit route may cost up to 3x (narrow) / 2x (wide) the other's tile columns.
+    const long long taps = (long long)ntl * ntw, ss = (long long)sL * sW, col = 4LL * ceil_div(2 * ntl * ntw * C, 64);
+    if (cconv_dx_narrow_ok(C, F, sL, sW)) {
+        if ((long long)ceil_div(2 * C, 16) * taps <= 3 * col) mode |= 4;          // (both sides per input position: x ss cancels)
+    } else if (4LL * ceil_div(2 * C, 64) * taps * ss * ss <= 2 * col) {
+        mode |= 4;
     }
     return mode;
 }
@@ -2926,10 +2930,12 @@ int dccn_cconv_patch_bwd_w(const float* x, const float* dout, float* dw, float* 
     DCCN_LAUNCH_CHECK();
     return DCCN_OK;
 }
-// input gradient at stride 1: dx[b,l,w,(c,iq)] = sum over taps of dout[b, l-l0-ti, w-w0-tj, :] . Weff[(ti,tj,c,iq), :] -- a
+// input gradient: dx[b,l,w,(c,iq)] = sum over taps of dout[b, (l-l0-ti)/sL, (w-w0-tj)/sW, :] . Weff[(ti,tj,c,iq), :] -- a
 // convolution of dout with the tap-flipped transposed weights, i.e. the SAME implicit GEMM with dout as the gathered operand
 // (geometry: rows = input positions, taps t' = nt-1-t, origin -(l0+ntl-1)) and Bt[(c,iq)][(ti',tj',n)] as a plain k-contiguous
 // operand built from w by the little kernel below (4 kin F floats).  No [rows, kin, 2] gradient-of-patches tensor, no col2im.
+// Strides (round 6): a tap contributes where its fine position is a multiple of the forward stride -- the loader's
+// inverse-stride gather (PatchGeom::isL / isW) reads dout there and zeros elsewhere.
 __global__ __launch_bounds__(256) void cconv_flip_wt_kernel(const float* __restrict__ w, float* __restrict__ bt, int C, int ntl,
                                                             int ntw, int F) {
     const long long K = (long long)ntl * ntw * 2 * F, total = 2LL * C * K;
@@ -2963,6 +2969,15 @@ int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, 
     const long long total = 4LL * C * ntl * ntw * F;
     hipLaunchKernelGGL(cconv_flip_wt_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, w, bt, C, ntl, ntw, F);
     DCCN_LAUNCH_CHECK();
+    if (cconv_dx_narrow_ok(C, F, sL, sW)) {   // few channels: 16-column tiles, strides by phase (cconv_dx_narrow.h)
+        DxNarrowArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dout = dout; a.bt = bt; a.dx = dx;
+        a.B = B; a.L = L; a.Wd = Wd; a.C2 = 2 * C; a.Lo = Lo; a.Wo = Wo; a.ntl = ntl; a.ntw = ntw; a.F2 = 2 * F;
+        a.l0 = -(tl0 - pl0) - (ntl - 1); a.w0 = -(tw0 - pw0) - (ntw - 1);
+        a.sL = sL; a.sW = sW;
+        return launch_cconv_dx_narrow(a, s);
+    }
     GemmParams p = gp_zero();                 // dx[B*L*Wd, 2C] = patches'(dout)[., ntl*ntw*2F] . Bt^T
     p.A = dout; p.B = bt; p.C = dx;
     p.M = B * L * Wd; p.N = 2 * C; p.K = ntl * ntw * 2 * F;
@@ -2971,6 +2986,9 @@ int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, 
     p.vecA = 1; p.vecB = 1;
     p.pg.L = Lo; p.pg.Wd = Wo; p.pg.c2 = 2 * F; p.pg.Lo = L; p.pg.Wo = Wd; p.pg.ntl = ntl; p.pg.ntw = ntw;
     p.pg.sL = 1; p.pg.sW = 1; p.pg.l0 = -(tl0 - pl0) - (ntl - 1); p.pg.w0 = -(tw0 - pw0) - (ntw - 1);
+    p.pg.isL = sL; p.pg.isW = sW;
+    patch_div_magic(sL, p.pg.il_mul, p.pg.il_shift);
+    patch_div_magic(sW, p.pg.iw_mul, p.pg.iw_shift);
     return launch_gemm<OP_KPATCH, OP_KCONTIG, 0, TAG_CCONV_BWD_X>(p, 1, s);
 }
 int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,

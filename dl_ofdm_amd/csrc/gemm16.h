@@ -716,7 +716,7 @@ __device__ __forceinline__ void gemm16_block(const GemmParams& p, const TailEpiP
         if constexpr (BWD && !(GEMM16_ABL & 32)) {
 #pragma unroll
             for (int ci = 0; ci < NCELL; ++ci)
-                if (cvalid[ci]) *reinterpret_cast<float2*>(cdz[ci]) = cdzv[ci];
+                if (cvalid[ci]) out_store2<1>(cdz[ci], cdzv[ci].x, cdzv[ci].y);
         }
         // (KS == 1: the k-loop ended with a barrier, nobody reads the tile buffers any more; KS > 1: red lies behind the
         // exchange region, which is only read above)

@@ -47,6 +47,12 @@ struct PatchGeom {
     int L, Wd, c2, Lo, Wo, ntl, ntw, sL, sW, l0, w0;
     unsigned per_mul, wo_mul;        // row -> (b, lo, wo) without integer division (gemm_kmajor.h patch_div): / (Lo*Wo), / Wo
     int per_shift, wo_shift;
+    // inverse strides (input gradient of a STRIDED convolution, dccn_cconv_patch_bwd_x): the gathered tensor is the
+    // convolution's output; a row's tap meets data only where its fine position n = row position + l0 + ti is a multiple of
+    // the forward stride: source l = n / isL (multiply-shift, patch_div_magic), zeros elsewhere.  isL, isW <= 1: plain gather.
+    int isL, isW;
+    unsigned il_mul, iw_mul;
+    int il_shift, iw_shift;
 };
 // floor(n / d) = (n * mul) >> shift for every 0 <= n < 2^31:  s = ceil(log2 d), mul = ceil(2^(31+s) / d) <= 2^32 - 1
 // (mul d = 2^(31+s) + e with e < d <= 2^s, so the error term n e / (d 2^(31+s)) stays below 1/d)
@@ -229,8 +235,19 @@ struct Tile {
             p_cc = r2 - p_tj * g.c2;
             p_kok = k < kend;
         }
-        const int l = (int)voff[3 * v + 1] + p_ti, w = (int)voff[3 * v + 2] + p_tj;
-        const bool ok = p_kok && (unsigned)l < (unsigned)g.L && (unsigned)w < (unsigned)g.Wd;
+        int l = (int)voff[3 * v + 1] + p_ti, w = (int)voff[3 * v + 2] + p_tj;
+        bool ok = p_kok;
+        if (g.isL > 1) {             // (uniform branch: the plain gather pays one scalar compare)
+            const int q = (int)(((unsigned long long)(unsigned)max(l, 0) * g.il_mul) >> g.il_shift);
+            ok = ok && l >= 0 && q * g.isL == l;
+            l = q;
+        }
+        if (g.isW > 1) {
+            const int q = (int)(((unsigned long long)(unsigned)max(w, 0) * g.iw_mul) >> g.iw_shift);
+            ok = ok && w >= 0 && q * g.isW == w;
+            w = q;
+        }
+        ok = ok && (unsigned)l < (unsigned)g.L && (unsigned)w < (unsigned)g.Wd;
         const unsigned off = ok ? (unsigned)((l * g.Wd + w) * g.c2 + p_cc) : 0u;       // (padding: any legal address)
         r[v] = *reinterpret_cast<const float4*>(p + (size_t)voff[3 * v] + off);
         okmask = (okmask & ~(1u << v)) | ((ok ? 1u : 0u) << v);

@@ -222,8 +222,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                *reinterpret_cast<float2*>(Cz + (size_t)(rowb + 2 * r + s) * p.ldc + col) =
-                    make_float2(acc[s][0][r], acc[s][1][r]);
+                out_store2<2>(Cz + (size_t)(rowb + 2 * r + s) * p.ldc + col, acc[s][0][r], acc[s][1][r]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -231,7 +230,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             for (int s = 0; s < 2; ++s) {
                 const int row = rowb + 2 * r + s;
                 if (row < p.M && col < p.N)
-                    *reinterpret_cast<float2*>(Cz + (size_t)row * p.ldc + col) = make_float2(acc[s][0][r], acc[s][1][r]);
+                    out_store2<2>(Cz + (size_t)row * p.ldc + col, acc[s][0][r], acc[s][1][r]);
             }
     }
     if (COLSUM && do_cs) {
@@ -244,7 +243,7 @@ __device__ __forceinline__ void kmajor_block(const GemmParams& p, const int L, c
             bsum.w += __shfl_xor(bsum.w, m, 64);
         }
         const int cc = n0 + 4 * c;
-        if (lane < 16 && cc < p.N) *reinterpret_cast<float4*>(p.colsum + goS + (size_t)z * p.N + cc) = bsum;
+        if (lane < 16 && cc < p.N) out_store4<2>(p.colsum + goS + (size_t)z * p.N + cc, bsum.x, bsum.y, bsum.z, bsum.w);
     }
 }
 

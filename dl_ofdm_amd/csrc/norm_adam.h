@@ -359,7 +359,7 @@ __device__ __forceinline__ void norm_fused_body(const float* __restrict__ x, flo
             };
             float o[4] = {div_rs2(v[p].x * inv[0] + sh[0]), div_rs2(v[p].y * inv[1] + sh[1]),
                           div_rs2(v[p].z * inv[2] + sh[2]), div_rs2(v[p].w * inv[3] + sh[3])};
-            *reinterpret_cast<float4*>(y + (size_t)r * cols + c4) = make_float4(o[0], o[1], o[2], o[3]);
+            out_store4<3>(y + (size_t)r * cols + c4, o[0], o[1], o[2], o[3]);
             if (power_partial != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
@@ -734,9 +734,9 @@ __device__ __forceinline__ void adam_stream_role(const AdamRxArgs& a, const dccn
             __builtin_nontemporal_store(sm, reinterpret_cast<nt_f32x4*>(a.m + i));
             __builtin_nontemporal_store(sv, reinterpret_cast<nt_f32x4*>(a.v + i));
         } else if (full) {
-            *reinterpret_cast<float4*>(a.param + i) = make_float4(p[0], p[1], p[2], p[3]);
-            *reinterpret_cast<float4*>(a.m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            *reinterpret_cast<float4*>(a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            out_store4<4>(a.param + i, p[0], p[1], p[2], p[3]);
+            out_store4<4>(a.m + i, mm[0], mm[1], mm[2], mm[3]);
+            out_store4<4>(a.v + i, vv[0], vv[1], vv[2], vv[3]);
         } else {
             for (int e = 0; e < cnt; ++e) { a.param[i + e] = p[e]; a.m[i + e] = mm[e]; a.v[i + e] = vv[e]; }
         }

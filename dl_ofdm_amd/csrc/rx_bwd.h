@@ -103,7 +103,7 @@ __device__ __forceinline__ void dweff_epilogue(const DweffArgs& d, const int ntn
         *reinterpret_cast<kf32x4*>(sX + row * RA + ((unsigned)(4 * c4) ^ ((unsigned)(row & 1) << 5))) = rx[v];
     }
     __syncthreads();
-    if (tid < 64) d.colsum[(size_t)q * 64 + tid] = sC[tid] + sC[64 + tid];
+    if (tid < 64) out_store<2>(d.colsum + (size_t)q * 64 + tid, sC[tid] + sC[64 + tid]);
 
     // 3. partial[m][n] = sum over the tile's 64 frames: 16 k-steps, fragments of step ks+1 read under the MFMAs of ks
     const int c = lane & 15, kq = lane >> 4, hA = wid >> 1, hB = wid & 1;
@@ -158,14 +158,14 @@ __device__ __forceinline__ void dweff_epilogue(const DweffArgs& d, const int ntn
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float2*>(P + (size_t)(32 * ch + 16 * hA + 4 * kq + r) * 64) =
-                make_float2(aw[ch][0][0][r] - aw[ch][1][1][r], aw[ch][0][1][r] - aw[ch][1][0][r]);
+            out_store2<2>(P + (size_t)(32 * ch + 16 * hA + 4 * kq + r) * 64, aw[ch][0][0][r] - aw[ch][1][1][r],
+                          aw[ch][0][1][r] - aw[ch][1][0][r]);
     if constexpr (ODD) {
         // odd unit: accumulator row i = 4 kq + r is dWeff row 32 (NU-1) + 8 kq + 4 (r/2) + 2 hA + r%2: n = 16 (NU-1) + 4 kq + 2 (r/2) + hA
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp)
-            *reinterpret_cast<float2*>(P + (size_t)(16 * (NU - 1) + 4 * kq + 2 * rp + hA) * 64) =
-                make_float2(ao[0][2 * rp] - ao[1][2 * rp + 1], ao[1][2 * rp] - ao[0][2 * rp + 1]);
+            out_store2<2>(P + (size_t)(16 * (NU - 1) + 4 * kq + 2 * rp + hA) * 64, ao[0][2 * rp] - ao[1][2 * rp + 1],
+                          ao[1][2 * rp] - ao[0][2 * rp + 1]);
     }
 }
 

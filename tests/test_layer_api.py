@@ -310,13 +310,16 @@ def test_multiply_shift_division_of_the_patch_loader_is_exact():
 
 
 def test_patch_backward_route_bits():
-    """dccn_cconv_patch_bwd_supported: bit 0 weight gradient, bit 1 input gradient (stride 1), bit 2 input gradient worth it"""
+    """dccn_cconv_patch_bwd_supported: bit 0 weight gradient, bit 1 input gradient as an implicit GEMM (any stride since round
+    6), bit 2 that route expected to beat GEMM + col2im"""
     from dl_ofdm_amd import _lib
     f = _lib.load().dccn_cconv_patch_bwd_supported
-    assert f(8, 560, 1, 2, 560, 1, 5, 1, 1, 1, 64) == 3          # 2 channels: 4 of 64 tile columns used, five taps deep
+    assert f(8, 560, 1, 2, 560, 1, 5, 1, 1, 1, 64) == 7          # 2 channels: 16-column tiles (cconv_dx_narrow.h), five taps deep
     assert f(8, 560, 1, 16, 560, 1, 5, 1, 1, 1, 32) == 7
     assert f(8, 560, 1, 64, 560, 1, 5, 1, 1, 1, 64) == 7
-    assert f(8, 560, 1, 16, 280, 1, 5, 1, 2, 1, 32) == 1         # strided: input gradient by col2im
+    assert f(8, 560, 1, 16, 280, 1, 5, 1, 2, 1, 32) == 7         # strided, 32 columns: narrow tiles, two phases of 2-3 taps
+    assert f(8, 560, 1, 64, 280, 1, 5, 1, 2, 1, 32) == 3         # strided, 128 columns: inverse-stride gather works, col2im is cheaper
+    assert f(8, 7, 64, 2, 7, 64, 7, 64, 1, 1, 2) == 3            # 448 taps x 4 columns: 16-column tiles stay 3/4 empty 448 times over
     assert f(8, 560, 1, 3, 560, 1, 5, 1, 1, 1, 32) == 0          # odd channel count: no float4 pieces
 
 

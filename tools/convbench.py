@@ -3,7 +3,7 @@ operand loader gathers the taps) against the im2col + GEMM route (dccn_cconv_im2
 dccn_cconv_gemm_fwd reads it back), same process, alternating rounds: the forward, and the backward (weight + input
 gradient) as implicit GEMMs (dccn_cconv_patch_bwd_w / _bwd_x) against im2col + GEMM + GEMM + col2im.
 
-    python tools/convbench.py [--k 5] [--iters 100] [--rounds 5]
+    python tools/convbench.py [--k 5] [--stride 1] [--iters 100] [--rounds 5]
 """
 import argparse
 import json
@@ -29,13 +29,14 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--stride", type=int, default=1)
     a = ap.parse_args()
     st_ = torch.cuda.current_stream().cuda_stream
     for B, L, C, F in SHAPES:
         x = torch.randn(B, L, C, 2, device="cuda")
         store = CX.VariableStore(seed=1)
         with torch.no_grad():
-            CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+            CX.layers_conv1d_complex(x, F, a.k, strides=a.stride, padding="same", scope=store)
         times = {True: [], False: []}
         for _ in range(a.rounds):
             for implicit in (True, False):
@@ -43,32 +44,32 @@ def main():
                 with torch.no_grad():
                     for _ in range(5):
                         store.begin()
-                        CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+                        CX.layers_conv1d_complex(x, F, a.k, strides=a.stride, padding="same", scope=store)
                     torch.cuda.synchronize()
                     t = HipTimer()
                     t.start(st_)
                     for _ in range(a.iters):
                         store.begin()
-                        CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+                        CX.layers_conv1d_complex(x, F, a.k, strides=a.stride, padding="same", scope=store)
                     t.stop(st_)
                 times[implicit].append(t.elapsed_ms() / a.iters)
         CX.IMPLICIT_GEMM = True
         med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
-        flop = 2.0 * B * L * (2 * a.k * C) * (2 * F)
+        flop = 2.0 * B * ((L + a.stride - 1) // a.stride) * (2 * a.k * C) * (2 * F)
         # backward of the same layer: one forward graph, its backward replayed (torch.autograd.grad, graph retained)
         xg = x.clone().requires_grad_()
         store.begin()
-        y = CX.layers_conv1d_complex(xg, F, a.k, strides=1, padding="same", scope=store)
+        y = CX.layers_conv1d_complex(xg, F, a.k, strides=a.stride, padding="same", scope=store)
         g = torch.randn_like(y)
         leaves = (xg, store.tensor("conv2d/kernel"), store.tensor("conv2d/bias"))
         # the parts alone: graphs in which only the input / only the variables require a gradient
         kv, bv = store.tensor("conv2d/kernel"), store.tensor("conv2d/bias")
         kv.requires_grad_(False); bv.requires_grad_(False)
         store.begin()
-        y_x = CX.layers_conv1d_complex(xg, F, a.k, strides=1, padding="same", scope=store)
+        y_x = CX.layers_conv1d_complex(xg, F, a.k, strides=a.stride, padding="same", scope=store)
         kv.requires_grad_(True); bv.requires_grad_(True)
         store.begin()
-        y_w = CX.layers_conv1d_complex(x, F, a.k, strides=1, padding="same", scope=store)
+        y_w = CX.layers_conv1d_complex(x, F, a.k, strides=a.stride, padding="same", scope=store)
         parts = {"": (y, leaves), "_dx": (y_x, leaves[:1]), "_dw": (y_w, leaves[1:])}
         bmed = {}
         for tag, (yy, lv) in parts.items():
@@ -98,7 +99,7 @@ def main():
             torch.autograd.grad(y, leaves, g, retain_graph=True)
         t.stop(st_)
         bmed["default"] = t.elapsed_ms() / a.iters
-        print(json.dumps(dict(shape=dict(B=B, L=L, C=C, F=F, k=a.k), implicit_ms=round(med[True], 4), im2col_ms=round(med[False], 4),
+        print(json.dumps(dict(shape=dict(B=B, L=L, C=C, F=F, k=a.k, stride=a.stride), implicit_ms=round(med[True], 4), im2col_ms=round(med[False], 4),
                               speedup=round(med[False] / med[True], 2), implicit_tflops=round(flop / med[True] / 1e9, 2),
                               patch_tensor_mb=round(B * L * a.k * C * 2 * 4 / 1e6, 1),
                               bwd_ms={k: round(v, 4) for k, v in bmed.items()},

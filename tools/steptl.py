@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tunes", default="")
     ap.add_argument("--bursts", type=int, default=8)
     ap.add_argument("--lead", type=int, default=400)
+    ap.add_argument("--prob", type=int, default=0, help="1: the step also writes output:0 (bench.py --store-prob)")
     a = ap.parse_args()
     lib = _lib.load()
     for kv in filter(None, a.tunes.split(",")):
@@ -28,13 +29,14 @@ def main():
         assert lib.dccn_set_tuning(int(k), int(v)) == 0, kv
     c = bench.CONFIGS[a.config]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
-    eng = RxEngine(dims, c["frames"], train=True, want_prob=True, want_tx_power=True, want_z=False)
+    eng = RxEngine(dims, c["frames"], train=True, want_prob=bool(a.prob), want_tx_power=True, want_z=False, want_dfft=False,
+                   want_grads=False)       # bench.py's plan
     eng.x.normal_()
     eng.bits.random_(0, 2)
     for _ in range(50):
         eng.train_step_pipelined()
     res = steptrace.trace_steps(eng.train_step_pipelined, eng.device, ring=16, bursts=a.bursts, lead=a.lead)
-    res["config"], res["tunes"] = a.config, a.tunes
+    res["config"], res["tunes"], res["prob"] = a.config, a.tunes, a.prob
     print(json.dumps(res))
 
 
