@@ -30,9 +30,10 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--shapes", default="0,1,2", help="indices into SHAPES")
     a = ap.parse_args()
     st_ = torch.cuda.current_stream().cuda_stream
-    for B, L, C, F in SHAPES:
+    for B, L, C, F in [SHAPES[int(i)] for i in a.shapes.split(",")]:
         x = torch.randn(B, L, C, 2, device="cuda")
         store = CX.VariableStore(seed=1)
         with torch.no_grad():
