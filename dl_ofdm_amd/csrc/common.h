@@ -171,17 +171,24 @@ __device__ __forceinline__ T* chain_at(T* p, const long long off) {
 // streams written that way (build option; the stream index is the template argument):
 //   0 C-Conv forward output   1 dz of the fused dense + tail   2 dense dW slabs, dWeff partials, column sums of the backward
 //   3 x_norm of the optimizer launch's R0 blocks   4 parameters / Adam slots of the optimizer launch
+//   5 y, noise and label bits of the fused static-channel generator (datagen.h)
 // Measured per stream on the C2 step (tools/wtscan.sh, in-situ timeline, profiles/r06_wt_stores.txt): 0: boundary in front of the
 // dense launch 1.73 -> 1.36 us for +0.1 us of C-Conv forward; 2: boundary in front of the optimizer launch 2.37 -> 1.50 us, the
 // backward launch unchanged (its blocks end at different times: the write-through overlaps the launch's own tail); 1: the
 // boundary gains 0.36 us but the dense launch loses 1.3 (every block stores at the very end); 3 / 4: the boundary in front of
-// the next C-Conv forward 2.5 -> 1.6-2.0 us but the bandwidth-bound optimizer launch loses 0.4-1.0.  Shipped: streams 0 and 2
+// the next C-Conv forward 2.5 -> 1.6-2.0 us but the bandwidth-bound optimizer launch loses 0.4-1.0; 5: the generate-and-train
+// loop 0.0987 -> 0.0962 ms per batch (13 MB less to drain in front of the step's first launch).  Shipped: streams 0, 2 and 5
 // (step 72.2 -> 71.4 us); the values stored are the same either way.
 #ifndef DCCN_WT_STORES
-#define DCCN_WT_STORES 5
+#define DCCN_WT_STORES 37
 #endif
 template <int STREAM>
 __device__ __forceinline__ void out_store(float* p, const float v) {
+    if constexpr ((DCCN_WT_STORES >> STREAM) & 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int STREAM>
+__device__ __forceinline__ void out_store(int* p, const int v) {
     if constexpr ((DCCN_WT_STORES >> STREAM) & 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }

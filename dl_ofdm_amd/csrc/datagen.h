@@ -420,7 +420,7 @@ __device__ __forceinline__ void gen_static_frames_body(const GenStaticArgs a, co
         for (int q = 0; q < NSMP; ++q) {
             const int i = tid + 256 * q;
             if (i < nfr * T) {
-                a.noise[(size_t)f0 * T + i] = z[q];
+                out_store2<5>(reinterpret_cast<float*>(a.noise + (size_t)f0 * T + i), z[q].x, z[q].y);
                 nw += (double)z[q].x * z[q].x + (double)z[q].y * z[q].y;
             }
         }
@@ -445,7 +445,7 @@ __device__ __forceinline__ void gen_static_frames_body(const GenStaticArgs a, co
                 const unsigned word = (a.abl & 2) ? (unsigned)cell : philox4x32_10((unsigned long long)cell, kStreamBits, a.offset, a.seed).v[0];
                 for (int j = 0; j < a.nbits; ++j) {
                     const int bit = (int)((word >> j) & 1u);
-                    a.bits_out[cell * a.nbits + j] = bit;
+                    out_store<5>(a.bits_out + cell * a.nbits + j, bit);
                     idx[q] = (idx[q] << 1) | bit;
                 }
             }
@@ -549,7 +549,7 @@ __device__ __forceinline__ void gen_static_frames_body(const GenStaticArgs a, co
         for (int q = 0; q < NSMP; ++q) {
             const int i = tid + 256 * q;
             if (i < nfr * T) {
-                a.y[(size_t)f0 * T + i] = yv[q];
+                out_store2<5>(reinterpret_cast<float*>(a.y + (size_t)f0 * T + i), yv[q].x, yv[q].y);
                 pw += (double)yv[q].x * yv[q].x + (double)yv[q].y * yv[q].y;
             }
         }

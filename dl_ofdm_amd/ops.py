@@ -199,9 +199,10 @@ _PATCH_BWD_DX_ALWAYS = False     # ... or the input gradient onto the implicit G
 class _CConvPatch(torch.autograd.Function):
     """dccn_cconv_patch_fwd: the general-k complex convolution as an implicit GEMM (the operand loader gathers the taps;
     no patch tensor in the forward).  The backward is implicit too where dccn_cconv_patch_bwd_supported says so: the weight
-    gradient's GEMM gathers its patch rows from x (dccn_cconv_patch_bwd_w), the input gradient at stride 1 is the same
-    implicit GEMM over dout with the taps flipped (dccn_cconv_patch_bwd_x).  Otherwise (strided input gradient): patches
-    materialised once by dccn_cconv_im2col, input gradient scattered back by dccn_cconv_col2im."""
+    gradient's GEMM gathers its patch rows from x (dccn_cconv_patch_bwd_w), the input gradient is the same implicit GEMM
+    over dout with the taps flipped (dccn_cconv_patch_bwd_x: any stride; 16-column tiles for few channels).  Only where
+    that is expected to lose (taps outnumbering the channels ~10:1, wide strided inputs): GEMM into the gradient of the
+    patches, scattered back by dccn_cconv_col2im."""
 
     @staticmethod
     def forward(ctx, x, w, bias, geom):

@@ -191,12 +191,16 @@ int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, floa
                          dccn_stream_t stream);
 /* The backward of the same convolutions without patch-sized tensors either (the gradients TensorFlow derives for
  * dev/py/complex.py:51-92, :140-196).  _bwd_supported: bit 0 = the weight gradient qualifies, bit 1 = the input gradient does
- * (stride 1 only), bit 2 = ... and is expected to be the faster route (enough channels to fill the GEMM's column tiles);
+ * (ANY stride since round 6), bit 2 = ... and is expected to be the faster route than GEMM + col2im (2C <= 32: 16-column
+ * tiles, strides by phase decomposition, csrc/cconv_dx_narrow.h -- unless the taps outnumber the channels ~10:1; wider inputs:
+ * 64-column tiles whose operand loader reads dout where a tap's fine position is a multiple of the stride -- at stride 1, or
+ * where the zeros a strided gather multiplies cost less than the [rows, kin, 2] round trip);
  * 0 -> dccn_cconv_im2col / _gemm_bwd_w / _gemm_bwd_x / _col2im as before.
  * _bwd_w: dw [ntl*ntw*C, 2F] (+ dbias [2F], nullable) = patches(x)^T . dout, the patch rows gathered from x [B, L, Wd, C, 2]
  *   by the weight-gradient GEMM's operand loader; dout [B*Lo*Wo, F, 2].  Deterministic (split-K slabs, fixed-order fold).
  * _bwd_x: dx [B, L, Wd, C, 2] = the convolution of dout with the tap-flipped transposed weights, as the same implicit GEMM
- *   gathering from dout (no [rows, kin, 2] intermediate, no scatter).  workspace: the flipped weights, 4*C*ntl*ntw*F floats. */
+ *   gathering from dout (no [rows, kin, 2] intermediate, no scatter), any strides.  workspace: the flipped weights,
+ *   4*C*ntl*ntw*F floats. */
 int dccn_cconv_patch_bwd_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int sL, int sW, int F);
 size_t dccn_cconv_patch_bwd_w_workspace_size(int B, int Lo, int Wo, int C, int ntl, int ntw, int F);
 int dccn_cconv_patch_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int B, int L, int Wd, int C, int Lo,

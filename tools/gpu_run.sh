@@ -67,7 +67,7 @@ for ln in sys.stdin:
                  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
                  "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
         i=$((i+1))
-        timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -o p -- python tools/opbench.py step --iters 10 > $O/pmc_$i.log 2>&1
+        timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -o p -- python tools/opbench.py step_pipe --bench-plan --iters 10 > $O/pmc_$i.log 2>&1
       done
       python tools/pmc_summary.py $O $O/pmc_counters.txt $O/pmc_traffic.json > /dev/null 2>&1; rm -rf $O/pmc_[0-9]; cat $O/pmc_counters.txt | cut -c1-170 | head -30 ;;
     ktc)

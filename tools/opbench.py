@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--config", default="c2")
     ap.add_argument("--tune", default="", help="dccn_set_tuning pairs, e.g. 0=2,1=1,4=3")
+    ap.add_argument("--bench-plan", action="store_true",
+                    help="the engine bench.py times: output:0 / z / dfft / the summed dense gradient not materialised")
     args = ap.parse_args()
     from dl_ofdm_amd import _lib
     for kv in filter(None, args.tune.split(",")):
@@ -27,7 +29,11 @@ def main():
         assert _lib.load().dccn_set_tuning(int(k), int(v)) == 0
     c = bench.CONFIGS[args.config]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
-    eng = RxEngine(dims, c["frames"], train=True)
+    if args.bench_plan:
+        eng = RxEngine(dims, c["frames"], train=True, want_prob=False, want_tx_power=True, want_z=False, want_dfft=False,
+                       want_grads=False)
+    else:
+        eng = RxEngine(dims, c["frames"], train=True)
     eng.x.normal_()
     eng.bits.random_(0, 2)
     eng.train_step()
