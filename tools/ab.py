@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
-    defaults = [lib.dccn_get_tuning(k) for k in range(28)]
+    defaults = [lib.dccn_get_tuning(k) for k in range(lib.dccn_tuning_count())]
     specs = args.tunes.split(";") if args.tunes else [""]
 
     def tune(spec):

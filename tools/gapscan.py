@@ -51,7 +51,7 @@ def main():
     dev = torch.device("cuda", 0)
     c = bench.CONFIGS["c2"]
     dims = RxDims(S=7, kin=c["nfft"] + c["cp"], F=c["F"], D=c["D"], nbits=c["nbits"])
-    defaults = [lib.dccn_get_tuning(k) for k in range(28)]
+    defaults = [lib.dccn_get_tuning(k) for k in range(lib.dccn_tuning_count())]
 
     def make_engine():
         eng = RxEngine(dims, c["frames"], device=dev, train=True, seed=1, want_prob=True, want_tx_power=True, want_z=False,

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
     lib = _lib.load()
-    defaults = [lib.dccn_get_tuning(k) for k in range(28)]
+    defaults = [lib.dccn_get_tuning(k) for k in range(lib.dccn_tuning_count())]
 
     def tune(spec):
         for k, v in enumerate(defaults):
