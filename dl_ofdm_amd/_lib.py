@@ -154,6 +154,9 @@ SIGNATURES = {
     "dccn_gen_static_apply_grouped": (_i, [_i, _vp, _vp, _vp, _vp]),
     "dccn_eq_monitor_accumulate_grouped": (_i, [_i, _vp, _vp]),
     "dccn_cconv_patch_bwd_supported": (_i, [_i] * 11),
+    "dccn_cconv1d_bwd_supported": (_i, [_i] * 7),
+    "dccn_cconv1d_bwd_workspace_size": (_sz, [_i]),
+    "dccn_cconv1d_bwd": (_i, [_vp] * 6 + [_i] * 9 + [_vp, _sz, _vp]),
     "dccn_cconv_patch_bwd_w_workspace_size": (C.c_size_t, [_i] * 7),
     "dccn_cconv_patch_bwd_w": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp, C.c_size_t, _vp]),
     "dccn_cconv_patch_bwd_x_workspace_size": (C.c_size_t, [_i] * 4),

@@ -20,6 +20,7 @@
 #include "datagen.h"
 #include "im2col.h"
 #include "cconv_dx_narrow.h"
+#include "cconv1d_bwd.h"
 #include "classical.h"
 
 namespace dccn {
@@ -2990,6 +2991,61 @@ int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, 
     patch_div_magic(sL, p.pg.il_mul, p.pg.il_shift);
     patch_div_magic(sW, p.pg.iw_mul, p.pg.iw_shift);
     return launch_gemm<OP_KPATCH, OP_KCONTIG, 0, TAG_CCONV_BWD_X>(p, 1, s);
+}
+// ---- few-channel 1-D C-Conv: input, weight and bias gradient in one pass over dout (cconv1d_bwd.h) -------------------------
+constexpr int kConv1dMaxBlocks = 1024;
+static int conv1d_bwd_pl(int ntl, int sL) { return 62 * sL - ntl + 2; }          // positions per chunk: its rows fit 64 (cconv1d_bwd.h)
+int dccn_cconv1d_bwd_supported(int B, int L, int C, int Lo, int ntl, int sL, int F) {
+    if (B <= 0 || L <= 0 || C <= 0 || Lo <= 0 || ntl <= 0 || sL <= 0 || F <= 0) return 0;
+    if ((C % 2) != 0 || (F != 32 && F != 64) || 2 * ntl * C > 30 || conv1d_bwd_pl(ntl, sL) < 1) return 0;
+    if ((long long)B * L * C * 2 >= (1LL << 31) || (long long)B * Lo * F * 2 >= (1LL << 31)) return 0;
+    return 1;
+}
+size_t dccn_cconv1d_bwd_workspace_size(int F) {
+    if (F <= 0) return 0;
+    size_t o = 0;
+    o = carve_size(o, (size_t)kConv1dMaxBlocks * 32 * 2 * F * sizeof(float));
+    o = carve_size(o, (size_t)kConv1dMaxBlocks * 2 * F * sizeof(float));
+    return align_up(o, 256);
+}
+int dccn_cconv1d_bwd(const float* x, const float* dout, const float* w, float* dx, float* dw, float* dbias, int B, int L, int C,
+                     int Lo, int ntl, int tl0, int sL, int pl0, int F, void* workspace, size_t workspace_bytes,
+                     dccn_stream_t stream) {
+    if (!x || !dout || !w || !dx || !dw || !dccn_cconv1d_bwd_supported(B, L, C, Lo, ntl, sL, F) || !aligned16(dout) || !aligned16(w))
+        return DCCN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dccn_cconv1d_bwd_workspace_size(F)) return DCCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    Conv1dBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dout = dout; a.w = w; a.dx = dx;
+    a.slabs = c.take<float>((size_t)kConv1dMaxBlocks * 32 * 2 * F);
+    a.colsum = c.take<float>((size_t)kConv1dMaxBlocks * 2 * F);
+    a.B = B; a.L = L; a.C2 = 2 * C; a.Lo = Lo; a.nt = ntl; a.F2 = 2 * F; a.NC = 2 * ntl * C;
+    a.o = tl0 - pl0; a.s = sL;
+    a.PL = conv1d_bwd_pl(ntl, sL);
+    a.nch = ceil_div(L, a.PL);
+    const long long total = (long long)B * a.nch;
+    int grid = 2 * kCUs;
+    if (grid > kConv1dMaxBlocks) grid = kConv1dMaxBlocks;
+    if (grid > total) grid = (int)total;
+    DCCN_NO_CHAINS();
+    if (F == 64) {
+        auto kern = cconv1d_bwd_fused_kernel<128>;
+        DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), conv1d_bwd_smem_bytes<128>()));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), conv1d_bwd_smem_bytes<128>(), s, a);
+    } else {
+        auto kern = cconv1d_bwd_fused_kernel<64>;
+        DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), conv1d_bwd_smem_bytes<64>()));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), conv1d_bwd_smem_bytes<64>(), s, a);
+    }
+    DCCN_LAUNCH_CHECK();
+    const int kin = ntl * C;
+    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
+    hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, a.slabs, grid, (long long)32 * 2 * F, a.colsum, dw, dbias,
+                       kin, F);
+    DCCN_LAUNCH_CHECK();
+    return DCCN_OK;
 }
 int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
                       int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {

@@ -191,6 +191,7 @@ def cconv_im2col(x: torch.Tensor, Lo: int, Wo: int, taps_l, taps_w, strides, pad
     return _Im2col.apply(x.contiguous(), geom)
 
 
+_PATCH_BWD_FUSED1D = True        # few-channel 1-D C-Convs: all three gradients in one pass over dout (dccn_cconv1d_bwd)
 _PATCH_BWD_IM2COL = False        # tools/convbench.py, tests: force the backward onto the im2col / col2im operators
 _PATCH_BWD_DX_ALWAYS = False     # ... or the input gradient onto the implicit GEMM wherever it qualifies (bit 1), not only
                                  # where dccn_cconv_patch_bwd_supported expects it to be the faster route (bit 2)
@@ -228,6 +229,16 @@ class _CConvPatch(torch.autograd.Function):
         dx = dw = db = None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         mode = 0 if _PATCH_BWD_IM2COL else lib.dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F)
+        if (_PATCH_BWD_FUSED1D and not _PATCH_BWD_IM2COL and ctx.needs_input_grad[0] and need_w and Wd == 1 and Wo == 1 and ntw == 1
+                and sW == 1 and lib.dccn_cconv1d_bwd_supported(B, L, C, Lo, ntl, sL, F)):
+            # one pass over dout for dx, dw and dbias (csrc/cconv1d_bwd.h)
+            dx, dw = torch.empty_like(x), torch.empty_like(w)
+            db = torch.empty(2 * F, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nws = lib.dccn_cconv1d_bwd_workspace_size(F)
+            ws = workspace(nws, x.device)
+            check(lib.dccn_cconv1d_bwd(_p(x), _p(dout), _p(w), _p(dx), _p(dw), _p(db), B, L, C, Lo, ntl, tl0, sL, pl0, F, _p(ws), nws,
+                                       _stream()), "dccn_cconv1d_bwd")
+            return dx, dw, db, None
         if ctx.needs_input_grad[0] and (mode & (2 if _PATCH_BWD_DX_ALWAYS else 4)):    # implicit GEMM over dout, taps flipped
             dx = torch.empty_like(x)
             nws = lib.dccn_cconv_patch_bwd_x_workspace_size(C, ntl, ntw, F)

@@ -211,6 +211,16 @@ int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, 
                            int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F, void* workspace,
                            size_t workspace_bytes, dccn_stream_t stream);
 
+/* Few-channel 1-D C-Convs (layers_conv1d_complex, dev/py/complex.py:51-92: x [B, L, C, 2], ntl live taps from tl0, stride sL,
+ * pl0 samples of padding in front; 2*ntl*C <= 30, F = 32 or 64): dx, dw [ntl*C, 2F] and dbias [2F] (nullable) in ONE pass over
+ * dout [B*Lo, F, 2] (csrc/cconv1d_bwd.h) -- the three gradients of dccn_cconv_patch_bwd_w / _bwd_x, same 1e-5 parity, for
+ * about the cost of one of them on these shapes (dout is the only large tensor).  Deterministic. */
+int dccn_cconv1d_bwd_supported(int B, int L, int C, int Lo, int ntl, int sL, int F);
+size_t dccn_cconv1d_bwd_workspace_size(int F);
+int dccn_cconv1d_bwd(const float* x, const float* dout, const float* w, float* dx, float* dw, float* dbias, int B, int L, int C,
+                     int Lo, int ntl, int tl0, int sL, int pl0, int F, void* workspace, size_t workspace_bytes,
+                     dccn_stream_t stream);
+
 /* The in-graph AWGN monitor branch of the receiver graph (dev/py/radio.py:62-88 AWGN_channel, called at
  * dev/py/ofdmreceiver_np.py:136; tensors `tx_signal:0`, `iq_tx:0`, `iq_rx:0`, `noise_power:0`, :151-152,172-183):
  * tx_signal = complex_clip(x_norm, peak); xn = batch_norm(tx_signal, eps 1e-8)/sqrt(2);

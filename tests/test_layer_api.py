@@ -284,6 +284,60 @@ def test_conv2d_random_geometries_forward_and_backward():
         done += 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,C,F,k,stride,padding", [
+    (37, 560, 2, 64, 5, 1, "same"),        # the bench shape's geometry: 59 positions per chunk, 10 chunks per item
+    (5, 61, 2, 32, 5, 1, "same"),
+    (3, 200, 2, 64, 7, 1, "valid"),
+    (4, 333, 2, 64, 5, 2, "same"),         # strided: 121 positions per chunk
+    (2, 500, 4, 32, 3, 3, "same"),
+    (6, 40, 6, 64, 2, 1, "same"),          # even kernel (asymmetric SAME padding), 24 patch columns
+    (1, 1, 2, 64, 3, 1, "same"),           # a single position: two of three taps see padding only
+])
+def test_conv1d_fused_backward_vs_separate_routes_and_literal(B, L, C, F, k, stride, padding):
+    """dccn_cconv1d_bwd (dx, dw, dbias in one pass over dout) against the implicit-GEMM routes (dccn_cconv_patch_bwd_x / _bwd_w)
+    and the fp64 autograd twin of the literal TensorFlow formulation at 1e-5."""
+    from dl_ofdm_amd import complex as CX, ops
+    from oracle.torch_ref import layers_conv1d_complex_literal_t
+    rng = np.random.RandomState(B * 1000 + L)
+    x = rng.randn(B, L, C, 2).astype(np.float32)
+    st = CX.VariableStore(seed=11)
+    xt = torch.as_tensor(x).cuda().requires_grad_()
+    CX.layers_conv1d_complex(xt, F, k, strides=stride, padding=padding, scope=st)
+    st.set("conv2d/bias", rng.randn(2 * F))
+    grads = {}
+    g = None
+    for fused in (True, False):
+        ops._PATCH_BWD_FUSED1D = fused
+        ops._PATCH_BWD_DX_ALWAYS = True
+        try:
+            st.begin()
+            xt.grad = None
+            for n in ("conv2d/kernel", "conv2d/bias"):
+                st.tensor(n).grad = None
+            y = CX.layers_conv1d_complex(xt, F, k, strides=stride, padding=padding, scope=st)
+            if g is None:
+                g = torch.as_tensor(rng.randn(*y.shape).astype(np.float32)).cuda()
+            y.backward(g)
+        finally:
+            ops._PATCH_BWD_FUSED1D, ops._PATCH_BWD_DX_ALWAYS = True, False
+        grads[fused] = (xt.grad.cpu().numpy().copy(), st.tensor("conv2d/kernel").grad.cpu().numpy().copy(),
+                        st.tensor("conv2d/bias").grad.cpu().numpy().copy())
+    for a, b in zip(grads[True], grads[False]):
+        assert relerr(a, b) <= 1e-5
+    tl = list(st.meta["conv2d/kernel"]["live_taps"][0])
+    full = rng.randn(k, 1, C, 2 * F)                          # dead taps (they only ever see padding): any value
+    full[tl] = st.tensor("conv2d/kernel").detach().cpu().numpy().astype(np.float64).reshape(len(tl), 1, C, 2 * F)
+    bias = st.tensor("conv2d/bias").detach().cpu().numpy().astype(np.float64)
+    x64 = torch.tensor(x.astype(np.float64), requires_grad=True)
+    k64, b64 = torch.tensor(full, requires_grad=True), torch.tensor(bias, requires_grad=True)
+    layers_conv1d_complex_literal_t(x64, k64, b64, stride, padding).backward(g.cpu().double())
+    assert relerr(grads[True][0], x64.grad.numpy()) <= 1e-5
+    assert relerr(grads[True][2], b64.grad.numpy()) <= 1e-5
+    live = k64.grad.numpy()[tl]
+    assert relerr(grads[True][1].reshape(live.shape), live) <= 1e-5
+
+
 def test_multiply_shift_division_of_the_patch_loader_is_exact():
     """csrc/gemm_f32_mfma.h patch_div_magic / gemm_kmajor.h patch_div (row -> (b, lo, wo) of the implicit weight-gradient GEMM):
     s = ceil(log2 d), mul = ceil(2^(31+s) / d), q = (n * mul) >> (31 + s) equals n // d for every 0 <= n < 2^31 -- the
