@@ -83,9 +83,20 @@ __global__ __launch_bounds__(256) void cconv1d_bwd_fused_kernel(const Conv1dBwdA
         qe = min(qe, qs + 63);
     };
     kf32x4 rd[NLD];
-    auto request = [&](const int ch) {       // the chunk's dout rows -> registers (zeros behind the last row)
+    float xr[8];                             // this thread's 8 entries of the chunk's patch tile: column tid % 32, rows tid / 32 + 8 v
+    const int xcol = tid & 31, xt = xcol / a.C2, xciq = xcol - xt * a.C2;
+    auto request = [&](const int ch) {       // the chunk's dout rows and patch entries -> registers (zeros behind the last row)
         int b, p0, p1, qs, qe, qown;
         geom(ch, b, p0, p1, qs, qe, qown);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {        // patch rows of x for the OWNED rows (others zero), column NC = 1 for owned rows (bias gradient)
+            const int q = qs + (tid >> 5) + 8 * v;
+            const int l = q * a.s + a.o + xt;
+            const bool own = q < qown && q <= qe;
+            const bool in = own && xcol < a.NC && l >= 0 && l < a.L;
+            const float xv = a.x[((size_t)b * a.L + (in ? l : 0)) * a.C2 + (in ? xciq : 0)];
+            xr[v] = in ? xv : ((own && xcol == a.NC) ? 1.f : 0.f);
+        }
 #pragma unroll
         for (int v = 0; v < NLD; ++v) {
             const int idx = tid + 256 * v, row = idx / (F2 / 4), c4 = idx - row * (F2 / 4);
@@ -105,22 +116,8 @@ __global__ __launch_bounds__(256) void cconv1d_bwd_fused_kernel(const Conv1dBwdA
             const int idx = tid + 256 * v, row = idx / (F2 / 4), c4 = idx - row * (F2 / 4);
             *reinterpret_cast<kf32x4*>(sD + row * LDD + 4 * c4) = rd[v];
         }
-        // patch rows of x for the OWNED rows (others zero), column NC = 1 for owned rows (bias gradient)
-        for (int i = tid; i < 64 * 32; i += 256) {
-            const int row = i >> 5, col = i & 31;
-            const int q = qs + row;
-            float v = 0.f;
-            if (q < qown && q <= qe) {
-                if (col < a.NC) {
-                    const int t = col / a.C2, ciq = col - t * a.C2;
-                    const int l = q * a.s + a.o + t;
-                    if (l >= 0 && l < a.L) v = a.x[((size_t)b * a.L + l) * a.C2 + ciq];
-                } else if (col == a.NC) {
-                    v = 1.f;
-                }
-            }
-            sX[row * kC1dLdX + col] = v;
-        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sX[((tid >> 5) + 8 * v) * kC1dLdX + xcol] = xr[v];
         if (ch + (int)gridDim.x < total) request(ch + (int)gridDim.x);          // next chunk's rows: in flight during the MFMAs
         __syncthreads();
 
