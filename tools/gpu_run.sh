@@ -16,6 +16,7 @@
 #   ktc                            kernel-trace summaries of C3 and C4
 #   eq | eqkt | eqab:<k=v0,v1>     equaliser step bench (73 / 1170 frames) | its kernel-trace summaries | A/B of a tuning key
 #   eqloop | e2e | conv            equaliser epoch loop | generate-and-train loop | general-k C-Conv bench
+#   convs[:stride] | convkt        the same bench strided | kernel-trace summary of its first shape
 #   config5[:args]                 tools/config5_sweep.py at full size -> config5/
 #   chains[:args]                  tools/chainbench.py (G equaliser chains on G streams of one process)
 #   sh:<command>                   any shell command (output -> sh_<n>.txt)
@@ -86,6 +87,10 @@ for ln in sys.stdin:
     eqloop) timeout 600 python tools/eqloop.py 2>&1 | grep -v amdgpu.ids | tee $O/eqloop.jsonl | cut -c1-220 ;;
     e2e)    timeout 600 python tools/e2ebench.py 2>&1 | grep -v amdgpu.ids | tee $O/e2ebench.jsonl | cut -c1-300 ;;
     conv)   timeout 600 python tools/convbench.py 2>&1 | grep -v amdgpu.ids | tee $O/convbench.jsonl | cut -c1-220 ;;
+    convs)  timeout 600 python tools/convbench.py --stride ${arg:-2} 2>&1 | grep -v amdgpu.ids | tee $O/convbench_stride${arg:-2}.jsonl | cut -c1-220 ;;
+    convkt)
+      timeout 600 rocprofv3 --kernel-trace --stats -d $O/conv_kt -o kt -- python tools/convbench.py --shapes 0 --rounds 1 --iters 30 > $O/conv_kt.log 2>&1
+      python tools/profile_summary.py $(find $O/conv_kt -name "*.db" | head -1) 14 > $O/conv_kernel_stats.txt 2>&1; rm -rf $O/conv_kt; cut -c1-160 $O/conv_kernel_stats.txt ;;
     config5)
       timeout 2400 python tools/config5_sweep.py --out $O/config5 --eq_epochs 0 $(echo $arg | tr ',' ' ') > $O/config5_run.log 2>&1; tail -3 $O/config5_run.log; cat $O/config5/config5_timing.json | head -40 ;;
     eqgkt)
