@@ -43,7 +43,8 @@ def main():
     engines = {}
     for spec in specs:                      # one engine per setting (workspace sizes may depend on the tuning)
         tune(spec)
-        eng = RxEngine(dims, c["frames"], train=True, want_prob=True, want_tx_power=True, want_z=False)
+        eng = RxEngine(dims, c["frames"], train=True, want_prob=False, want_tx_power=True, want_z=False, want_dfft=False,
+                       want_grads=False)       # the plan bench.py times
         eng.x.normal_()
         eng.bits.random_(0, 2)
         engines[spec] = eng
