@@ -19,7 +19,7 @@ enum ClassicalEstimate : int { CE_LS = 0, CE_LMMSE = 1, CE_ALMMSE = 2, CE_PERFEC
 constexpr int kClassicalPartials = 512;
 
 // Y [n, S*K, 2] -> gp [2][n][P] (plane 0 = real parts, plane 1 = imaginary parts) = Y[pilot] / pv
-__global__ __launch_bounds__(256) void classical_pilot_ls_kernel(const float2* __restrict__ Y, const int* __restrict__ pil,
+static __global__ __launch_bounds__(256) void classical_pilot_ls_kernel(const float2* __restrict__ Y, const int* __restrict__ pil,
                                                                  float* __restrict__ gp, int n, int SK, int P, float2 pv) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)n * P) return;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void classical_pilot_ls_kernel(const float2* _
 
 // per-block partial sums (fixed order): [0] Re, [1] Im of sum Y_p conj(H_p pv), [2] sum |H_p pv|^2 over the pilots of the
 // block's frames; [3] sum |G_ls|^2 over all cells.  H [n, S*K, 2] nullable (then [0..2] stay 0); Gls planes [2][n][SK].
-__global__ __launch_bounds__(256) void classical_gain_kernel(const float2* __restrict__ Y, const float2* __restrict__ H,
+static __global__ __launch_bounds__(256) void classical_gain_kernel(const float2* __restrict__ Y, const float2* __restrict__ H,
                                                              const float* __restrict__ Gls, const int* __restrict__ pil,
                                                              double* __restrict__ partial, int n, int SK, int P, float2 pv) {
     __shared__ double sh[4][4];
@@ -78,7 +78,7 @@ __device__ __forceinline__ void classical_sum_partials(const double* __restrict_
 }
 
 // one frame per block.  G [n, S*K, 2] (mode CE_FRAME_MEAN: V [n, K, 2]).  c = LS error variance at a pilot.
-__global__ __launch_bounds__(256) void classical_estimate_kernel(const float* __restrict__ Gls, const float2* __restrict__ H,
+static __global__ __launch_bounds__(256) void classical_estimate_kernel(const float* __restrict__ Gls, const float2* __restrict__ H,
                                                                  const double* __restrict__ partial, int nblk,
                                                                  float2* __restrict__ G, int n, int S, int K, int mode, float c) {
     __shared__ double sh[4][4];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void classical_estimate_kernel(const float* __
 
 // x = Y / G at the data cells (G row stride g_sk: S*K, or K with g_mod = K when the estimate is one row per frame),
 // nearest point of table[m], detected bits (nullable) and bit errors against `bits` (per-block partial, fixed order)
-__global__ __launch_bounds__(256) void classical_detect_kernel(const float2* __restrict__ Y, const float2* __restrict__ G,
+static __global__ __launch_bounds__(256) void classical_detect_kernel(const float2* __restrict__ Y, const float2* __restrict__ G,
                                                                const int* __restrict__ dat, const float2* __restrict__ table,
                                                                const int* __restrict__ labels, const int32_t* __restrict__ bits,
                                                                int32_t* __restrict__ det, long long* __restrict__ err_partial,
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void classical_detect_kernel(const float2* __r
 }
 
 // out[0] = sum of the detect partials (errors), out[1..4] = the gain partial totals as doubles reinterpreted by the host
-__global__ __launch_bounds__(256) void classical_finish_kernel(const long long* __restrict__ err_partial, int nerr,
+static __global__ __launch_bounds__(256) void classical_finish_kernel(const long long* __restrict__ err_partial, int nerr,
                                                                const double* __restrict__ partial, int nblk,
                                                                long long* __restrict__ errors, double* __restrict__ sums) {
     __shared__ double sh[4][4];

@@ -45,7 +45,7 @@ __device__ __forceinline__ float2 box_muller(unsigned w0, unsigned w1) {
 }
 
 // test hook: out[i] = the four words of counter (i, stream, offset)
-__global__ __launch_bounds__(256) void philox_fill_kernel(unsigned* __restrict__ out, long long n, unsigned stream,
+static __global__ __launch_bounds__(256) void philox_fill_kernel(unsigned* __restrict__ out, long long n, unsigned stream,
                                                           unsigned offset, unsigned long long seed) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(unsigned* __restrict__
 // cell.  cell_map[S*K]: >= 0 data-cell index d, -1 pilot, -2 empty.  bits_in == nullptr: draw the label bits
 // (bit j of cell (frame,d) = bit j of Philox word 0 at index frame*D+d) and store them to bits_out;
 // the constellation index is MSB-first over the nbits labels (ofdm.py:121-153 const_map order).
-__global__ __launch_bounds__(256) void tx_grid_kernel(const int* __restrict__ bits_in, int* __restrict__ bits_out,
+static __global__ __launch_bounds__(256) void tx_grid_kernel(const int* __restrict__ bits_in, int* __restrict__ bits_out,
                                                       const int* __restrict__ cell_map,
                                                       const float2* __restrict__ const_tab, float2 pilot,
                                                       float2* __restrict__ grid, long long n_cells, int SK, int D,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void tx_grid_kernel(const int* __restrict__ bi
 // frames (nullable): the frame indices this launch covers (frame-interleaved 'mix' channels run one launch per
 // profile); tap_stride: taps per frame in taps_in and in the Philox index; g_stride: float2 per frame in g;
 // h_rep: copies of H per frame (the mix channels report H per symbol for static frames too).
-__global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restrict__ taps_in,
+static __global__ __launch_bounds__(64) void channel_taps_kernel(const float* __restrict__ taps_in,
                                                           const float* __restrict__ coeff,
                                                           const float* __restrict__ alpha, float2* __restrict__ g,
                                                           float2* __restrict__ H, int n_taps, int L, int nfft,
@@ -157,7 +157,7 @@ struct TapGen {
     int enabled, n_taps, identity, tap_stride;
     unsigned offset; unsigned long long seed;
 };
-__global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
+static __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                        float2* __restrict__ y, double* __restrict__ partial, int T,
                                                        int L, const int* __restrict__ frames, int g_stride, int n_frames,
                                                        int pbase, const TapGen tg, const int ipb) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void fir_same_kernel(const float2* __restrict_
 // SNR per frame; mean |y|^2 = sum of the FIR stage's block partials / total, added up by every block itself.
 // noise_in (standard normals [n, T, 2]) == nullptr: draw them.  Also emits the per-block partial sums of the
 // noise power (finished by sum_partials_kernel).  grid = (ceil(T/256), frames).
-__global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y, const double* __restrict__ power_partial,
+static __global__ __launch_bounds__(256) void awgn_kernel(const float2* __restrict__ y, const double* __restrict__ power_partial,
                                                    int n_partial, double total,
                                                    const float* __restrict__ snr_db,
                                                    const float* __restrict__ noise_in, float2* __restrict__ out,
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 // x = y / sqrt(mean |y|^2) + noise where a buffer is wanted (the first batch of a pipelined loop, tests, iq dumps): the
 // expression of awgn_kernel on the generator's y and noise.  grid: any; 256 threads.
-__global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* y_, const float4* noise_, const double* ppart_, int npart,
+static __global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* y_, const float4* noise_, const double* ppart_, int npart,
                                                                double total, float4* x_, long long n4, const double* npart_noise_,
                                                                int n_noise, float* npow_out_, const ChainOffs co) {
     const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void gen_static_apply_kernel(const float4* y_,
 // noise = (|amp| sin(phase), |amp| cos(phase)); iq_rx = fp16(xn + noise), iq_tx = fp16(clipped signal),
 // noise_power = mean(noise_re^2 + noise_im^2).  The receiver never consumes this branch (`rx_iq_data = iq_tx_re`);
 // it only feeds the constellation dumps and the printed noise power.  grid = (ceil(T/256), frames).
-__global__ __launch_bounds__(256) void ingraph_awgn_kernel(const float2* __restrict__ clipped,
+static __global__ __launch_bounds__(256) void ingraph_awgn_kernel(const float2* __restrict__ clipped,
                                                            const float2* __restrict__ xn,
                                                            const float* __restrict__ snr_db, __half2* __restrict__ iq_tx,
                                                            __half2* __restrict__ iq_rx, double* __restrict__ noise_partial,
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void ingraph_awgn_kernel(const float2* __restr
 //   mu_im likewise with cos(a_n - a0_k) and th_im;  tap = (mu_re + i mu_im) coeff_k;  g[s] = taps[s] . alpha;  H[s] = fft(g[s])
 // theta_in [frames, 2, 48, n_taps] (uniform phases in [0, 2 pi)) == nullptr: draw them.  One block per frame.
 constexpr int kSinusoids = 48;
-__global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restrict__ theta_in,
+static __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restrict__ theta_in,
                                                           const float* __restrict__ coeff,
                                                           const float* __restrict__ alpha, float2* __restrict__ g,
                                                           float2* __restrict__ H, int n_taps, int L, int nfft, int S,
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64) void doppler_taps_kernel(const float* __restric
 // x[s*n_sc - n_taps .. (s+1)*n_sc) with np.convolve(., g_s, 'same') and keeps its last n_sc outputs, i.e.
 // y[s*n_sc + t] = sum_l g_s[l] x[s*n_sc + t + off - l] over t + off - l in [-n_taps, n_sc) (nothing beyond the
 // symbol's own end, nothing before the frame).  grid = (ceil(T/256), frames); + partial sums of |y|^2.
-__global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
+static __global__ __launch_bounds__(256) void fir_doppler_kernel(const float2* __restrict__ x, const float2* __restrict__ g,
                                                           float2* __restrict__ y, double* __restrict__ partial, int T,
                                                           int L, int n_sc, int n_taps, const int* __restrict__ frames,
                                                           int g_stride, int n_frames, int pbase) {

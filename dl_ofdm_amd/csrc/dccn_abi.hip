@@ -1,27 +1,6 @@
 // libdccn.so -- C ABI over the gfx950 kernels (see include/dccn.h for the contract and the
 // reference call site each entry point replaces).
-#include <math.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdlib.h>
-
-#include "common.h"
-#include "gemm_f32_mfma.h"
-#include "cconv_fwd.h"
-#include "norm_adam.h"
-#include "tail.h"
-#include "gemm16.h"
-#include "gemm_kmajor.h"
-#include "rx_bwd.h"
-#include "equalizer.h"
-#include "fewrow.h"
-#include "eq_opt.h"
-#include "eq_bottleneck.h"
-#include "datagen.h"
-#include "im2col.h"
-#include "cconv_dx_narrow.h"
-#include "cconv1d_bwd.h"
-#include "classical.h"
+#include "abi_impl.h"
 
 namespace dccn {
 thread_local int g_last_hip_error = 0;
@@ -29,128 +8,11 @@ thread_local ChainCtx tl_chain = {1, {{0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0,
 StepTraceState g_step_trace;
 thread_local unsigned long long* tl_stamp = nullptr;
 
-// bump allocator over a caller-provided workspace
-struct Carver {
-    char* base;
-    size_t off, cap;
-    Carver(void* p, size_t n) : base(static_cast<char*>(p)), off(0), cap(n) {}
-    template <typename T>
-    T* take(size_t count) {
-        off = align_up(off, 256);
-        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;     // base == nullptr: size-only dry run
-        off += count * sizeof(T);
-        return r;
-    }
-    bool ok() const { return off <= cap && (base != nullptr || off == 0); }
-};
-static size_t carve_size(size_t off, size_t bytes) { return align_up(off, 256) + bytes; }
-
-// Kernel-configuration knobs (dccn_set_tuning): which tile configuration the GEMM-shaped operators launch.
-// 0 = the 32x32x2 family of gemm_f32_mfma.h, > 0 = a gemm16.h configuration (see the *_impl functions).
-enum TuneKey : int {
-    // (keys 15, 16, 22, 23, 26 -- the optimizer launch that also ran the next C-Conv forward, Adam in the dW epilogue, non-temporal
-    // gradient loads, 160x64 / 128x64 dense + tail tiles, prefetch_fwd -- were built, measured without gain in rounds 3-5 and
-    // removed in round 6 together with their kernels; dccn_set_tuning refuses them)
-    TUNE_DENSE_FWD = 0,         // > 0: the dense forward runs with the demodulation tail in its epilogue (48x64 / 80x64 tiles)
-    TUNE_DENSE_BWD = 1,         // grouped dX + dW
-    TUNE_CCONV_FWD = 2,
-    TUNE_CCONV_BWD_W = 3,
-    TUNE_DENSE_BWD_SPLITS = 4,  // 0 = automatic
-    TUNE_CCONV_BWD_SPLITS = 5,  // 0 = automatic
-    TUNE_SMEM_MIN_KB = 6,       // minimum dynamic LDS per block of the gemm16 launches (caps resident blocks per CU)
-    TUNE_WHOLE_K = 7,           // 1: short-k GEMMs (C-Conv forward / weight gradient at N=64) run their k range as one tile
-    TUNE_SKINNY = 8,            // > 0: GEMMs with <= 96 output rows (the equaliser's 73-frame batch) use small gemm16 tiles
-    TUNE_DENSE_BWD_BIG = 9,     // 1: large dense layers run dX and dW (128x128x32 tiles) as one grouped launch
-    TUNE_DENSE_FWD_PLAIN = 10,  // 1: the un-fused dense forward (nbits >= 3, layer API) of small layers runs 48x64 gemm16 tiles
-    TUNE_FUSED_BWD = 11,        // 1: small layers: the C-Conv weight gradient rides in the epilogue of the dense dX tiles (rx_bwd.h)
-    TUNE_BWD_PRIO = 12,         // s_setprio level (0-3) of the dX blocks of the fused backward launch
-    TUNE_TAIL_FUSE_HI = 13,     // 8-QAM / 16-QAM tail inside the dense forward launch: bit 0 lane-per-cell forms, bit 1 quad-lane training
-    TUNE_DW_GRADED = 14,        // > 0: graded k ranges for the dense dW items of the fused backward launch (preset number)
-    TUNE_SKINNY_GROUPED = 17,   // 1: few-row dense backward (<= 96 rows): dX (16x64 tiles) and the unsplit dW in one grid
-    TUNE_NORM_ON_BWD = 18,      // 1 / 2: double-buffered pipelining: R0 of the next batch rides on the backward launch (leading / closing workgroups)
-    TUNE_EQ_EPILOGUES = 19,     // equaliser step: tanh / tanh-gradient / gradient add in GEMM stores: 1 = the few-row GEMMs,
-                                //    2 = also the 48x64 / 64x64 tiles of larger batches
-    TUNE_EQ_REPLAN = 20,        // 1: equaliser step: one job-table optimizer launch, corr/eq C-Conv pair as grouped launches,
-                                //    concat / split in GEMM stores, merged element-wise launches (eq_step.h)
-    TUNE_FEWROW = 21,           // 1: few-row GEMMs (<= 96 rows, K = 640 / 896) on the one-latency 16x16 tiles of fewrow.h
-    TUNE_ADAM_OVERLAP = 25,     // 1: large layers: the dense kernel's Adam update runs on a second stream next to the C-Conv weight-gradient launch
-                                //    2: ... with non-temporal loads and stores (it must not displace the GEMM's operand panels)
-    TUNE_EQ_RIDERS = 24,        // 1: equaliser step: the Adam updates of dense_3 / dense_4 ride behind the pilot bottleneck's backward launch
-    TUNE_DENSE_RAGGED = 27,     // 1: large layers' fused dense + tail: a short last row tile (<= 32 rows) runs 32x64 blocks in the same grid
-    TUNE_COUNT = 28
-};
-// The knobs are process-global DEFAULTS (relaxed atomics: one thread may turn them while another plans a launch); a call never
-// sees them change under it: every step / operator entry opens a TuneScope, which copies the table once -- from the plan's own
-// table when the caller captured one at plan creation (dccn_rx_buffers.tuning / dccn_eq_buffers.tuning, dccn_tuning_snapshot),
-// from the globals otherwise -- and everything the call plans reads that copy.
 thread_local int tl_whole_k = -1;
 thread_local int tl_tune_depth = 0;
 thread_local int tl_tune_vals[TUNE_COUNT];
-struct TuneTable {
-    std::atomic<int> v[TUNE_COUNT];
-    int operator[](int k) const { return tl_tune_depth > 0 ? tl_tune_vals[k] : v[k].load(std::memory_order_relaxed); }
-    int global(int k) const { return v[k].load(std::memory_order_relaxed); }
-    void set(int k, int x) { v[k].store(x, std::memory_order_relaxed); }
-};
-// defaults = the fastest measured (A/B runs of tools/ab.py inside one process on one box, medians of 4-6 rounds of 300 steps;
-// boxes of the pool differ by up to 9 % in absolute time, so only same-process comparisons decide):
-//    2 = 7  round 5: the staged whole-k C-Conv forward of cconv_fwd.h (stages of 32 k consumed as they land): 7.15 -> 5.04 us in
-//           situ, C2 step 76.36 -> 74.67 us, bit-identical (gpurun_out/r05a; 8 / 9 = other LDS-store slots: 74.59 / 74.76);
-//   12 = 3  dX tiles at wave priority 3: -0.4 us per C2 step;
-//   13 = 1  8-QAM training 86.7 -> 84.4 us with the tail in the dense launch; the quad-lane form of 16-QAM training is
-//           built and parity-tested but slower than its own launch (104.8 vs 98.8 us: one wave per SIMD cannot hide the
-//           transcendental / DPP latencies of 24 cells per quad), so bit 1 stays off;
-//   14 = 14 graded dense-dW ranges {9,5,2,2,1}/19 of the batch (k-tiles of 64 frames; round 4: {8,6,3,2}, 80.2 -> 77.4 us per C2
-//           step over three uniform ranges).  Round 5 re-scanned 24 presets on the lighter launch (folded dWeff partials):
-//           steeper grading packs the grid's tail better although a fifth slab is written and summed -- backward launch
-//           33.1 -> 31.0 us in situ, optimizer 6.9 -> 7.2, step 74.4 -> 73.5 us ({8,5,3,2,1} 73.6, {9,5,3,2} 73.8, {10,5,3,1}
-//           73.7, six ranges 74.3-74.8, three ranges 76.3-77.4, two 80.8: gpurun_out/r05a, r05c-r05e);
-//   17 = 1  few-row dense backward as one grid: equaliser step at 73 frames 0.401 -> 0.375 ms (five launches fewer);
-//   19 = 2  element-wise stages in GEMM stores: 73 frames 0.2688 -> 0.2663 ms (few-row tiles); 1170 frames 0.5276 -> 0.5247 ms
-//           (the stage costs the GEMM 8-10 us where the stand-alone launch cost 5: a small net gain);
-//   20 = 1  equaliser re-plan: 73 frames 0.319 -> 0.263 ms, 1170 frames 0.570 -> 0.509 ms (tools/eqbench.py --ab 20=0,1,2);
-//   18 = 0  R0 of the next batch on the backward launch (second x_norm buffer): 78.8 vs 78.6 us -- the optimizer launch it
-//           came from is bounded by the 133-term C-Conv fold, not by R0; built, bitwise-tested, off.
-//   21 = 1  few-row GEMMs on the one-latency tiles of fewrow.h: equaliser step at 73 frames 0.243 -> 0.180 ms (tools/eqbench.py --ab 21=0,1);
-//   24 = 1  equaliser step: Adam updates of dense_3 / dense_4 and the smoothing kernel's fold as riders of the bottleneck backward
-//           launch: 73 frames 0.1749 -> 0.1707 ms (tools/eqbench.py --ab 24=0,1);
-//   25 = 2  large layers: the dense kernel's Adam update (3.2 GB at N = 1024) on the library's low-priority second stream next to the
-//           C-Conv weight-gradient launch: C4 step 4998 -> 4804 us, with non-temporal loads / stores 4775 us (tools/ab.py --config c4).
-static TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}, {1}}};
-
-struct TuneScope {
-    explicit TuneScope(const int* plan = nullptr) {
-        if (tl_tune_depth++ == 0) {
-            for (int k = 0; k < TUNE_COUNT; ++k) tl_tune_vals[k] = plan ? plan[k] : g_tune.global(k);
-            tl_whole_k = tl_tune_vals[TUNE_WHOLE_K];
-        }
-    }
-    ~TuneScope() {
-        if (--tl_tune_depth == 0) tl_whole_k = -1;
-    }
-    TuneScope(const TuneScope&) = delete;
-    TuneScope& operator=(const TuneScope&) = delete;
-};
-
-// few output rows, long k: 64x64 tiles leave most CUs without a block (73x896 = 28 tiles); 16- or 32-row tiles give 2-5x
-// the blocks, and loads two k-tiles ahead cover the latency that the short MFMA phases cannot
-template <int KA, int KB, int TAG, int ACT = 1>
-static int skinny_launch(int variant, const GemmParams& p, hipStream_t s) {
-    if constexpr (ACT != 1) return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 1, 0, TAG, 2, ACT>(p, 1, s);   // 16x64 + element-wise stage
-    switch (variant) {
-        case 1: return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 16x64
-        case 2: return launch_gemm16<KA, KB, 1, 4, 2, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 32x64
-        case 3: return launch_gemm16<KA, KB, 2, 2, 1, 1, 64, 1, 0, TAG, 2>(p, 1, s);       // 32x32
-        case 4: return launch_gemm16<KA, KB, 1, 4, 1, 1, 64, 2, 0, TAG, 2>(p, 1, s);       // 16x64, 8 waves
-        default: return DCCN_ERR_INVALID_ARG;
-    }
-}
-static bool skinny_ok(const GemmParams& p) {
-    return g_tune[TUNE_SKINNY] > 0 && p.M <= 96 && p.N >= 256 && p.K >= 256 && p.vecA && p.vecB && (p.K % 4 == 0) &&
-           (p.N % 4 == 0);
-}
-constexpr int kVariantKmajor = 7;   // TUNE_DENSE_BWD / TUNE_CCONV_BWD_W value: weight gradient in the k-major form of gemm_kmajor.h
-static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; }
+TuneTable g_tune = {{{9}, {7}, {7}, {7}, {0}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {3}, {1}, {14}, {0}, {0}, {1}, {0}, {2}, {1}, {1}, {0}, {0}, {1}, {2}, {0}, {1}}};
+std::atomic<int> g_whole_k_global{1};
 
 // ---------------------------------------------------------------------------------------
 // R0
@@ -158,33 +20,28 @@ static size_t tune_smem_min() { return (size_t)g_tune[TUNE_SMEM_MIN_KB] * 1024; 
 static int norm_grid_x(int cols) { return ceil_div(ceil_div(cols, 4), 64); }
 static int norm_grid_y(int batch) { return ceil_div(batch, kNormRowsPerBlock); }
 
-static int norm_fused_blocks(int cols) { return ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8; }
+int norm_fused_blocks(int cols) { return ceil_div(ceil_div(cols, 4 * kNormFusedCG), 8) * 8; }
 static size_t norm_power_slots(int batch, int cols) {
     const size_t a = (size_t)norm_grid_x(cols) * norm_grid_y(batch), b = (size_t)norm_fused_blocks(cols);
     return a > b ? a : b;
 }
-static size_t norm_ws_bytes(int batch, int cols) {
+size_t norm_ws_bytes(int batch, int cols) {
     size_t o = 0;
     o = carve_size(o, (size_t)kNormRowChunks * cols * 2 * sizeof(double));
     o = carve_size(o, 2 * norm_power_slots(batch, cols) * sizeof(double));      // two slots: dccn_rx_buffers.norm_slot
     return align_up(o, 256);
 }
 
-static bool norm_fused_ok(const float* x, const float* y, int batch, int cols) {
+bool norm_fused_ok(const float* x, const float* y, int batch, int cols) {
     return (cols % 4 == 0) && batch <= 128 * kNormFusedRPT && aligned16(x) && aligned16(y);
 }
 
-struct PowerPartials {      // where normalise left the R8 partial sums (finished by a later kernel)
-    const double* partial;
-    int n;
-    double denom;
-};
 
 // want_power: also emit the per-block partial sums of the clipped power (R8); adam != nullptr: the
 // optimizer bookkeeping of the fused training step rides on the first kernel
 // where norm_impl leaves the R8 partial sums for a [batch, cols] input in workspace `ws` (no launch)
-static void norm_power_partials(int batch, int cols, void* ws, size_t ws_bytes, const float* x, const float* y,
-                                PowerPartials* pp, int slot = 0) {
+void norm_power_partials(int batch, int cols, void* ws, size_t ws_bytes, const float* x, const float* y,
+                                PowerPartials* pp, int slot) {
     Carver c(ws, ws_bytes);
     c.take<double>((size_t)kNormRowChunks * cols * 2);
     pp->partial = c.take<double>(2 * norm_power_slots(batch, cols)) + (slot ? norm_power_slots(batch, cols) : 0);
@@ -192,9 +49,9 @@ static void norm_power_partials(int batch, int cols, void* ws, size_t ws_bytes, 
     pp->denom = (double)batch * (double)(cols / 2);
 }
 
-static int norm_impl(const float* x, float* y, float* mean, float* var, bool want_power, PowerPartials* pp, int batch,
+int norm_impl(const float* x, float* y, float* mean, float* var, bool want_power, PowerPartials* pp, int batch,
                      int cols, float eps, float peak, dccn_adam_state* adam, dccn_adam_hparams hp, void* ws,
-                     size_t ws_bytes, hipStream_t s, int slot = 0) {
+                     size_t ws_bytes, hipStream_t s, int slot) {
     if (!x || !y || batch <= 0 || cols <= 0 || (want_power && (cols & 1))) return DCCN_ERR_INVALID_ARG;
     if (ws_bytes < norm_ws_bytes(batch, cols) || !ws) return DCCN_ERR_WORKSPACE;
     Carver c(ws, ws_bytes);
@@ -231,13 +88,13 @@ static int norm_impl(const float* x, float* y, float* mean, float* var, bool wan
 // ---------------------------------------------------------------------------------------
 // GEMM-shaped ops
 // ---------------------------------------------------------------------------------------
-static GemmParams gp_zero() {
+GemmParams gp_zero() {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.stamp = tl_stamp;         // non-null only while a StepTraceScope names the launch being built (common.h)
     return p;
 }
-static int round_k(int K) { return ceil_div(K, 64) * 64; }
+int round_k(int K) { return ceil_div(K, 64) * 64; }
 // the fast GEMM loaders use 32-bit byte offsets from a uniform base: operand must be < 2 GiB
 static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < (1LL << 31); }
 
@@ -245,9 +102,9 @@ static bool small_enough(long long rows, long long ld) { return rows * ld * 4 < 
 // act = 2: y = tanh(x.w + bias) when the launch plan has the stage (few-row 16x64 tiles); *act_done tells
 // act = 5 (+ aux = the received cells, out2 / out3): the output is a channel estimate; eq and corr of model.py:431-438
 // leave the same launch
-static int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                          hipStream_t s, int ldx = 0, int act = 1, bool* act_done = nullptr, const float* aux = nullptr,
-                          float* out2 = nullptr, float* out3 = nullptr) {
+int dense_fwd_impl(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                          hipStream_t s, int ldx, int act, bool* act_done, const float* aux,
+                          float* out2, float* out3) {
     if (act_done) *act_done = false;
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     const int lda = ldx > 0 ? ldx : K;
@@ -312,7 +169,7 @@ static GemmParams dense_bwd_x_params(const float* dy, const float* w, float* dx,
     return p;
 }
 
-static int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
+int dense_bwd_x_impl(const float* dy, const float* w, float* dx, int M, int K, int N, hipStream_t s) {
     if (!dy || !w || !dx || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     const GemmParams p = dense_bwd_x_params(dy, w, dx, M, K, N);
     if (g_tune[TUNE_FEWROW] && g_tune[TUNE_SKINNY] > 0 && fewrow_ng(p)) return launch_fewrow<OP_KCONTIG, 1, TAG_DENSE_BWD_X>(p, s);
@@ -326,7 +183,7 @@ static int max_splits16(int Mo, int No) {
     long long m = (1024 + tiles - 1) / tiles;
     return (int)(m < 1 ? 1 : (m > 8 ? 8 : m));
 }
-static size_t splitk_ws_bytes(int Mo, int No, int Kr) {
+size_t splitk_ws_bytes(int Mo, int No, int Kr) {
     const SplitPlan sp = plan_splitk(Mo, No, Kr);
     const int ms = max_splits16(Mo, No);
     const int n = sp.splits > ms ? sp.splits : ms;
@@ -382,13 +239,8 @@ static int graded_ranges(int preset, int M, int off[9]) {
 }
 
 // defer != nullptr: leave the split-K slabs un-reduced (the fused Adam kernel sums them) and report them
-struct DeferredSlabs {
-    const float* dw_slabs;
-    const float* db_slabs;
-    int splits;
-};
-static int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
-                            size_t ws_bytes, hipStream_t s, DeferredSlabs* defer = nullptr, int ldx = 0) {
+int dense_bwd_w_impl(const float* x, const float* dy, float* dw, float* dbias, int M, int K, int N, void* ws,
+                            size_t ws_bytes, hipStream_t s, DeferredSlabs* defer, int ldx) {
     if (!x || !dy || !dw || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < splitk_ws_bytes(K, N, M)) return DCCN_ERR_WORKSPACE;
     const SplitPlan sp = dense_dw_plan(M, K, N);
@@ -455,10 +307,10 @@ static void dense_bwd16_tiles(int variant, int& xm, int& xn, int& wm, int& wn) {
 // dense backward as ONE grouped launch: dx = dy.w^T together with the split-K slabs of dw = x^T.dy
 // (left un-reduced for the fused Adam kernel).  Falls back to two launches when the grouped
 // configuration does not apply (128x128 tiles, unaligned operands, single split).
-static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+int dense_bwd_grouped_impl(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
                                   int M, int K, int N, void* ws, size_t ws_bytes, hipStream_t s, DeferredSlabs* defer,
-                                  int actx = 1, const float* aux = nullptr, bool* act_done = nullptr,
-                                  float* split_dst = nullptr, long long split_pairs_gc = 0, bool* split_done = nullptr) {
+                                  int actx, const float* aux, bool* act_done,
+                                  float* split_dst, long long split_pairs_gc, bool* split_done) {
     if (act_done) *act_done = false;
     if (split_done) *split_done = false;
     if (!x || !dy || !w || !dx || !dw || !defer || M <= 0 || K <= 0 || N <= 0) return DCCN_ERR_INVALID_ARG;
@@ -564,8 +416,8 @@ static int dense_bwd_grouped_impl(const float* x, const float* dy, const float* 
     return DCCN_OK;
 }
 
-static int cconv_fwd_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
-                          hipStream_t s, int ldx = 0) {
+int cconv_fwd_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
+                          hipStream_t s, int ldx) {
     if (!x || !w || !out || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // out[rows,2F] = x[rows,2kin] . Weff[2kin,2F]
     p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
@@ -603,8 +455,8 @@ static int cconv_fwd_impl(const float* x, const float* w, const float* bias, flo
     return launch_gemm<OP_KCONTIG, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, s);
 }
 
-static int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int rows, int kin, int F, hipStream_t s,
-                            int ldc = 0) {
+int cconv_bwd_x_impl(const float* dout, const float* w, float* dx, int rows, int kin, int F, hipStream_t s,
+                            int ldc) {
     if (!dout || !w || !dx || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // dx[rows,2kin] = dout[rows,2F] . Weff^T
     p.A = dout; p.B = w; p.C = dx;
@@ -662,7 +514,7 @@ static void cconv_bw16_tiles(int variant, int& tm, int& tn) {
     if (variant == 4) { tm = 32; tn = 128; }
 }
 // workspace of the C-Conv weight gradient: the legacy split plan or up to kCconvBwMaxSplits slabs of a small output
-static size_t cconv_bw_ws_bytes(int rows, int kin, int F) {
+size_t cconv_bw_ws_bytes(int rows, int kin, int F) {
     const size_t legacy = splitk_ws_bytes(2 * kin, 2 * F, rows);
     if (4LL * kin * F > 512 * 512) return legacy;
     size_t o = 0;
@@ -672,14 +524,10 @@ static size_t cconv_bw_ws_bytes(int rows, int kin, int F) {
     return o > legacy ? o : legacy;
 }
 
-struct FoldDefer {          // the fold left to the optimizer kernel (fused training step)
-    const float* slabs; const float* colsum;
-    int splits; long long slab;
-};
 
-static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
-                            void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin = nullptr,
-                            FoldDefer* defer = nullptr) {
+int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float* dbias, int rows, int kin, int F,
+                            void* ws, size_t ws_bytes, hipStream_t s, const TailFinalizeArgs* fin,
+                            FoldDefer* defer) {
     if (!x || !dout || !dw || rows <= 0 || kin <= 0 || F <= 0) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < cconv_bw_ws_bytes(rows, kin, F)) return DCCN_ERR_WORKSPACE;
     const int variant = g_tune[TUNE_CCONV_BWD_W] == kVariantKmajor ? 0 : g_tune[TUNE_CCONV_BWD_W];
@@ -776,13 +624,13 @@ static int cconv_bwd_w_impl(const float* x, const float* dout, float* dw, float*
 // join_pairs: the two outputs are the IQ-pair streams of ONE [rows, F, 4] tensor (tf.concat on the last axis,
 // model.py:456): out = that tensor, group g writes floats 2g, 2g+1 of every cell.  Returns false when the shapes do
 // not qualify for the grouped kernels (the caller then runs the layers one by one).
-static bool cconv_pair_ok(const float* x, const float* w, const float* o, int rows, int kin, int F, long long gx, long long gw,
+bool cconv_pair_ok(const float* x, const float* w, const float* o, int rows, int kin, int F, long long gx, long long gw,
                           long long go) {
     return (kin % 2 == 0) && (F % 2 == 0) && (kin % 32 == 0) && (F % 32 == 0) && aligned16(x) && aligned16(w) && aligned16(o) &&
            (gx % 4 == 0) && (gw % 4 == 0) && (go % 2 == 0) && small_enough(rows, 4LL * (kin > F ? kin : F)) &&
            small_enough(kin, 2LL * F) && (long long)ceil_div(rows, 128) * ceil_div(2 * F, 128) < 2 * kCUs;
 }
-static int cconv_fwd_grouped_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
+int cconv_fwd_grouped_impl(const float* x, const float* w, const float* bias, float* out, int rows, int kin, int F,
                                   int groups, long long gx, long long gw, long long gb, bool join_pairs, hipStream_t s) {
     if (!x || !w || !out || rows <= 0 || groups < 1 || groups > 2 || (join_pairs && groups != 2)) return DCCN_ERR_INVALID_ARG;
     GemmParams p = gp_zero();                 // out_g[rows,2F] = x_g[rows,2kin] . Weff_g[2kin,2F]
@@ -806,10 +654,10 @@ static int cconv_fwd_grouped_impl(const float* x, const float* w, const float* b
 // backward of `groups` (1,kin)->F C-Convs in ONE launch: dx_g = dout_g . Weff_g^T and the split-K slabs of
 // dWeff_g = x_g^T . dout_g (+ column sums), left un-folded in ws for the optimizer launch (defer[g]).
 // Strides in elements: gx (x and dx), gd (dout), gw (kernels).
-static size_t cconv_bwd_grouped_ws_bytes(int rows, int kin, int F, int groups) {
+size_t cconv_bwd_grouped_ws_bytes(int rows, int kin, int F, int groups) {
     return (size_t)groups * cconv_bw_ws_bytes(rows, kin, F);
 }
-static int cconv_bwd_grouped_impl(const float* x, const float* dout, const float* w, float* dx, int rows, int kin, int F,
+int cconv_bwd_grouped_impl(const float* x, const float* dout, const float* w, float* dx, int rows, int kin, int F,
                                   int groups, long long gx, long long gd, long long gw, void* ws, size_t ws_bytes,
                                   FoldDefer* defer, hipStream_t s) {
     if (!x || !dout || !w || !dx || !defer || rows <= 0 || groups < 1 || groups > 2) return DCCN_ERR_INVALID_ARG;
@@ -931,7 +779,7 @@ static int tail_blocks(long long cells, bool quad4 = false) {
     if (b < 1) b = 1;
     return (int)b;
 }
-static size_t tail_ws_bytes(long long cells, int nbits) {
+size_t tail_ws_bytes(long long cells, int nbits) {
     size_t o = 0;
     o = carve_size(o, (size_t)kTailBlocksMax * sizeof(TailBlockMetrics));
     o = carve_size(o, (size_t)kTailBlocksMax * tail_param_count(nbits) * sizeof(float));
@@ -955,10 +803,10 @@ static int tail_launch(bool bwd, const float* z, const int32_t* bits, const floa
 
 // pp/power_out: optional R8 finish riding on the slab-reduction kernel (fused receiver step)
 // defer != nullptr: do not launch the slab reduction; hand its arguments to the caller (fused receiver step)
-static int tail_impl(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob,
+int tail_impl(bool bwd, const float* z, const int32_t* bits, const float* tailp, float* prob,
                      dccn_metrics* metrics, float* dz, float* dtailp, long long cells, int nbits,
                      const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes, hipStream_t s,
-                     TailFinalizeArgs* defer = nullptr) {
+                     TailFinalizeArgs* defer) {
     if (!z || !bits || !tailp || !metrics || cells <= 0 || nbits < 1 || nbits > 4) return DCCN_ERR_INVALID_ARG;
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
     if (!ws || ws_bytes < tail_ws_bytes(cells, nbits)) return DCCN_ERR_WORKSPACE;
@@ -1018,7 +866,7 @@ static int dense_tail_max_blocks(int M, int N) {
     const int few = (M <= 96 && (N % 16) == 0) ? ceil_div(M, 16) * (N / 16) : 0;
     return few > b && few <= kTailBlocksMax ? few : b;
 }
-static size_t dense_tail_ws_bytes(int M, int N, int nbits) {
+size_t dense_tail_ws_bytes(int M, int N, int nbits) {
     const size_t nb = (size_t)dense_tail_max_blocks(M, N);
     size_t o = 0;
     o = carve_size(o, nb * sizeof(TailBlockMetrics));
@@ -1030,14 +878,14 @@ static bool dense_tail_shape_ok(int M, int K, int N, int nbits) {
     return g_tune[TUNE_DENSE_FWD] > 0 && nbits >= 1 && nbits <= 4 && M > 0 && K > 0 && N > 0 && (K % 4 == 0) && (N % 4 == 0) &&
            small_enough(M, K) && small_enough(K, N) && (long long)ceil_div(M, 128) * ceil_div(N, 128) < 2 * kCUs;
 }
-static bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
+bool dense_tail_ok(const float* x, const float* w, int M, int K, int N, int nbits) {
     return dense_tail_shape_ok(M, K, N, nbits) && aligned16(x) && aligned16(w);
 }
 // which steps take the fused launch for 8-QAM / 16-QAM (knob 13: bit 0 = the lane-per-cell forms -- nbits 3, and nbits 4
 // evaluation; bit 1 = the quad-lane form of 16-QAM training).  The operator dccn_dense_tail_* itself accepts every nbits.
 // bit 2: BPSK / QPSK steps of LARGE layers (>= two rounds of 128x128 tiles) run the dense forward on the 128x128x32 tile
 // family and the tail as its own launch.
-static bool dense_tail_planned(int nbits, bool train, int M = 0, int N = 0) {
+bool dense_tail_planned(int nbits, bool train, int M, int N) {
     const int k = g_tune[TUNE_TAIL_FUSE_HI];
     if (nbits <= 2) return !((k & 4) && (long long)ceil_div(M, 128) * ceil_div(N, 128) >= 2 * kCUs);
     return (nbits == 4 && train) ? (k & 2) != 0 : (k & 1) != 0;
@@ -1060,10 +908,10 @@ static int dense_tail_hi_launch(int variant, const GemmParams& p, const TailEpiP
 }
 
 // z nullable (not materialised then).  defer: as tail_impl.
-static int dense_tail_impl(bool bwd, const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
+int dense_tail_impl(bool bwd, const float* x, const float* w, const float* bias, float* z, const int32_t* bits,
                            const float* tailp, float* prob, dccn_metrics* metrics, float* dz, float* dtailp, int M,
                            int K, int N, int nbits, const PowerPartials* pp, float* power_out, void* ws, size_t ws_bytes,
-                           hipStream_t s, TailFinalizeArgs* defer = nullptr) {
+                           hipStream_t s, TailFinalizeArgs* defer) {
     if (!x || !w || !bits || !tailp || !metrics || M <= 0 || K <= 0 || N <= 0 || (N & 1) || nbits < 1 || nbits > 4)
         return DCCN_ERR_INVALID_ARG;
     if (bwd && (!dz || !dtailp)) return DCCN_ERR_INVALID_ARG;
@@ -1148,9 +996,9 @@ static int dense_tail_impl(bool bwd, const float* x, const float* w, const float
 }
 
 // prep = false: the per-step bookkeeping (alpha, beta powers, global_step) already rode on an earlier kernel of the step
-static int adam_impl(float* param, const float* grad, float* m, float* v, const float* reg_coef,
+int adam_impl(float* param, const float* grad, float* m, float* v, const float* reg_coef,
                      const float* reg_gate, dccn_adam_state* st, dccn_adam_hparams hp, long long n, hipStream_t s,
-                     bool prep = true) {
+                     bool prep) {
     if (!param || !grad || !m || !v || !st || n <= 0) return DCCN_ERR_INVALID_ARG;
     if (prep) {
         hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, st, hp);
@@ -1172,13 +1020,7 @@ static bool shape_ok(const dccn_rx_shape* sh) {
            sh->nbits <= 4;
 }
 
-struct RxLayout {
-    long long o_conv_w, o_conv_b, o_dense_w, o_dense_b, o_tail, total;
-    int rows, cols, dK, dN;
-    long long cells;
-    size_t ws_norm, ws_tail, ws_dense_bw, ws_conv_bw, ws_sync;
-};
-static RxLayout rx_layout(const dccn_rx_shape* sh) {
+RxLayout rx_layout(const dccn_rx_shape* sh) {
     RxLayout L;
     const long long F2 = 2LL * sh->F;
     L.o_conv_w = 0;
@@ -1252,7 +1094,7 @@ static bool overlap_streams(OverlapStreams* o) {
 }
 
 // ---- fused static-channel generator launch (datagen.h gen_static_frames_kernel; ABI entry points further down) ----
-static bool gen_static_ok(const dccn_gen_static* g) {
+bool gen_static_ok(const dccn_gen_static* g) {
     if (!g || !g->bits_out || !g->cell_map || !g->const_tab || !g->idft || !g->snr_db || !g->y || !g->noise || !g->power_partial)
         return false;
     if (g->frames <= 0 || g->frames > 65535 || g->S <= 0 || 2 * g->S > 16 || g->K <= 0 || g->CP < 0 || g->D <= 0 || g->nbits < 1 ||
@@ -1275,7 +1117,7 @@ static bool gen_static_ok(const dccn_gen_static* g) {
 }
 // the generator launch's argument block from its descriptor (also used by launches that carry the generator's workgroups as
 // riders: eq_step.h)
-static int gen_static_args(const dccn_gen_static* g, GenStaticArgs* out) {
+int gen_static_args(const dccn_gen_static* g, GenStaticArgs* out) {
     if (!gen_static_ok(g)) return DCCN_ERR_INVALID_ARG;
     if (ceil_div(g->frames, kGenFramesPerBlock) > kChanPartials) return DCCN_ERR_INVALID_ARG;
     GenStaticArgs& a = *out;
@@ -1310,7 +1152,7 @@ static int gen_static_args(const dccn_gen_static* g, GenStaticArgs* out) {
 #endif
     return DCCN_OK;
 }
-static int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenChainScalars* chains = nullptr) {
+int gen_static_launch(const dccn_gen_static* g, hipStream_t s, const GenChainScalars* chains) {
     GenStaticArgs a;
     DCCN_TRY(gen_static_args(g, &a));
     const size_t smem = gen_static_smem_bytes<7, 64, 16>();
@@ -1582,24 +1424,14 @@ static int rx_step_impl(const dccn_rx_shape* sh, const dccn_rx_buffers* b, bool 
     return DCCN_OK;
 }
 
-static int eq_monitor_blocks(int B, int K) {
+int eq_monitor_blocks(int B, int K) {
     long long n = ceil_div_ll((long long)B * K * 2, 256);
     if (n > 256) n = 256;
     return (int)(n < 1 ? 1 : n);
 }
-#include "eq_step.h"
-
 }  // namespace dccn
 
 using namespace dccn;
-
-struct dccn_rx_graph {
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-    hipStream_t cap;     // capture happens on a private stream: the caller's may be the (uncapturable) null stream
-    hipStream_t side;
-    hipEvent_t ev_fork, ev_join;
-};
 
 struct dccn_timer {
     hipEvent_t a, b;
@@ -2015,326 +1847,7 @@ int dccn_rx_graph_create(const dccn_rx_shape* shape, const dccn_rx_buffers* buf,
     *out = g;
     return DCCN_OK;
 }
-// ---- fused equaliser step ---------------------------------------------------------------------------
-int dccn_eq_param_offsets(const dccn_eq_shape* shape, long long* offsets) {
-    if (!eq_shape_ok(shape) || !offsets) return DCCN_ERR_INVALID_ARG;
-    const EqDims d = eq_dims(shape);
-    for (int i = 0; i < 21; ++i) offsets[i] = d.o[i];
-    return DCCN_OK;
-}
-size_t dccn_eq_workspace_size(const dccn_eq_shape* shape, int train) {
-    if (!eq_shape_ok(shape)) return 0;
-    return eq_ws_bytes(shape, train);
-}
-int dccn_eq_workspace_tensor(const dccn_eq_shape* shape, int train, const char* name, size_t* byte_offset, size_t* count) {
-    if (!eq_shape_ok(shape) || !name || !byte_offset || !count) return DCCN_ERR_INVALID_ARG;
-    const EqDims d = eq_dims(shape);
-    // carve a dummy base so that every pointer is base + offset (the Carver hands out nullptr for a null base)
-    char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 40);
-    Carver c(base, ~static_cast<size_t>(0) >> 2);
-    EqWs w;
-    memset(&w, 0, sizeof(w));
-    eq_carve(c, shape, d, train != 0, w);
-    const size_t B = d.B, R = d.R, SK2 = d.SK2, K2 = 2 * (size_t)d.K, N2 = 2 * (size_t)d.nsc;
-    struct Ent { const char* n; const float* p; size_t cnt; bool tr; };
-    const Ent tab[] = {
-        {"x_norm", w.x_norm, R * N2, false}, {"ln", w.ln, R * N2, false}, {"t1", w.t1, R * K2, false}, {"y", w.y, R * K2, false},
-        {"d1", w.d1, B * d.Pp, false}, {"d2", w.d2, B * SK2, false}, {"d3", w.d3, B * SK2, false}, {"d4", w.d4, B * SK2, false},
-        {"T", w.T, SK2 * SK2, false}, {"be", w.be, SK2, false}, {"eq", w.eq, B * SK2, false}, {"corr", w.corr, B * SK2, false},
-        {"eqc", w.eqc, R * K2, false}, {"corc", w.corc, R * K2, false}, {"cat", w.cat, R * 2 * K2, false},
-        {"fft", w.fft, R * 2 * (size_t)d.F, false}, {"z", w.z, B * 2 * (size_t)d.D, false},
-        {"dz", w.dz, B * 2 * (size_t)d.D, true}, {"dfft", w.dfft, R * 2 * (size_t)d.F, true}, {"dout", w.dout, R * N2, true},
-        {"dcat", w.dcat, R * 2 * K2, true}, {"deqc", w.deqc, R * K2, true}, {"dcorc", w.dcorc, R * K2, true},
-        {"deq", w.deq, B * SK2, true}, {"dcorr", w.dcorr, B * SK2, true}, {"dy", w.dy, B * SK2, true}, {"dh", w.dh, B * SK2, true},
-        {"dT", w.dT, SK2 * SK2, true}, {"dbe", w.dbe, SK2, true}, {"dd4", w.dd4, B * SK2, true}, {"dd3", w.dd3, B * SK2, true},
-        {"dd2", w.dd2, B * SK2, true}, {"dd1", w.dd1, B * d.Pp, true}, {"dflat", w.dflat, B * SK2, true}, {"dt1", w.dt1, R * K2, true},
-    };
-    for (const Ent& e : tab) {
-        if (strcmp(e.n, name) != 0) continue;
-        if (e.tr && !train) return DCCN_ERR_INVALID_ARG;
-        *byte_offset = (size_t)(reinterpret_cast<const char*>(e.p) - base);
-        *count = e.cnt;
-        return DCCN_OK;
-    }
-    return DCCN_ERR_INVALID_ARG;
-}
-size_t dccn_eq_rx_folded_floats(const dccn_eq_shape* shape) {
-    if (!eq_shape_ok(shape)) return 0;
-    const size_t N2 = 2 * (size_t)(shape->K + shape->CP), dN = 2 * (size_t)shape->D;
-    return (size_t)shape->S * N2 * dN + dN;
-}
-int dccn_eq_rx_fold(const dccn_eq_shape* shape, const float* rx_params, float* out, dccn_stream_t stream) {
-    if (!eq_shape_ok(shape) || !rx_params || !out) return DCCN_ERR_INVALID_ARG;
-    const EqDims d = eq_dims(shape);
-    dccn_rx_shape rsh;
-    rsh.batch = 1; rsh.S = d.S; rsh.kin = d.cp ? d.nsc : d.K; rsh.F = d.F; rsh.D = d.D; rsh.nbits = shape->nbits;
-    const RxLayout L = rx_layout(&rsh);
-    const int N2 = 2 * d.nsc, rows = d.S * N2;
-    hipLaunchKernelGGL(eq_rx_fold_kernel, dim3(rows + 1), dim3(256), 0, (hipStream_t)stream, rx_params + L.o_conv_w,
-                       rx_params + L.o_conv_b, rx_params + L.o_dense_w, rx_params + L.o_dense_b, out, out + (size_t)rows * L.dN,
-                       d.S, N2, d.win, rsh.kin, d.F, L.dN);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_eq_eval_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_stream_t stream) {
-    return eq_step_impl(shape, buf, false, dccn_adam_hparams(), (hipStream_t)stream);
-}
-int dccn_eq_train_step(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, dccn_adam_hparams hp,
-                       dccn_stream_t stream) {
-    return eq_step_impl(shape, buf, true, hp, (hipStream_t)stream);
-}
-// ---- chain groups: G independent equaliser chains per launch sequence (common.h ChainCtx) ------------------------------
-// every device pointer of chain g must lie at ONE byte offset from chain 0's (the chains' arenas have the same layout)
-struct ChainOffsetCheck {
-    long long off[kMaxChains];
-    bool have[kMaxChains];
-    bool ok = true;
-    int n;
-    explicit ChainOffsetCheck(int n_) : n(n_) { for (int g = 0; g < kMaxChains; ++g) { off[g] = 0; have[g] = false; } }
-    // pointers p[g] (field f of every chain's struct)
-    void field(const void* const* p) {
-        for (int g = 0; g < n && ok; ++g) {
-            if ((p[g] == nullptr) != (p[0] == nullptr)) { ok = false; return; }
-            if (p[g] == nullptr) continue;
-            const long long d = (long long)(reinterpret_cast<const char*>(p[g]) - reinterpret_cast<const char*>(p[0]));
-            if (!have[g]) { off[g] = d; have[g] = true; }
-            else if (off[g] != d) ok = false;
-        }
-    }
-    bool finish(ChainCtx* ctx) {
-        if (!ok) return false;
-        ctx->G = n;
-        for (int g = 0; g < kMaxChains; ++g) { ctx->co.off[g] = 0; ctx->nbits[g] = 0; }
-        for (int g = 0; g < n; ++g) {
-            if (!have[g] || (off[g] & 255) != 0 || (g > 0 && off[g] == 0)) return false;
-            ctx->co.off[g] = off[g];
-        }
-        return true;
-    }
-};
-#define CHAIN_FIELD(chk, arr, n, member)                                             \
-    do {                                                                             \
-        const void* f__[kMaxChains];                                                 \
-        for (int g__ = 0; g__ < (n); ++g__) f__[g__] = (const void*)((arr)[g__]->member); \
-        (chk).field(f__);                                                            \
-    } while (0)
-
-static bool gen_static_same_plan(const dccn_gen_static* a, const dccn_gen_static* b) {
-    if (a->frames != b->frames || a->S != b->S || a->K != b->K || a->CP != b->CP || a->D != b->D || a->n_taps != b->n_taps ||
-        a->L != b->L || a->identity != b->identity || a->n_profiles != b->n_profiles || a->tap_stride != b->tap_stride ||
-        a->h_rep != b->h_rep || a->pilot_re != b->pilot_re || a->pilot_im != b->pilot_im)
-        return false;
-    for (int i = 0; i < a->n_profiles; ++i)
-        if (a->profiles[i].n_taps != b->profiles[i].n_taps || a->profiles[i].L != b->profiles[i].L ||
-            a->profiles[i].identity != b->profiles[i].identity)
-            return false;
-    return true;
-}
-static void gen_static_chain_fields(ChainOffsetCheck& chk, const dccn_gen_static* const* g, int n) {
-    CHAIN_FIELD(chk, g, n, bits_out); CHAIN_FIELD(chk, g, n, cell_map); CHAIN_FIELD(chk, g, n, const_tab);
-    CHAIN_FIELD(chk, g, n, idft); CHAIN_FIELD(chk, g, n, coeff); CHAIN_FIELD(chk, g, n, alpha); CHAIN_FIELD(chk, g, n, snr_db);
-    CHAIN_FIELD(chk, g, n, y); CHAIN_FIELD(chk, g, n, noise); CHAIN_FIELD(chk, g, n, power_partial);
-    CHAIN_FIELD(chk, g, n, noise_partial); CHAIN_FIELD(chk, g, n, noise_power_out); CHAIN_FIELD(chk, g, n, tx_out);
-    CHAIN_FIELD(chk, g, n, H_out);
-    for (int i = 0; i < g[0]->n_profiles && chk.ok; ++i) {
-        CHAIN_FIELD(chk, g, n, profiles[i].coeff);
-        CHAIN_FIELD(chk, g, n, profiles[i].alpha);
-    }
-}
-
-int dccn_chain_group_max(void) { return kMaxChains; }
-
-int dccn_gen_static_frames_grouped(int n_chains, const dccn_gen_static* const* g, dccn_stream_t stream) {
-    if (n_chains < 1 || n_chains > kMaxChains || !g) return DCCN_ERR_INVALID_ARG;
-    for (int i = 0; i < n_chains; ++i)
-        if (!g[i] || !gen_static_ok(g[i]) || !gen_static_same_plan(g[0], g[i])) return DCCN_ERR_INVALID_ARG;
-    if (n_chains == 1) return gen_static_launch(g[0], (hipStream_t)stream);
-    ChainOffsetCheck chk(n_chains);
-    gen_static_chain_fields(chk, g, n_chains);
-    ChainCtx ctx;
-    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
-    GenChainScalars gc;
-    memset(&gc, 0, sizeof(gc));
-    gc.n = n_chains;
-    for (int i = 0; i < n_chains; ++i) { gc.nbits[i] = g[i]->nbits; gc.offset[i] = g[i]->offset; gc.seed[i] = g[i]->seed; ctx.nbits[i] = g[i]->nbits; }
-    ChainScope scope(ctx);
-    return gen_static_launch(g[0], (hipStream_t)stream, &gc);
-}
-
-int dccn_gen_static_apply_grouped(int n_chains, const dccn_gen_static* const* g, float* const* x_out, float* const* noise_power,
-                                  dccn_stream_t stream) {
-    if (n_chains < 1 || n_chains > kMaxChains || !g || !x_out) return DCCN_ERR_INVALID_ARG;
-    for (int i = 0; i < n_chains; ++i)
-        if (!g[i] || !x_out[i] || !gen_static_ok(g[i]) || !gen_static_same_plan(g[0], g[i])) return DCCN_ERR_INVALID_ARG;
-    if (n_chains == 1) return dccn_gen_static_apply(g[0], x_out[0], noise_power ? noise_power[0] : nullptr, stream);
-    ChainOffsetCheck chk(n_chains);
-    gen_static_chain_fields(chk, g, n_chains);
-    chk.field(reinterpret_cast<const void* const*>(x_out));
-    if (noise_power) chk.field(reinterpret_cast<const void* const*>(noise_power));
-    ChainCtx ctx;
-    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
-    ChainScope scope(ctx);
-    return dccn_gen_static_apply(g[0], x_out[0], noise_power ? noise_power[0] : nullptr, stream);
-}
-
-int dccn_eq_group_supported(const dccn_eq_shape* shape) {
-    if (!eq_shape_ok(shape) || g_tune[TUNE_EQ_REPLAN] != 1 || !g_tune[TUNE_FEWROW] || g_tune[TUNE_SKINNY] <= 0) return 0;
-    const EqDims d = eq_dims(shape);
-    // the launches that carry a chain index: the few-row plan of the fused step (<= 96 frames), the pilot bottleneck as one
-    // launch per direction, the frozen receiver folded into one matrix
-    return (d.B <= 96 && (d.Pp == 16 || d.Pp == 32) && dccn_eq_norm_rides(shape) == 1 && (d.S * 2 * d.nsc) % 16 == 0 &&
-            d.S * 2 * d.nsc <= 1152) ? 1 : 0;
-}
-
-int dccn_eq_train_step_grouped(int n_chains, const dccn_eq_shape* const* shapes, const dccn_eq_buffers* const* bufs,
-                               dccn_adam_hparams hp, dccn_stream_t stream) {
-    if (n_chains < 1 || n_chains > kMaxChains || !shapes || !bufs) return DCCN_ERR_INVALID_ARG;
-    for (int i = 0; i < n_chains; ++i) {
-        if (!shapes[i] || !bufs[i] || !eq_shape_ok(shapes[i])) return DCCN_ERR_INVALID_ARG;
-        const dccn_eq_shape *a = shapes[0], *c = shapes[i];
-        // one launch plan: everything but the modulation agrees
-        if (a->batch != c->batch || a->S != c->S || a->K != c->K || a->CP != c->CP || a->cp != c->cp || a->F != c->F || a->D != c->D ||
-            a->pilot_size != c->pilot_size || a->P != c->P)
-            return DCCN_ERR_INVALID_ARG;
-        const dccn_eq_buffers *p = bufs[0], *q = bufs[i];
-        if (p->workspace_bytes != q->workspace_bytes || p->reg_uniform != q->reg_uniform || p->x_prenormalised != q->x_prenormalised ||
-            p->norm_slot != q->norm_slot || (p->x_next_virtual == nullptr) != (q->x_next_virtual == nullptr))
-            return DCCN_ERR_INVALID_ARG;
-        if (q->prob != nullptr) return DCCN_ERR_INVALID_ARG;          // (its size depends on the modulation: not part of the arena)
-    }
-    if (n_chains == 1) return eq_step_impl(shapes[0], bufs[0], true, hp, (hipStream_t)stream);
-    if (!dccn_eq_group_supported(shapes[0])) return DCCN_ERR_UNSUPPORTED;
-    ChainOffsetCheck chk(n_chains);
-    CHAIN_FIELD(chk, bufs, n_chains, x); CHAIN_FIELD(chk, bufs, n_chains, bits); CHAIN_FIELD(chk, bufs, n_chains, eq_params);
-    CHAIN_FIELD(chk, bufs, n_chains, eq_grads); CHAIN_FIELD(chk, bufs, n_chains, adam_m); CHAIN_FIELD(chk, bufs, n_chains, adam_v);
-    CHAIN_FIELD(chk, bufs, n_chains, reg_coef); CHAIN_FIELD(chk, bufs, n_chains, adam); CHAIN_FIELD(chk, bufs, n_chains, rx_params);
-    CHAIN_FIELD(chk, bufs, n_chains, out_eq); CHAIN_FIELD(chk, bufs, n_chains, chest); CHAIN_FIELD(chk, bufs, n_chains, snr_db);
-    CHAIN_FIELD(chk, bufs, n_chains, pilot_carriers); CHAIN_FIELD(chk, bufs, n_chains, metrics); CHAIN_FIELD(chk, bufs, n_chains, tx_power);
-    CHAIN_FIELD(chk, bufs, n_chains, workspace); CHAIN_FIELD(chk, bufs, n_chains, rx_folded); CHAIN_FIELD(chk, bufs, n_chains, x_next);
-    if (bufs[0]->x_next_virtual != nullptr) {
-        const dccn_gen_static* gv[kMaxChains];
-        for (int i = 0; i < n_chains; ++i) {
-            gv[i] = bufs[i]->x_next_virtual;
-            if (!gen_static_same_plan(gv[0], gv[i])) return DCCN_ERR_INVALID_ARG;
-        }
-        CHAIN_FIELD(chk, gv, n_chains, y); CHAIN_FIELD(chk, gv, n_chains, noise); CHAIN_FIELD(chk, gv, n_chains, power_partial);
-        CHAIN_FIELD(chk, gv, n_chains, noise_partial); CHAIN_FIELD(chk, gv, n_chains, noise_power_out);
-    }
-    for (int i = 0; i < n_chains; ++i)
-        if ((bufs[i]->monitor == nullptr) != (bufs[0]->monitor == nullptr)) return DCCN_ERR_INVALID_ARG;
-    if (bufs[0]->monitor != nullptr) {
-        const dccn_eq_monitor* mm[kMaxChains];
-        for (int i = 0; i < n_chains; ++i) {
-            mm[i] = bufs[i]->monitor;
-            if (mm[i]->chan_per_symbol != mm[0]->chan_per_symbol || mm[i]->workspace_bytes != mm[0]->workspace_bytes)
-                return DCCN_ERR_INVALID_ARG;
-        }
-        CHAIN_FIELD(chk, mm, n_chains, chest); CHAIN_FIELD(chk, mm, n_chains, chan); CHAIN_FIELD(chk, mm, n_chains, metrics);
-        CHAIN_FIELD(chk, mm, n_chains, tx_power); CHAIN_FIELD(chk, mm, n_chains, noise_power); CHAIN_FIELD(chk, mm, n_chains, acc5);
-        CHAIN_FIELD(chk, mm, n_chains, rms_out); CHAIN_FIELD(chk, mm, n_chains, workspace);
-    }
-    ChainCtx ctx;
-    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
-    if (bufs[0]->rx_folded == nullptr) return DCCN_ERR_UNSUPPORTED;
-    for (int i = 0; i < n_chains; ++i) {
-        ctx.nbits[i] = shapes[i]->nbits;
-        if (bufs[i]->gen_next_rides != bufs[0]->gen_next_rides) return DCCN_ERR_INVALID_ARG;
-        if (bufs[0]->gen_next_rides) {                     // (the generator's per-chain scalars travel with the group)
-            const dccn_gen_static* gv = bufs[i]->x_next_virtual;
-            if (!gv) return DCCN_ERR_INVALID_ARG;
-            ctx.gen_seed[i] = gv->seed; ctx.gen_offset[i] = gv->offset; ctx.gen_nbits[i] = gv->nbits;
-        }
-    }
-    if (bufs[0]->gen_next_rides) {
-        const dccn_gen_static* gv[kMaxChains];
-        for (int i = 0; i < n_chains; ++i) gv[i] = bufs[i]->x_next_virtual;
-        ChainOffsetCheck chk2(n_chains);
-        gen_static_chain_fields(chk2, gv, n_chains);
-        ChainCtx same;
-        if (!chk2.finish(&same)) return DCCN_ERR_INVALID_ARG;
-        for (int i = 0; i < n_chains; ++i)
-            if (same.co.off[i] != ctx.co.off[i]) return DCCN_ERR_INVALID_ARG;
-    }
-    ChainScope scope(ctx);
-    return eq_step_impl(shapes[0], bufs[0], true, hp, (hipStream_t)stream);
-}
-
-int dccn_eq_monitor_accumulate_grouped(int n_chains, const dccn_eq_monitor* const* m, dccn_stream_t stream) {
-    if (n_chains < 1 || n_chains > kMaxChains || !m) return DCCN_ERR_INVALID_ARG;
-    for (int i = 0; i < n_chains; ++i) {
-        if (!m[i]) return DCCN_ERR_INVALID_ARG;
-        if (m[i]->chan_per_symbol != m[0]->chan_per_symbol || m[i]->B != m[0]->B || m[i]->S != m[0]->S || m[i]->K != m[0]->K ||
-            m[i]->workspace_bytes != m[0]->workspace_bytes)
-            return DCCN_ERR_INVALID_ARG;
-    }
-    const dccn_eq_monitor* a = m[0];
-    if (n_chains == 1)
-        return dccn_eq_monitor_accumulate(a->chest, a->chan, a->chan_per_symbol, a->B, a->S, a->K, a->metrics, a->tx_power,
-                                          a->noise_power, a->acc5, a->rms_out, a->workspace, a->workspace_bytes, stream);
-    ChainOffsetCheck chk(n_chains);
-    CHAIN_FIELD(chk, m, n_chains, chest); CHAIN_FIELD(chk, m, n_chains, chan); CHAIN_FIELD(chk, m, n_chains, metrics);
-    CHAIN_FIELD(chk, m, n_chains, tx_power); CHAIN_FIELD(chk, m, n_chains, noise_power); CHAIN_FIELD(chk, m, n_chains, acc5);
-    CHAIN_FIELD(chk, m, n_chains, rms_out); CHAIN_FIELD(chk, m, n_chains, workspace);
-    ChainCtx ctx;
-    if (!chk.finish(&ctx)) return DCCN_ERR_INVALID_ARG;
-    ChainScope scope(ctx);
-    return dccn_eq_monitor_accumulate(a->chest, a->chan, a->chan_per_symbol, a->B, a->S, a->K, a->metrics, a->tx_power,
-                                      a->noise_power, a->acc5, a->rms_out, a->workspace, a->workspace_bytes, stream);
-}
-
-int dccn_eq_norm_rides(const dccn_eq_shape* shape) {
-    if (!eq_shape_ok(shape)) return 0;
-    const EqDims d = eq_dims(shape);
-    const int ncols = d.S * 2 * d.nsc;
-    return (g_tune[TUNE_EQ_REPLAN] != 0 && kNormFusedCG == 2 && (ncols % 4) == 0 && d.B <= 128 * kNormFusedRPT) ? 1 : 0;
-}
-int dccn_eq_graph_create(const dccn_eq_shape* shape, const dccn_eq_buffers* buf, int mode, dccn_adam_hparams hp,
-                         dccn_stream_t stream, dccn_rx_graph** out) {
-    if (!out || !eq_shape_ok(shape) || !buf) return DCCN_ERR_INVALID_ARG;
-    (void)stream;
-    dccn_rx_graph* g = new dccn_rx_graph();
-    memset(g, 0, sizeof(*g));
-    if (hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking) != hipSuccess) {
-        dccn_rx_graph_destroy(g);
-        return DCCN_ERR_LAUNCH;
-    }
-    hipError_t e = hipStreamBeginCapture(g->cap, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) {
-        dccn_rx_graph_destroy(g);
-        return hip_fail(e);
-    }
-    const int st = eq_step_impl(shape, buf, (mode & 1) != 0, hp, g->cap);
-    e = hipStreamEndCapture(g->cap, &g->graph);
-    if (st != DCCN_OK || e != hipSuccess) {
-        dccn_rx_graph_destroy(g);
-        return st != DCCN_OK ? st : hip_fail(e);
-    }
-    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        dccn_rx_graph_destroy(g);
-        return hip_fail(e);
-    }
-    *out = g;
-    return DCCN_OK;
-}
-
-int dccn_rx_graph_launch(dccn_rx_graph* g, dccn_stream_t stream) {
-    if (!g || !g->exec) return DCCN_ERR_STATE;
-    DCCN_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
-    return DCCN_OK;
-}
-int dccn_rx_graph_destroy(dccn_rx_graph* g) {
-    if (!g) return DCCN_OK;
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->side) (void)hipStreamDestroy(g->side);
-    if (g->cap) (void)hipStreamDestroy(g->cap);
-    delete g;
-    return DCCN_OK;
-}
-
+// ---- HIP-event timers on the caller's stream ------------------------------------------------------------------
 int dccn_timer_create(dccn_timer** out) {
     if (!out) return DCCN_ERR_INVALID_ARG;
     dccn_timer* t = new dccn_timer();
@@ -2367,774 +1880,6 @@ int dccn_timer_destroy(dccn_timer* t) {
     (void)hipEventDestroy(t->b);
     delete t;
     return DCCN_OK;
-}
-int dccn_stream_synchronize(dccn_stream_t stream) {
-    DCCN_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return DCCN_OK;
-}
-
-// ---- equaliser stage operators ------------------------------------------------------------------
-static inline unsigned ew_blocks(long long n) { return ew_blocks_n(n); }
-int dccn_layer_norm_fwd(const float* x, float* y, float* mean, float* inv, int rows, int cols, float eps,
-                        dccn_stream_t stream) {
-    if (!x || !y || rows <= 0 || cols <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, y, mean, inv, cols,
-                       eps);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_layer_norm_bwd(const float* dy, const float* y, const float* inv, float* dx, int rows, int cols,
-                        dccn_stream_t stream) {
-    if (!dy || !y || !inv || !dx || rows <= 0 || cols <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, y, inv, dx, cols);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_tanh_fwd(const float* x, float* y, long long n, dccn_stream_t stream) {
-    if (!x || !y || n <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_tanh_bwd(const float* dy, const float* y, float* dx, long long n, dccn_stream_t stream) {
-    if (!dy || !y || !dx || n <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_equalize_fwd(const float* y, const float* h, float* eq, float* corr, long long n_pairs,
-                      dccn_stream_t stream) {
-    if (!y || !h || !eq || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(equalize_fwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)y, (const float2*)h, (float2*)eq, (float2*)corr, n_pairs);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_equalize_bwd(const float* y, const float* h, const float* d_eq, const float* d_corr, float* dy, float* dh,
-                      long long n_pairs, dccn_stream_t stream) {
-    if (!y || !h || (!d_eq && !d_corr) || (!dy && !dh) || n_pairs <= 0) return DCCN_ERR_INVALID_ARG;
-    DCCN_LAUNCH_CHAINS_Z(equalize_bwd_kernel, dim3(ew_blocks(n_pairs)), dim3(256), 0, (hipStream_t)stream,
-                         (const float2*)y, (const float2*)h, (const float2*)d_eq, (const float2*)d_corr, (float2*)dy,
-                         (float2*)dh, n_pairs);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_pilot_snr(const float* eq, const int* carriers, float* snr_db, int frames, int S, int K, int P,
-                   dccn_stream_t stream) {
-    if (!eq || !carriers || !snr_db || frames <= 0 || S <= 0 || K <= 0 || P <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(pilot_snr_kernel, dim3(frames), dim3(64), 0, (hipStream_t)stream, (const float2*)eq, carriers,
-                       snr_db, S, K, P);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_cconv2d_same_expand(const float* w, const float* bias, float* T, float* bias_eff, int L, int W, int kL,
-                             int kW, dccn_stream_t stream) {
-    if (!w || !T || L <= 0 || W <= 0 || kL <= 0 || kW <= 0) return DCCN_ERR_INVALID_ARG;
-    const long long n = (long long)L * W * 2;
-    if (n * n > (1LL << 31)) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(cconv2d_same_expand_kernel, dim3(ew_blocks(n * n)), dim3(256), 0, (hipStream_t)stream, w, bias,
-                       T, bias_eff, L, W, kL, kW);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_cconv2d_same_reduce(const float* dT, const float* dbias_eff, float* dw, float* dbias, int L, int W, int kL,
-                             int kW, dccn_stream_t stream) {
-    if (!dT || !dw || L <= 0 || W <= 0 || kL <= 0 || kW <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(cconv2d_same_reduce_kernel, dim3(kL * kW + 1), dim3(64), 0, (hipStream_t)stream, dT, dbias_eff,
-                       dw, dbias, L, W, kL, kW);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-// ---- device-side input generator ------------------------------------------------------------------
-int dccn_philox_fill(uint32_t* out, long long n, unsigned stream, unsigned offset, unsigned long long seed,
-                     dccn_stream_t stream_handle) {
-    if (!out || n <= 0) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream_handle, out, n, stream, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_ofdm_tx_frames(const int32_t* bits_in, int32_t* bits_out, const int32_t* cell_map, const float* const_tab,
-                        float pilot_re, float pilot_im, const float* idft, float* grid_ws, float* tx, int frames,
-                        int S, int K, int CP, int D, int nbits, unsigned long long seed, unsigned offset,
-                        dccn_stream_t stream) {
-    if (!cell_map || !const_tab || !idft || !grid_ws || !tx || frames <= 0 || S <= 0 || K <= 0 || CP < 0 || D <= 0 ||
-        nbits < 1 || nbits > 4)
-        return DCCN_ERR_INVALID_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const long long n_cells = (long long)frames * S * K;
-    hipLaunchKernelGGL(tx_grid_kernel, dim3((unsigned)ceil_div_ll(n_cells, 256)), dim3(256), 0, s, bits_in, bits_out,
-                       cell_map, (const float2*)const_tab, make_float2(pilot_re, pilot_im), (float2*)grid_ws, n_cells,
-                       S * K, D, nbits, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    return dense_fwd_impl(grid_ws, idft, nullptr, tx, frames * S, 2 * K, 2 * (K + CP), s);
-}
-static int chan_blocks_x(int T) { return ceil_div(T, 256); }
-// persistent FIR grid: all items when they are few, else eight blocks per CU; never more than the partial slots
-static int fir_blocks(int items, int cap) {
-    int b = items < 8 * kCUs ? items : 8 * kCUs;
-    if (b > cap) b = cap;
-    return b < 1 ? 1 : b;
-}
-// static-channel FIR: whole frames per block (bx items each) so that a frame's taps are set up once in the launch
-struct FirPlan {
-    int blocks, ipb;
-};
-static FirPlan fir_plan(int items, int bx, int cap) {
-    const int b0 = fir_blocks(items, cap);
-    FirPlan p;
-    p.ipb = ceil_div(ceil_div(items, b0), bx) * bx;
-    p.blocks = ceil_div(items, p.ipb);
-    return p;
-}
-size_t dccn_channel_awgn_workspace_size(int frames, int T, int L) {
-    if (frames <= 0 || T <= 0 || L <= 0) return 0;
-    size_t o = 0;
-    o = carve_size(o, (size_t)frames * L * 2 * sizeof(float));
-    o = carve_size(o, (size_t)frames * T * 2 * sizeof(float));
-    o = carve_size(o, (size_t)kChanPartials * sizeof(double));
-    o = carve_size(o, (size_t)frames * chan_blocks_x(T) * sizeof(double));
-    o = carve_size(o, 4 * sizeof(float));
-    return align_up(o, 256);
-}
-int dccn_channel_awgn(const float* tx, const float* taps_in, const float* coeff, const float* alpha, int n_taps,
-                      int L, int identity, const float* snr_db, const float* noise_in, float* out, float* H, int nfft,
-                      float* noise_power, int frames, int T, unsigned long long seed, unsigned offset,
-                      void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!tx || !snr_db || !out || frames <= 0 || frames > 65535 || T <= 0 || L <= 0 || L > 64) return DCCN_ERR_INVALID_ARG;
-    if (!identity && (!coeff || !alpha || n_taps <= 0 || n_taps > 16)) return DCCN_ERR_INVALID_ARG;
-    if (H && nfft <= 0) return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_channel_awgn_workspace_size(frames, T, L)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    Carver c(workspace, workspace_bytes);
-    float* g = c.take<float>((size_t)frames * L * 2);
-    float* y = c.take<float>((size_t)frames * T * 2);
-    const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)kChanPartials);
-    double* npartial = c.take<double>((size_t)frames * bx);
-    // nobody wants the frequency response and the taps are drawn here: the FIR blocks draw them themselves
-    TapGen tg;
-    memset(&tg, 0, sizeof(tg));
-    tg.enabled = (H == nullptr && taps_in == nullptr) ? 1 : 0;
-    tg.coeff = coeff; tg.alpha = alpha; tg.n_taps = n_taps; tg.identity = identity; tg.tap_stride = n_taps;
-    tg.offset = offset; tg.seed = seed;
-    if (!tg.enabled) {
-        hipLaunchKernelGGL(channel_taps_kernel, dim3(frames), dim3(64), 0, s, taps_in, coeff, alpha, (float2*)g, (float2*)H,
-                           n_taps, L, nfft, identity, offset, seed, (const int*)nullptr, n_taps, L, 1);
-        DCCN_LAUNCH_CHECK();
-    }
-    const FirPlan fp = fir_plan(frames * bx, bx, kChanPartials);
-    const int nfb = fp.blocks;
-    hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, (const int*)nullptr, L, frames, 0, tg, fp.ipb);
-    DCCN_LAUNCH_CHECK();
-    const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, nfb, total,
-                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    if (noise_power) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
-                           noise_power);
-        DCCN_LAUNCH_CHECK();
-    }
-    return DCCN_OK;
-}
-
-// ---- fused static-channel generator (datagen.h gen_static_frames_kernel) ----------------------------------------------
-static_assert(sizeof(dccn_gen_static) == 200 && sizeof(dccn_rx_buffers) == 208 && sizeof(dccn_eq_buffers) == 208 &&
-              sizeof(dccn_eq_monitor) == 88, "ctypes mirrors in dl_ofdm_amd/_lib.py");
-int dccn_gen_static_supported(int S, int K, int CP) {
-    return (S == 7 && K == 64 && CP == 16) ? 1 : 0;
-}
-int dccn_gen_static_partials(int frames) { return frames > 0 ? ceil_div(frames, kGenFramesPerBlock) : 0; }
-int dccn_gen_static_frames(const dccn_gen_static* g, dccn_stream_t stream) { return gen_static_launch(g, (hipStream_t)stream); }
-int dccn_gen_static_apply(const dccn_gen_static* g, float* x_out, float* noise_power, dccn_stream_t stream) {
-    if (!gen_static_ok(g) || !x_out || !aligned16(x_out)) return DCCN_ERR_INVALID_ARG;
-    const int T = g->S * (g->K + g->CP);
-    const long long n4 = (long long)g->frames * T * 2 / 4;
-    if (((long long)g->frames * T * 2) % 4 != 0) return DCCN_ERR_INVALID_ARG;
-    const int np = dccn_gen_static_partials(g->frames);
-    long long blocks = ceil_div_ll(n4, 256);
-    if (blocks > 4 * kCUs) blocks = 4 * kCUs;
-    DCCN_LAUNCH_CHAINS_Z(gen_static_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                         reinterpret_cast<const float4*>(g->y), reinterpret_cast<const float4*>(g->noise),
-                         (const double*)g->power_partial, np, (double)g->frames * (double)T, reinterpret_cast<float4*>(x_out), n4,
-                         (const double*)((noise_power && g->noise_partial) ? g->noise_partial : nullptr), np,
-                         (noise_power && g->noise_partial) ? noise_power : nullptr);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-size_t dccn_channel_doppler_awgn_workspace_size(int frames, int T, int L, int S) {
-    if (frames <= 0 || T <= 0 || L <= 0 || S <= 0) return 0;
-    return dccn_channel_awgn_workspace_size(frames, T, L * S);
-}
-int dccn_channel_doppler_awgn(const float* tx, const float* theta_in, const float* coeff, const float* alpha,
-                              int n_taps, int L, float Fd, float t_sym, int S, int n_sc, const float* snr_db,
-                              const float* noise_in, float* out, float* H, int nfft, float* noise_power, int frames,
-                              unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
-                              dccn_stream_t stream) {
-    if (!tx || !coeff || !alpha || !snr_db || !out || frames <= 0 || frames > 65535 || S <= 0 || S > 16 || n_sc <= 0 ||
-        L <= 0 || L > 64 || n_taps <= 0 || n_taps > 16 || (H && nfft <= 0))
-        return DCCN_ERR_INVALID_ARG;
-    const int T = S * n_sc;
-    if (!workspace || workspace_bytes < dccn_channel_doppler_awgn_workspace_size(frames, T, L, S))
-        return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    Carver c(workspace, workspace_bytes);
-    float* g = c.take<float>((size_t)frames * S * L * 2);
-    float* y = c.take<float>((size_t)frames * T * 2);
-    const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)kChanPartials);
-    double* npartial = c.take<double>((size_t)frames * bx);
-    hipLaunchKernelGGL(doppler_taps_kernel, dim3(frames), dim3(64), 0, s, theta_in, coeff, alpha, (float2*)g, (float2*)H,
-                       n_taps, L, nfft, S, Fd, t_sym, offset, seed, (const int*)nullptr, n_taps, S * L);
-    DCCN_LAUNCH_CHECK();
-    const int nfb = fir_blocks(frames * bx, kChanPartials);
-    hipLaunchKernelGGL(fir_doppler_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                       (float2*)y, partial, T, L, n_sc, n_taps, (const int*)nullptr, S * L, frames, 0);
-    DCCN_LAUNCH_CHECK();
-    const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, nfb, total,
-                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    if (noise_power) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
-                           noise_power);
-        DCCN_LAUNCH_CHECK();
-    }
-    return DCCN_OK;
-}
-
-size_t dccn_channel_groups_awgn_workspace_size(int frames, int T, int S) {
-    if (frames <= 0 || T <= 0 || S <= 0) return 0;
-    return dccn_channel_awgn_workspace_size(frames, T, 64 * S);
-}
-int dccn_channel_groups_awgn(const float* tx, const dccn_channel_group* groups, int n_groups, const float* taps_in,
-                             const float* theta_in, float t_sym, int S, int n_sc, const float* snr_db,
-                             const float* noise_in, float* out, float* H, int nfft, float* noise_power, int frames,
-                             unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
-                             dccn_stream_t stream) {
-    if (!tx || !groups || n_groups <= 0 || !snr_db || !out || frames <= 0 || frames > 65535 || S <= 0 || S > 16 ||
-        n_sc <= 0 || (H && nfft <= 0))
-        return DCCN_ERR_INVALID_ARG;
-    const int T = S * n_sc;
-    int covered = 0;
-    for (int i = 0; i < n_groups; ++i) {
-        const dccn_channel_group& g = groups[i];
-        if (g.n_frames < 0 || (g.n_frames > 0 && !g.frames && n_groups > 1)) return DCCN_ERR_INVALID_ARG;
-        if (!g.identity && (!g.coeff || !g.alpha || g.n_taps <= 0 || g.n_taps > 16 || g.L <= 0 || g.L > 64))
-            return DCCN_ERR_INVALID_ARG;
-        covered += g.n_frames;
-    }
-    if (covered != frames) return DCCN_ERR_INVALID_ARG;        // every frame belongs to exactly one group
-    if (!workspace || workspace_bytes < dccn_channel_groups_awgn_workspace_size(frames, T, S)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    Carver c(workspace, workspace_bytes);
-    const int gstride = 64 * S;
-    float* g = c.take<float>((size_t)frames * gstride * 2);
-    float* y = c.take<float>((size_t)frames * T * 2);
-    const int bx = chan_blocks_x(T);
-    double* partial = c.take<double>((size_t)kChanPartials);
-    double* npartial = c.take<double>((size_t)frames * bx);
-    int live = 0;
-    for (int i = 0; i < n_groups; ++i) live += groups[i].n_frames > 0 ? 1 : 0;
-    const int pcap = kChanPartials / (live > 0 ? live : 1);       // partial slots per group launch
-    int pbase = 0;
-    for (int i = 0; i < n_groups; ++i) {
-        const dccn_channel_group& q = groups[i];
-        if (q.n_frames == 0) continue;
-        if (q.identity || q.Fd <= 0.f) {
-            const int L = q.identity ? 1 : q.L;
-            TapGen tg;                          // (see dccn_channel_awgn)
-            memset(&tg, 0, sizeof(tg));
-            tg.enabled = (H == nullptr && taps_in == nullptr) ? 1 : 0;
-            tg.coeff = q.coeff; tg.alpha = q.alpha; tg.n_taps = q.n_taps; tg.identity = q.identity; tg.tap_stride = 16;
-            tg.offset = offset; tg.seed = seed;
-            if (!tg.enabled) {
-                hipLaunchKernelGGL(channel_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, taps_in, q.coeff, q.alpha, (float2*)g,
-                                   (float2*)H, q.n_taps, L, nfft, q.identity, offset, seed, q.frames, 16, gstride, S);
-                DCCN_LAUNCH_CHECK();
-            }
-            const FirPlan fp = fir_plan(q.n_frames * bx, bx, pcap);
-            const int nfb = fp.blocks;
-            hipLaunchKernelGGL(fir_same_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx, (const float2*)g,
-                               (float2*)y, partial, T, L, q.frames, gstride, q.n_frames, pbase, tg, fp.ipb);
-            DCCN_LAUNCH_CHECK();
-            pbase += nfb;
-        } else {
-            hipLaunchKernelGGL(doppler_taps_kernel, dim3(q.n_frames), dim3(64), 0, s, theta_in, q.coeff, q.alpha, (float2*)g,
-                               (float2*)H, q.n_taps, q.L, nfft, S, q.Fd, t_sym, offset, seed, q.frames, 16, gstride);
-            DCCN_LAUNCH_CHECK();
-            const int nfb = fir_blocks(q.n_frames * bx, pcap);
-            hipLaunchKernelGGL(fir_doppler_kernel, dim3(nfb), dim3(256), 0, s, (const float2*)tx,
-                               (const float2*)g, (float2*)y, partial, T, q.L, n_sc, q.n_taps, q.frames, gstride, q.n_frames, pbase);
-            DCCN_LAUNCH_CHECK();
-            pbase += nfb;
-        }
-    }
-    const double total = (double)frames * (double)T;
-    hipLaunchKernelGGL(awgn_kernel, dim3(bx, frames), dim3(256), 0, s, (const float2*)y, (const double*)partial, pbase, total,
-                       snr_db, noise_in, (float2*)out, noise_power ? npartial : nullptr, T, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    if (noise_power) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)npartial, frames * bx, total,
-                           noise_power);
-        DCCN_LAUNCH_CHECK();
-    }
-    return DCCN_OK;
-}
-
-// ---- classical pilot-aided receivers (classical.h) -----------------------------------------------------------------
-size_t dccn_classical_workspace_size(void) {
-    size_t o = 0;
-    o = carve_size(o, (size_t)kClassicalPartials * 4 * sizeof(double));
-    o = carve_size(o, (size_t)kClassicalPartials * sizeof(long long));
-    return align_up(o, 256);
-}
-static int classical_blocks(long long items) {
-    long long b = items < 2 * kCUs ? items : 2 * kCUs;
-    if (b > kClassicalPartials) b = kClassicalPartials;
-    return (int)(b < 1 ? 1 : b);
-}
-int dccn_dense_fwd_ld(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K, int N,
-                      dccn_stream_t stream) {
-    if (ldx < K) return DCCN_ERR_INVALID_ARG;
-    return dense_fwd_impl(x, w, bias, y, M, K, N, (hipStream_t)stream, ldx);
-}
-int dccn_classical_pilot_ls(const float* Y, const int* pil, float* gp, int n, int SK, int P, float pv_re, float pv_im,
-                            dccn_stream_t stream) {
-    if (!Y || !pil || !gp || n <= 0 || SK <= 0 || P <= 0 || (pv_re == 0.f && pv_im == 0.f)) return DCCN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(classical_pilot_ls_kernel, dim3((unsigned)ceil_div_ll((long long)n * P, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float2*)Y, pil, gp, n, SK, P, make_float2(pv_re, pv_im));
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_classical_gain(const float* Y, const float* H, const float* Gls, const int* pil, int n, int SK, int P, float pv_re,
-                        float pv_im, double* sums4, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!Y || !Gls || !pil || n <= 0 || SK <= 0 || P <= 0) return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
-    Carver c(workspace, workspace_bytes);
-    double* partial = c.take<double>((size_t)kClassicalPartials * 4);
-    const int nblk = classical_blocks(n);       // (dccn_classical_estimate modes 1 / 3 read these partials: dccn.h order contract)
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(classical_gain_kernel, dim3(nblk), dim3(256), 0, s, (const float2*)Y, (const float2*)H, Gls, pil, partial,
-                       n, SK, P, make_float2(pv_re, pv_im));
-    DCCN_LAUNCH_CHECK();
-    if (sums4) {
-        hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)nullptr, 0, (const double*)partial,
-                           nblk, (long long*)nullptr, sums4);
-        DCCN_LAUNCH_CHECK();
-    }
-    return DCCN_OK;
-}
-int dccn_classical_estimate(const float* Gls, const float* H, float* G, int n, int S, int K, int mode, float c_var,
-                            void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!Gls || !G || n <= 0 || S <= 0 || S > 32 || K <= 0 || mode < CE_LS || mode > CE_FRAME_MEAN) return DCCN_ERR_INVALID_ARG;
-    if ((mode == CE_LMMSE || mode == CE_PERFECT) && !H) return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
-    Carver c(workspace, workspace_bytes);
-    double* partial = c.take<double>((size_t)kClassicalPartials * 4);
-    hipLaunchKernelGGL(classical_estimate_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, Gls, (const float2*)H,
-                       (const double*)partial, classical_blocks(n), (float2*)G, n, S, K, mode, c_var);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_classical_detect(const float* Y, const float* G, const int* dat, const float* table, const int* labels,
-                          const int32_t* bits, int32_t* det, long long* errors, int n, int SK, int D, int m, int nbits,
-                          int g_row, int g_mod, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!Y || !G || !dat || !table || !labels || !bits || !errors || n <= 0 || SK <= 0 || D <= 0 || m <= 0 || nbits < 1 ||
-        nbits > 8 || g_row <= 0)
-        return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_classical_workspace_size()) return DCCN_ERR_WORKSPACE;
-    Carver c(workspace, workspace_bytes);
-    c.take<double>((size_t)kClassicalPartials * 4);
-    long long* ep = c.take<long long>((size_t)kClassicalPartials);
-    const int nblk = classical_blocks(ceil_div_ll((long long)n * D, 256));
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(classical_detect_kernel, dim3(nblk), dim3(256), 0, s, (const float2*)Y, (const float2*)G, dat,
-                       (const float2*)table, labels, bits, det, ep, n, SK, D, m, nbits, g_row, g_mod);
-    DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(classical_finish_kernel, dim3(1), dim3(256), 0, s, (const long long*)ep, nblk, (const double*)nullptr, 0,
-                       errors, (double*)nullptr);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-// ---- per-step monitors of the equaliser harness in one launch (equalizer.h eq_monitor_kernel) --------------------
-size_t dccn_eq_monitor_workspace_size(int B, int S, int K) {
-    if (B <= 0 || S <= 0 || K <= 0) return 0;
-    return align_up(256 + (size_t)eq_monitor_blocks(B, K) * sizeof(double), 256);
-}
-int dccn_eq_monitor_accumulate(const float* chest, const float* chan, int chan_per_symbol, int B, int S, int K,
-                               const dccn_metrics* metrics, const float* tx_power, const float* noise_power, float* acc5,
-                               float* rms_out, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!chest || !chan || B <= 0 || S <= 0 || K <= 0 || (acc5 && !metrics) || (!acc5 && !rms_out)) return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_eq_monitor_workspace_size(B, S, K)) return DCCN_ERR_WORKSPACE;
-    EqMonitorArgs a;
-    a.chest = chest; a.chan = chan; a.gt_per_symbol = chan_per_symbol ? 1 : 0; a.B = B; a.S = S; a.K = K;
-    a.metrics = metrics; a.tx_power = tx_power; a.noise_power = noise_power; a.acc = acc5; a.rms_out = rms_out;
-    a.counter = static_cast<unsigned*>(workspace);
-    a.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) + 256);
-    DCCN_LAUNCH_CHAINS_Z(eq_monitor_kernel, dim3(eq_monitor_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-// ---- the equaliser's pilot bottleneck as one launch per direction (eq_bottleneck.h) ---------------------------
-int dccn_eq_bottleneck_supported(int B, int SK2, int P) {
-    return ((P == 16 || P == 32) && B > 0 && SK2 >= 64 && (SK2 % 64) == 0) ? 1 : 0;
-}
-size_t dccn_eq_bottleneck_workspace_size(int B, int SK2, int P) {
-    if (!dccn_eq_bottleneck_supported(B, SK2, P)) return 0;
-    return align_up(eq_bottleneck_part_floats(B, SK2, P) * sizeof(float), 256);
-}
-int dccn_eq_bottleneck_fwd(const float* y, const float* W1, const float* b1, const float* W2, const float* b2, float* d1,
-                           float* d2, int B, int SK2, int P, dccn_stream_t stream) {
-    if (!y || !W1 || !W2 || !d1 || !d2 || !eq_bottleneck_ok(B, SK2, P, y, W1, W2) || !aligned16(d1)) return DCCN_ERR_INVALID_ARG;
-    const int q = eq_bottleneck_q(B, SK2);
-    auto kern = P == 32 ? eq_bottleneck_fwd_kernel<2> : eq_bottleneck_fwd_kernel<1>;
-    DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), ceil_div(B, 16)), dim3(256), 0, (hipStream_t)stream, y, W1, b1, W2, b2,
-                         d1, d2, B, SK2, q);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_eq_bottleneck_bwd(const float* dd2, const float* d1, const float* y, const float* W1, const float* W2,
-                           const float* dy_in, float* dy_out, float* dW1, float* db1, float* dW2, float* db2, int B, int SK2,
-                           int P, void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    if (!dd2 || !d1 || !y || !W1 || !W2 || !dy_in || !dy_out || !dW1 || !db1 || !dW2 || !db2 ||
-        !eq_bottleneck_ok(B, SK2, P, y, W1, W2) || !aligned16(dd2) || !aligned16(d1))
-        return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_eq_bottleneck_workspace_size(B, SK2, P)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const int tiles = ceil_div(B, 16), q = eq_bottleneck_q(B, SK2);
-    float* pw2 = static_cast<float*>(workspace);
-    float* pb2 = pw2 + (size_t)tiles * P * SK2;
-    float* pw1 = pb2 + (size_t)tiles * SK2;
-    float* pb1 = pw1 + (size_t)tiles * SK2 * P;
-    auto kern = P == 32 ? eq_bottleneck_bwd_kernel<2> : eq_bottleneck_bwd_kernel<1>;
-    EqRideArgs no_ride;
-    memset(&no_ride, 0, sizeof(no_ride));
-    dccn_adam_hparams no_hp;
-    memset(&no_hp, 0, sizeof(no_hp));
-    GenStaticArgs no_gen;
-    GenChainScalars no_gc;
-    memset(&no_gen, 0, sizeof(no_gen));
-    memset(&no_gc, 0, sizeof(no_gc));
-    DCCN_LAUNCH_CHAINS_Z(kern, dim3(ceil_div(SK2 / 16, q), tiles), dim3(256), 0, s, dd2, d1, y, W1, W2, dy_in, dy_out, pw2, pb2,
-                         pw1, pb1, B, SK2, q, tiles, no_ride, no_hp, 0, 0, no_gen, no_gc);
-    DCCN_LAUNCH_CHECK();
-    // (the fused equaliser step leaves these sums to its optimizer launch)
-    DCCN_TRY(launch_splitk_reduce2(pw2, tiles, (long long)P * SK2, dW2, (long long)P * SK2, pb2, (long long)SK2, db2, (long long)SK2, s));
-    DCCN_TRY(launch_splitk_reduce2(pw1, tiles, (long long)SK2 * P, dW1, (long long)SK2 * P, pb1, (long long)P, db1, (long long)P, s));
-    return DCCN_OK;
-}
-
-// ---- patch gather of the general-k complex convolutions -----------------------------------------------------
-static bool im2col_geom_ok(const Im2colGeom& g) {
-    return g.B > 0 && g.L > 0 && g.Wd > 0 && g.C > 0 && g.Lo > 0 && g.Wo > 0 && g.ntl > 0 && g.ntw > 0 && g.sL > 0 && g.sW > 0 &&
-           g.tl0 >= 0 && g.tw0 >= 0 && g.pl0 >= 0 && g.pw0 >= 0;
-}
-int dccn_cconv_im2col(const float* x, float* rows, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
-                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
-    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
-    if (!x || !rows || !im2col_geom_ok(g)) return DCCN_ERR_INVALID_ARG;
-    const long long n = (long long)B * Lo * Wo * ntl * ntw * C;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)x, (float2*)rows, g, n);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-// the same convolution without the patch tensor: the GEMM's A-loader gathers the taps (gemm_f32_mfma.h OP_KPATCH)
-int dccn_cconv_patch_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int F) {
-    // float4 pieces must not straddle cells: 2C multiple of 4; 32-bit element offsets into x; weights on the vector loaders
-    if (B <= 0 || L <= 0 || Wd <= 0 || C <= 0 || Lo <= 0 || Wo <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
-    if ((C % 2) != 0 || (F % 2) != 0) return 0;
-    if ((long long)B * L * Wd * C * 2 >= (1LL << 31) || (long long)B * Lo * Wo >= (1LL << 31)) return 0;
-    if ((long long)ntl * ntw * C * 2 * 2 * F * 4 >= (1LL << 31)) return 0;
-    return 1;
-}
-int dccn_cconv_patch_fwd(const float* x, const float* w, const float* bias, float* out, int B, int L, int Wd, int C, int Lo,
-                         int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
-                         dccn_stream_t stream) {
-    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
-    if (!x || !w || !out || !im2col_geom_ok(g) || !dccn_cconv_patch_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, F) ||
-        !aligned16(x) || !aligned16(w))
-        return DCCN_ERR_INVALID_ARG;
-    const int kin = ntl * ntw * C;
-    GemmParams p = gp_zero();                 // out[rows,2F] = patches[rows,2kin] . Weff[2kin,2F]
-    p.A = x; p.B = w; p.C = out; p.bias = bias; p.cbias = 1;
-    p.M = B * Lo * Wo; p.N = 2 * F; p.K = 2 * kin;
-    p.lda = 0; p.ldb = 2 * F; p.ldc = 2 * F;
-    p.klen = round_k(2 * kin);
-    p.cF = F;
-    p.vecA = 1; p.vecB = 1;
-    p.pg.L = L; p.pg.Wd = Wd; p.pg.c2 = 2 * C; p.pg.Lo = Lo; p.pg.Wo = Wo; p.pg.ntl = ntl; p.pg.ntw = ntw;
-    p.pg.sL = sL; p.pg.sW = sW; p.pg.l0 = tl0 - pl0; p.pg.w0 = tw0 - pw0;
-    return launch_gemm<OP_KPATCH, OP_CCONV_W, 0, TAG_CCONV_FWD>(p, 1, (hipStream_t)stream);
-}
-// ---- the backward of the same convolutions without the patch tensor ---------------------------------------------
-// weight gradient: dWeff[(ti,tj,c,iq), n] = sum over output positions of patch(x)^T . dout -- the k-major weight-gradient
-// GEMM (gemm_kmajor.h) with its A rows gathered from x itself (APATCH); split-K slabs folded like every C-Conv's
-int dccn_cconv_patch_bwd_supported(int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int sL, int sW, int F) {
-    if (!dccn_cconv_patch_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, F)) return 0;
-    if (sL <= 0 || sW <= 0) return 0;
-    if ((long long)B * Lo * Wo * F * 2 >= (1LL << 31)) return 0;          // 32-bit element offsets into dout
-    int mode = 1 | 2;                  // bit 0: weight gradient; bit 1: input gradient as an implicit GEMM (any stride, round 6)
-    // bit 2: ... and it is expected to beat GEMM + col2im.  Cost per INPUT position in units of 16 tile columns x 2F deep rows:
-    //   few channels (2C <= 32, cconv_dx_narrow.h): ceil(2C/16) columns x the taps of the position's stride phase (ntl*ntw / (sL*sW));
-    //   otherwise (64-wide tiles, inverse-stride gather): 4 ceil(2C/64) columns x ALL ntl*ntw taps (zeros where the stride skips);
-    //   GEMM + col2im: 4 ceil(2 kin/64) columns per OUTPUT position (sL*sW times fewer) plus the [rows, kin, 2] round trip and the
-    //   scatter launch -- which is why the implicit route may cost up to 3x (narrow) / 2x (wide) the other's tile columns.
-    const long long taps = (long long)ntl * ntw, ss = (long long)sL * sW, col = 4LL * ceil_div(2 * ntl * ntw * C, 64);
-    if (cconv_dx_narrow_ok(C, F, sL, sW)) {
-        if ((long long)ceil_div(2 * C, 16) * taps <= 3 * col) mode |= 4;          // (both sides per input position: x ss cancels)
-    } else if (4LL * ceil_div(2 * C, 64) * taps * ss * ss <= 2 * col) {
-        mode |= 4;
-    }
-    return mode;
-}
-size_t dccn_cconv_patch_bwd_w_workspace_size(int B, int Lo, int Wo, int C, int ntl, int ntw, int F) {
-    if (B <= 0 || Lo <= 0 || Wo <= 0 || C <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
-    return cconv_bw_ws_bytes(B * Lo * Wo, ntl * ntw * C, F);
-}
-int dccn_cconv_patch_bwd_w(const float* x, const float* dout, float* dw, float* dbias, int B, int L, int Wd, int C, int Lo,
-                           int Wo, int ntl, int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F,
-                           void* workspace, size_t workspace_bytes, dccn_stream_t stream) {
-    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
-    if (!x || !dout || !dw || !im2col_geom_ok(g) || !aligned16(x) || !aligned16(dout) ||
-        !(dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F) & 1))
-        return DCCN_ERR_INVALID_ARG;
-    const int rows = B * Lo * Wo, kin = ntl * ntw * C;
-    if (!workspace || workspace_bytes < cconv_bw_ws_bytes(rows, kin, F)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const SplitPlan sp = plan_splitk(2 * kin, 2 * F, rows);
-    Carver c(workspace, workspace_bytes);
-    float* slabs = c.take<float>((size_t)sp.splits * 4 * kin * F);
-    float* cs = c.take<float>((size_t)sp.splits * 2 * F);
-    GemmParams p = gp_zero();                 // dWeff[2kin,2F] = patches(x)[rows,2kin]^T . dout[rows,2F]
-    p.A = x; p.B = dout; p.C = slabs; p.colsum = cs;
-    p.M = 2 * kin; p.N = 2 * F; p.K = rows;
-    p.lda = 0; p.ldb = 2 * F; p.ldc = 2 * F;
-    p.klen = sp.klen;
-    p.slab = (long long)4 * kin * F;
-    p.vecA = 1; p.vecB = 1;
-    p.pg.L = L; p.pg.Wd = Wd; p.pg.c2 = 2 * C; p.pg.Lo = Lo; p.pg.Wo = Wo; p.pg.ntl = ntl; p.pg.ntw = ntw;
-    p.pg.sL = sL; p.pg.sW = sW; p.pg.l0 = tl0 - pl0; p.pg.w0 = tw0 - pw0;
-    patch_div_magic(Lo * Wo, p.pg.per_mul, p.pg.per_shift);
-    patch_div_magic(Wo, p.pg.wo_mul, p.pg.wo_shift);
-    if (!kmajor_ok(p)) return DCCN_ERR_INVALID_ARG;
-    DCCN_TRY((launch_kmajor<1, TAG_CCONV_BWD_W, true>(p, sp.splits, s)));
-    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
-    hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, slabs, sp.splits, p.slab, cs, dw, dbias, kin, F);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-// input gradient: dx[b,l,w,(c,iq)] = sum over taps of dout[b, (l-l0-ti)/sL, (w-w0-tj)/sW, :] . Weff[(ti,tj,c,iq), :] -- a
-// convolution of dout with the tap-flipped transposed weights, i.e. the SAME implicit GEMM with dout as the gathered operand
-// (geometry: rows = input positions, taps t' = nt-1-t, origin -(l0+ntl-1)) and Bt[(c,iq)][(ti',tj',n)] as a plain k-contiguous
-// operand built from w by the little kernel below (4 kin F floats).  No [rows, kin, 2] gradient-of-patches tensor, no col2im.
-// Strides (round 6): a tap contributes where its fine position is a multiple of the forward stride -- the loader's
-// inverse-stride gather (PatchGeom::isL / isW) reads dout there and zeros elsewhere.
-__global__ __launch_bounds__(256) void cconv_flip_wt_kernel(const float* __restrict__ w, float* __restrict__ bt, int C, int ntl,
-                                                            int ntw, int F) {
-    const long long K = (long long)ntl * ntw * 2 * F, total = 2LL * C * K;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i / K);
-    const int k = (int)(i - (long long)j * K);
-    const int tp = k / (2 * F), nn = k - tp * 2 * F;
-    const int tip = tp / ntw, tjp = tp - tip * ntw;
-    const int n = (((ntl - 1 - tip) * ntw) + (ntw - 1 - tjp)) * C + (j >> 1);
-    const int iq = j & 1, f = nn >> 1, oq = nn & 1;
-    const float wa = w[(size_t)n * 2 * F + f], wb = w[(size_t)n * 2 * F + F + f];
-    // Weff[2n, 2f] = Wa, [2n, 2f+1] = Wb, [2n+1, 2f] = -Wb, [2n+1, 2f+1] = -Wa (gemm_f32_mfma.h OP_CCONV_W)
-    bt[i] = iq == 0 ? (oq == 0 ? wa : wb) : (oq == 0 ? -wb : -wa);
-}
-size_t dccn_cconv_patch_bwd_x_workspace_size(int C, int ntl, int ntw, int F) {
-    if (C <= 0 || ntl <= 0 || ntw <= 0 || F <= 0) return 0;
-    return align_up((size_t)4 * C * ntl * ntw * F * sizeof(float), 256);
-}
-int dccn_cconv_patch_bwd_x(const float* dout, const float* w, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl,
-                           int ntw, int tl0, int tw0, int sL, int sW, int pl0, int pw0, int F, void* workspace,
-                           size_t workspace_bytes, dccn_stream_t stream) {
-    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
-    if (!dout || !w || !dx || !im2col_geom_ok(g) || !aligned16(dout) || !aligned16(dx) ||
-        !(dccn_cconv_patch_bwd_supported(B, L, Wd, C, Lo, Wo, ntl, ntw, sL, sW, F) & 2))
-        return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_cconv_patch_bwd_x_workspace_size(C, ntl, ntw, F) || !aligned16(workspace))
-        return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    float* bt = reinterpret_cast<float*>(workspace);
-    const long long total = 4LL * C * ntl * ntw * F;
-    hipLaunchKernelGGL(cconv_flip_wt_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, w, bt, C, ntl, ntw, F);
-    DCCN_LAUNCH_CHECK();
-    if (cconv_dx_narrow_ok(C, F, sL, sW)) {   // few channels: 16-column tiles, strides by phase (cconv_dx_narrow.h)
-        DxNarrowArgs a;
-        memset(&a, 0, sizeof(a));
-        a.dout = dout; a.bt = bt; a.dx = dx;
-        a.B = B; a.L = L; a.Wd = Wd; a.C2 = 2 * C; a.Lo = Lo; a.Wo = Wo; a.ntl = ntl; a.ntw = ntw; a.F2 = 2 * F;
-        a.l0 = -(tl0 - pl0) - (ntl - 1); a.w0 = -(tw0 - pw0) - (ntw - 1);
-        a.sL = sL; a.sW = sW;
-        return launch_cconv_dx_narrow(a, s);
-    }
-    GemmParams p = gp_zero();                 // dx[B*L*Wd, 2C] = patches'(dout)[., ntl*ntw*2F] . Bt^T
-    p.A = dout; p.B = bt; p.C = dx;
-    p.M = B * L * Wd; p.N = 2 * C; p.K = ntl * ntw * 2 * F;
-    p.lda = 0; p.ldb = p.K; p.ldc = 2 * C;
-    p.klen = round_k(p.K);
-    p.vecA = 1; p.vecB = 1;
-    p.pg.L = Lo; p.pg.Wd = Wo; p.pg.c2 = 2 * F; p.pg.Lo = L; p.pg.Wo = Wd; p.pg.ntl = ntl; p.pg.ntw = ntw;
-    p.pg.sL = 1; p.pg.sW = 1; p.pg.l0 = -(tl0 - pl0) - (ntl - 1); p.pg.w0 = -(tw0 - pw0) - (ntw - 1);
-    p.pg.isL = sL; p.pg.isW = sW;
-    patch_div_magic(sL, p.pg.il_mul, p.pg.il_shift);
-    patch_div_magic(sW, p.pg.iw_mul, p.pg.iw_shift);
-    return launch_gemm<OP_KPATCH, OP_KCONTIG, 0, TAG_CCONV_BWD_X>(p, 1, s);
-}
-// ---- few-channel 1-D C-Conv: input, weight and bias gradient in one pass over dout (cconv1d_bwd.h) -------------------------
-constexpr int kConv1dMaxBlocks = 1024;
-static int conv1d_bwd_pl(int ntl, int sL) { return 62 * sL - ntl + 2; }          // positions per chunk: its rows fit 64 (cconv1d_bwd.h)
-int dccn_cconv1d_bwd_supported(int B, int L, int C, int Lo, int ntl, int sL, int F) {
-    if (B <= 0 || L <= 0 || C <= 0 || Lo <= 0 || ntl <= 0 || sL <= 0 || F <= 0) return 0;
-    if ((C % 2) != 0 || (F != 32 && F != 64) || 2 * ntl * C > 30 || conv1d_bwd_pl(ntl, sL) < 1) return 0;
-    if ((long long)B * L * C * 2 >= (1LL << 31) || (long long)B * Lo * F * 2 >= (1LL << 31)) return 0;
-    return 1;
-}
-size_t dccn_cconv1d_bwd_workspace_size(int F) {
-    if (F <= 0) return 0;
-    size_t o = 0;
-    o = carve_size(o, (size_t)kConv1dMaxBlocks * 32 * 2 * F * sizeof(float));
-    o = carve_size(o, (size_t)kConv1dMaxBlocks * 2 * F * sizeof(float));
-    return align_up(o, 256);
-}
-int dccn_cconv1d_bwd(const float* x, const float* dout, const float* w, float* dx, float* dw, float* dbias, int B, int L, int C,
-                     int Lo, int ntl, int tl0, int sL, int pl0, int F, void* workspace, size_t workspace_bytes,
-                     dccn_stream_t stream) {
-    if (!x || !dout || !w || !dx || !dw || !dccn_cconv1d_bwd_supported(B, L, C, Lo, ntl, sL, F) || !aligned16(dout) || !aligned16(w))
-        return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_cconv1d_bwd_workspace_size(F)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    Carver c(workspace, workspace_bytes);
-    Conv1dBwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.dout = dout; a.w = w; a.dx = dx;
-    a.slabs = c.take<float>((size_t)kConv1dMaxBlocks * 32 * 2 * F);
-    a.colsum = c.take<float>((size_t)kConv1dMaxBlocks * 2 * F);
-    a.B = B; a.L = L; a.C2 = 2 * C; a.Lo = Lo; a.nt = ntl; a.F2 = 2 * F; a.NC = 2 * ntl * C;
-    a.o = tl0 - pl0; a.s = sL;
-    a.PL = conv1d_bwd_pl(ntl, sL);
-    a.nch = ceil_div(L, a.PL);
-    const long long total = (long long)B * a.nch;
-    int grid = 2 * kCUs;
-    if (grid > kConv1dMaxBlocks) grid = kConv1dMaxBlocks;
-    if (grid > total) grid = (int)total;
-    DCCN_NO_CHAINS();
-    if (F == 64) {
-        auto kern = cconv1d_bwd_fused_kernel<128>;
-        DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), conv1d_bwd_smem_bytes<128>()));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), conv1d_bwd_smem_bytes<128>(), s, a);
-    } else {
-        auto kern = cconv1d_bwd_fused_kernel<64>;
-        DCCN_TRY(set_max_dynamic_smem(reinterpret_cast<const void*>(kern), conv1d_bwd_smem_bytes<64>()));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), conv1d_bwd_smem_bytes<64>(), s, a);
-    }
-    DCCN_LAUNCH_CHECK();
-    const int kin = ntl * C;
-    const int fold_blocks = ceil_div(kin * F + F, kRedLanes);
-    hipLaunchKernelGGL(cconv_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, a.slabs, grid, (long long)32 * 2 * F, a.colsum, dw, dbias,
-                       kin, F);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-int dccn_cconv_col2im(const float* drows, float* dx, int B, int L, int Wd, int C, int Lo, int Wo, int ntl, int ntw, int tl0,
-                      int tw0, int sL, int sW, int pl0, int pw0, dccn_stream_t stream) {
-    const Im2colGeom g{B, L, Wd, C, Lo, Wo, ntl, ntw, tl0, tw0, sL, sW, pl0, pw0};
-    if (!drows || !dx || !im2col_geom_ok(g)) return DCCN_ERR_INVALID_ARG;
-    const long long n = (long long)B * L * Wd * C;
-    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)drows, (float2*)dx, g, n);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-// ---- in-graph AWGN monitor branch (`iq_tx:0`, `iq_rx:0`, `noise_power:0`) -----------------------------------
-size_t dccn_ingraph_awgn_workspace_size(int frames, int pairs_per_frame) {
-    if (frames <= 0 || pairs_per_frame <= 0) return 0;
-    size_t o = 0;
-    o = carve_size(o, (size_t)frames * pairs_per_frame * 2 * sizeof(float));                   // clipped
-    o = carve_size(o, (size_t)frames * pairs_per_frame * 2 * sizeof(float));                   // re-normalised
-    o = carve_size(o, norm_ws_bytes(frames, 2 * pairs_per_frame));
-    o = carve_size(o, dccn_clip_power_workspace_size((long long)frames * pairs_per_frame));
-    o = carve_size(o, (size_t)frames * ceil_div(pairs_per_frame, 256) * sizeof(double));
-    o = carve_size(o, 256);
-    return align_up(o, 256);
-}
-int dccn_ingraph_awgn(const float* x_norm, const float* snr_db, float* tx_signal, uint16_t* iq_tx_f16,
-                      uint16_t* iq_rx_f16, float* noise_power, int frames, int pairs_per_frame, float peak,
-                      unsigned long long seed, unsigned offset, void* workspace, size_t workspace_bytes,
-                      dccn_stream_t stream) {
-    if (!x_norm || !snr_db || !noise_power || frames <= 0 || pairs_per_frame <= 0) return DCCN_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < dccn_ingraph_awgn_workspace_size(frames, pairs_per_frame)) return DCCN_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const long long n_pairs = (long long)frames * pairs_per_frame;
-    Carver c(workspace, workspace_bytes);
-    float* clipped = c.take<float>((size_t)n_pairs * 2);
-    float* xn = c.take<float>((size_t)n_pairs * 2);
-    const size_t nws = norm_ws_bytes(frames, 2 * pairs_per_frame);
-    void* ws_norm = c.take<char>(nws);
-    const size_t cws = dccn_clip_power_workspace_size(n_pairs);
-    void* ws_clip = c.take<char>(cws);
-    const int gx = ceil_div(pairs_per_frame, 256);
-    double* partial = c.take<double>((size_t)frames * gx);
-    float* scratch_pw = c.take<float>(64);            // complex_clip's power output is `tx_power:0`, served elsewhere
-    float* clip_dst = tx_signal ? tx_signal : clipped;
-    DCCN_TRY(dccn_clip_power(x_norm, clip_dst, scratch_pw, n_pairs, peak, ws_clip, cws, stream));
-    dccn_adam_hparams hp;
-    memset(&hp, 0, sizeof(hp));
-    DCCN_TRY(norm_impl(clip_dst, xn, nullptr, nullptr, false, nullptr, frames, 2 * pairs_per_frame, 1e-8f, peak, nullptr, hp,
-                       ws_norm, nws, s));
-    hipLaunchKernelGGL(ingraph_awgn_kernel, dim3(gx, frames), dim3(256), 0, s, (const float2*)clip_dst, (const float2*)xn,
-                       snr_db, reinterpret_cast<__half2*>(iq_tx_f16), reinterpret_cast<__half2*>(iq_rx_f16), partial,
-                       pairs_per_frame, offset, seed);
-    DCCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, frames * gx, (double)n_pairs,
-                       noise_power);
-    DCCN_LAUNCH_CHECK();
-    return DCCN_OK;
-}
-
-// ---- CRC32C (host) --------------------------------------------------------------------------------------
-static uint32_t g_crc32c_table[8][256];
-static bool g_crc32c_ready = false;
-static void crc32c_init() {
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
-        g_crc32c_table[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-        for (int t = 1; t < 8; ++t)
-            g_crc32c_table[t][i] = (g_crc32c_table[t - 1][i] >> 8) ^ g_crc32c_table[0][g_crc32c_table[t - 1][i] & 0xffu];
-    g_crc32c_ready = true;
-}
-uint32_t dccn_crc32c(uint32_t crc, const void* data, size_t n) {
-    if (!g_crc32c_ready) crc32c_init();
-    const unsigned char* p = static_cast<const unsigned char*>(data);
-    uint32_t c = crc ^ 0xffffffffu;
-    while (n >= 8) {                                     // slicing-by-8
-        uint32_t lo, hi;
-        memcpy(&lo, p, 4);
-        memcpy(&hi, p + 4, 4);
-        lo ^= c;
-        c = g_crc32c_table[7][lo & 0xffu] ^ g_crc32c_table[6][(lo >> 8) & 0xffu] ^ g_crc32c_table[5][(lo >> 16) & 0xffu] ^
-            g_crc32c_table[4][lo >> 24] ^ g_crc32c_table[3][hi & 0xffu] ^ g_crc32c_table[2][(hi >> 8) & 0xffu] ^
-            g_crc32c_table[1][(hi >> 16) & 0xffu] ^ g_crc32c_table[0][hi >> 24];
-        p += 8;
-        n -= 8;
-    }
-    while (n--) c = g_crc32c_table[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
-    return c ^ 0xffffffffu;
 }
 
 }  // extern "C"

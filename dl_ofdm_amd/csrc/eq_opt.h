@@ -292,7 +292,7 @@ __device__ __forceinline__ void eq_ride_body(const EqRideArgs& r, const dccn_ada
     else eq_opt_sum(p, J, k, bx - J.block0);
 }
 
-__global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a0, const dccn_adam_hparams hp, const ChainOffs co) {
+static __global__ __launch_bounds__(256) void eq_opt_kernel(const EqOptArgs a0, const dccn_adam_hparams hp, const ChainOffs co) {
     const int chain = (int)blockIdx.z;                               // chain groups (common.h)
     const long long coff = co.off[chain];
     int j = 0;

@@ -2,7 +2,7 @@
 // pre-planned launch sequence (capturable into a hipGraph) over flat arenas --
 //   R0 normalise -> equalizer_ofdm (model.py:349-478) -> frozen basic receiver -> loss/BER
 //   -> backward to the Equalizer/* variables only -> TF Adam on the equaliser arena.
-// Included inside namespace dccn of dccn_abi.hip, after the *_impl helpers it is built from.
+// Included inside namespace dccn of dccn_abi_eq.hip, behind abi_impl.h (the operators' *_impl launch planning it is built from).
 // FLAGS.cp=False (model.py:364-366, 1236-1240): the equaliser's first dense layer and the receiver's C-Conv read
 // the K-sample window behind the cyclic prefix of [.., n_sc, 2] rows -- a column window of the same buffers.
 

@@ -50,14 +50,14 @@ __device__ __forceinline__ void layer_norm_fwd_body(const float* __restrict__ x,
         if (inv_out) inv_out[row] = inv;
     }
 }
-__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+static __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              float* __restrict__ mean_out,
                                                              float* __restrict__ inv_out, int cols, float eps) {
     layer_norm_fwd_body(x, y, mean_out, inv_out, cols, eps, (int)blockIdx.x);
 }
 
 // dx = inv * (dy - mean(dy) - y * mean(dy*y))   (y = normalised output)
-__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+static __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ inv, float* __restrict__ dx,
                                                              int cols) {
     __shared__ float sh[4];
@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __rest
 }
 
 // activation=tf.nn.tanh of the channel-estimate dense layer (model.py:421-426)
-__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+static __global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = tanhf(x[i]);
 }
-__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+static __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ dx, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -106,7 +106,7 @@ __device__ __forceinline__ void equalize_fwd_body(const float2* __restrict__ y, 
         if (corr) corr[i] = make_float2(er * er - ei * (-ei), er * (-ei) + ei * er);
     }
 }
-__global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+static __global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
                                                            float2* __restrict__ eq, float2* __restrict__ corr,
                                                            long long n) {
     equalize_fwd_body(y, h, eq, corr, n, (int)blockIdx.x, (int)gridDim.x);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void equalize_fwd_kernel(const float2* __restr
 
 // real-valued backward of the pair above; d_corr may be null.  corr = (er^2+ei^2, 0), so only its
 // real cotangent reaches eq.
-__global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* y_, const float2* h_, const float2* d_eq_, const float2* d_corr_,
+static __global__ __launch_bounds__(256) void equalize_bwd_kernel(const float2* y_, const float2* h_, const float2* d_eq_, const float2* d_corr_,
                                                            float2* dy_, float2* dh_, long long n, const ChainOffs co) {
     const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
     const float2* __restrict__ y = chain_at(y_, coff);
@@ -178,12 +178,12 @@ __device__ __forceinline__ void pilot_snr_body(const float2* __restrict__ eq, co
     const float ratio = fminf(fmaxf(mean / var, 0.001f), 10000.0f);
     if (lane == 0) snr_db[frame] = logf(ratio) / logf(10.0f);
 }
-__global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict__ eq, const int* __restrict__ carriers,
+static __global__ __launch_bounds__(64) void pilot_snr_kernel(const float2* __restrict__ eq, const int* __restrict__ carriers,
                                                        float* __restrict__ snr_db, int S, int K, int P) {
     pilot_snr_body<false>(eq, nullptr, nullptr, carriers, snr_db, S, K, P, (int)blockIdx.x, (int)threadIdx.x);
 }
 // equalise + the pilot monitor in one launch: blocks [0, eq_blocks) equalise, each later block serves four frames
-__global__ __launch_bounds__(256) void equalize_fwd_snr_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+static __global__ __launch_bounds__(256) void equalize_fwd_snr_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
                                                                float2* __restrict__ eq, float2* __restrict__ corr,
                                                                long long n, int eq_blocks, const int* __restrict__ carriers,
                                                                float* __restrict__ snr_db, int frames, int S, int K, int P) {
@@ -281,7 +281,7 @@ __device__ __forceinline__ void eq_monitor_body(const EqMonitorArgs& a, const un
     }
     *a.counter = 0u;
 }
-__global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0, const ChainOffs co) {
+static __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0, const ChainOffs co) {
     const EqMonitorArgs a = a0.at_chain(co.off[blockIdx.z]);
     eq_monitor_body(a, blockIdx.x, gridDim.x, true);
 }
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void eq_monitor_kernel(const EqMonitorArgs a0,
 // (k' = k - win, rows of the cyclic prefix are zero when cp = 0) and bf = bd + sum_s cb . Wd_s.  The receiver's weights do
 // not change while the equaliser trains, so Mf is built once; the step then runs ONE few-row GEMM where it ran the
 // C-Conv and the dense layer, and its transpose on the way back (dout = dz . Mf^T).  Block r = row of Mf, block `rows` = bf.
-__global__ __launch_bounds__(256) void eq_rx_fold_kernel(const float* __restrict__ cw, const float* __restrict__ cb,
+static __global__ __launch_bounds__(256) void eq_rx_fold_kernel(const float* __restrict__ cw, const float* __restrict__ cb,
                                                          const float* __restrict__ wd, const float* __restrict__ bd,
                                                          float* __restrict__ Mf, float* __restrict__ bf, int S, int N2,
                                                          int win, int kin, int F, int dN) {
@@ -351,7 +351,7 @@ __device__ __forceinline__ void cconv2d_same_expand_body(const float* __restrict
         }
     }
 }
-__global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* __restrict__ w,
+static __global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* __restrict__ w,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ T, float* __restrict__ bias_eff,
                                                                   int L, int W, int kL, int kW) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void cconv2d_same_expand_kernel(const float* _
 // the equaliser step's second launch: layer_norm of the normalised frames (one block per frame) and, in the blocks behind
 // them, the expansion of the smoothing kernel -- two independent 5 us launches as one
 // adam != nullptr: the optimizer's per-step bookkeeping rides here (steps whose normalisation the previous step already ran)
-__global__ __launch_bounds__(256) void eq_prep_kernel(const float* x_, float* y_, int frames, int cols, float eps, const float* w_,
+static __global__ __launch_bounds__(256) void eq_prep_kernel(const float* x_, float* y_, int frames, int cols, float eps, const float* w_,
                                                       const float* bias_, float* T_, float* bias_eff_, int L, int W,
                                                       dccn_adam_state* adam_, dccn_adam_hparams hp, const ChainOffs co) {
     const long long coff = co.off[blockIdx.z];                     // chain groups (common.h)
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void eq_prep_kernel(const float* x_, float* y_
 
 // transpose of the expansion: one wave per tap gathers its diagonal of dT; wave kL*kW reduces the
 // bias cotangent.
-__global__ __launch_bounds__(64) void cconv2d_same_reduce_kernel(const float* __restrict__ dT,
+static __global__ __launch_bounds__(64) void cconv2d_same_reduce_kernel(const float* __restrict__ dT,
                                                                  const float* __restrict__ dbias_eff,
                                                                  float* __restrict__ dw, float* __restrict__ dbias,
                                                                  int L, int W, int kL, int kW) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void cconv2d_same_reduce_kernel(const float* __
 
 // ---- glue of the fused equaliser step ------------------------------------------------------------------
 // tf.concat([equalized, corr_re], axis=-1) (model.py:456): two IQ-pair streams -> [n, 4]
-__global__ __launch_bounds__(256) void concat_pairs_kernel(const float2* __restrict__ a, const float2* __restrict__ b,
+static __global__ __launch_bounds__(256) void concat_pairs_kernel(const float2* __restrict__ a, const float2* __restrict__ b,
                                                            float4* __restrict__ out, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void concat_pairs_kernel(const float2* __restr
         out[i] = make_float4(u.x, u.y, v.x, v.y);
     }
 }
-__global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restrict__ in, float2* __restrict__ a,
+static __global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restrict__ in, float2* __restrict__ a,
                                                           float2* __restrict__ b, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -440,12 +440,12 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float4* __restri
     }
 }
 // plain zero fill (a kernel rather than hipMemsetAsync so that graph capture sees an ordinary launch)
-__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ a, long long n) {
+static __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ a, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a[i] = 0.f;
 }
 // a += b  (the two gradient paths into the frequency-domain input, model.py:383 and :392)
-__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b,
+static __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b,
                                                           long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a[i] += b[i];

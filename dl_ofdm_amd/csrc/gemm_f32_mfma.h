@@ -352,7 +352,7 @@ __device__ __forceinline__ int xcd_tile(const int L, const int T) {
 }
 // tuning knob (dccn_set_tuning key 7): single-tile launches for short k ranges.  A call that runs under a tuning snapshot
 // (dccn_abi.hip TuneScope: the plan's own table, or the globals as they stood when the call began) reads the snapshot's value
-static std::atomic<int> g_whole_k_global{1};
+extern std::atomic<int> g_whole_k_global;      // (dccn_abi.hip)
 extern thread_local int tl_whole_k;           // -1: no snapshot in force
 struct WholeK {
     operator int() const { return tl_whole_k >= 0 ? tl_whole_k : g_whole_k_global.load(std::memory_order_relaxed); }
@@ -935,7 +935,7 @@ __device__ __forceinline__ void cconv_fold_body(const float* __restrict__ partia
     }
 }
 
-__global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict__ partial, int splits,
+static __global__ __launch_bounds__(256) void cconv_fold_kernel(const float* __restrict__ partial, int splits,
                                                          long long slab, const float* __restrict__ colsum,
                                                          float* __restrict__ dw, float* __restrict__ dbias,
                                                          int kin, int F, int tilew = 0) {

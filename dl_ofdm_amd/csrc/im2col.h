@@ -16,7 +16,7 @@ struct Im2colGeom {
     int sL, sW, pl0, pw0;     // strides, padding before
 };
 
-__global__ __launch_bounds__(256) void im2col_kernel(const float2* __restrict__ x, float2* __restrict__ rows, Im2colGeom g,
+static __global__ __launch_bounds__(256) void im2col_kernel(const float2* __restrict__ x, float2* __restrict__ rows, Im2colGeom g,
                                                      long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float2* __restrict__ 
     rows[i] = v;
 }
 
-__global__ __launch_bounds__(256) void col2im_kernel(const float2* __restrict__ drows, float2* __restrict__ dx, Im2colGeom g,
+static __global__ __launch_bounds__(256) void col2im_kernel(const float2* __restrict__ drows, float2* __restrict__ dx, Im2colGeom g,
                                                      long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

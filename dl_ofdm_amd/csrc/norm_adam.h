@@ -28,7 +28,7 @@ __device__ __forceinline__ float adam_alpha(const dccn_adam_state* st, const dcc
 // In the fused training step the first thread of the first block also does the optimizer's
 // per-step bookkeeping (it runs long before the Adam kernel of this step and after the one of the
 // previous step): alpha for THIS step from the current global_step / beta powers, then advance them.
-__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int batch, int cols,
+static __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int batch, int cols,
                                                       double* __restrict__ partial,
                                                       dccn_adam_state* __restrict__ adam, dccn_adam_hparams hp) {
     __shared__ double red[4][64][8];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
 // shift = -mean*inv), then y = (x*inv + shift)/sqrt(2)   (+ R8: per-block partial sums of the clipped power)
 // grid (ceil(cols/4/64), ceil(batch/kNormRowsPerBlock)), block (64,4)
 // power_partial[blockIdx.y*gridDim.x + blockIdx.x] = sum over the block of |clip(y)|^2 (fp64)
-__global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ x, float* __restrict__ y,
+static __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const double* __restrict__ partial, int batch, int cols,
                                                         float eps, float peak, double* __restrict__ power_partial,
                                                         float* __restrict__ mean_out, float* __restrict__ var_out) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(128 * CG) void norm_fused_kernel(const float* x_, f
 }
 
 // out[0] = (float)(sum(partial[0..n)) / denom)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double denom,
+static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double denom,
                                                            float* __restrict__ out) {
     __shared__ double red[4];
     double s = 0.0;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 }
 
 // ---- R8 standalone: clip + power over [n_pairs,2] ----------------------------------------
-__global__ __launch_bounds__(256) void clip_power_kernel(const float* __restrict__ x, float* __restrict__ y,
+static __global__ __launch_bounds__(256) void clip_power_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          long long n_pairs, float peak,
                                                          double* __restrict__ partial) {
     __shared__ double red[4];
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void clip_power_kernel(const float* __restrict
 // ---- R7: TF Adam -----------------------------------------------------------------------
 // prep: alpha = lr*sqrt(1-b2p)/(1-b1p) with lr = lr0*rate^floor(step/decay_steps); then the
 // state advances (beta powers *= beta, global_step += 1) -- exactly one thread.
-__global__ void adam_prep_kernel(dccn_adam_state* __restrict__ st, dccn_adam_hparams hp) {
+static __global__ void adam_prep_kernel(dccn_adam_state* __restrict__ st, dccn_adam_hparams hp) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float step = st->global_step;
         const float lr = hp.lr0 * powf(hp.decay_rate, floorf(step / hp.decay_steps));
@@ -466,7 +466,7 @@ __global__ void adam_prep_kernel(dccn_adam_state* __restrict__ st, dccn_adam_hpa
 
 // m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); p -= m*alpha/(sqrt(v)+eps)   (TF ApplyAdam form)
 // g = grad + gate*reg_coef*param
-__global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ param, const float* __restrict__ grad,
+static __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          const float* __restrict__ reg_coef,
                                                          const float* __restrict__ reg_gate,

@@ -776,7 +776,7 @@ __device__ __forceinline__ void demod_tail_finalize_body(const TailFinalizeArgs&
     }
 }
 
-__global__ __launch_bounds__(256) void demod_tail_finalize_kernel(TailFinalizeArgs a) {
+static __global__ __launch_bounds__(256) void demod_tail_finalize_kernel(TailFinalizeArgs a) {
     demod_tail_finalize_body(a, blockIdx.x);
 }
 

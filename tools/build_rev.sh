@@ -7,6 +7,6 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 (cd $ROOT && git archive $REV dl_ofdm_amd/csrc include) | tar -x -C $T
 mkdir -p $(dirname $OUT)
-(cd $T/dl_ofdm_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function "$@" dccn_abi.hip -o $OUT)
+(cd $T/dl_ofdm_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function "$@" $(ls dccn_abi*.hip) -o $OUT)
 rm -rf $T
 echo built $OUT

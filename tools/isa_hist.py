@@ -1,6 +1,6 @@
 """Instruction histogram of one kernel in a device-only assembly dump.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S dl_ofdm_amd/csrc/dccn_abi.hip -o /tmp/dccn.s
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S dl_ofdm_amd/csrc/dccn_abi.hip -o /tmp/dccn.s      (or dccn_abi_eq / _gen / _conv.hip: one unit at a time)
     python tools/isa_hist.py /tmp/dccn.s <symbol prefix> [--loops]
 """
 import collections
