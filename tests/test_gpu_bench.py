@@ -100,8 +100,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # the training loop with the device-side generator (configs[1]: QPSK on Rayleigh EPA), timed by the same run
     e = d["e2e"]
     assert e["symbols_per_s"] > 1e7 and e["symbols_per_s"] < d["value"] * 1.001 and 0.0 < e["ber_last"] < 0.5
-    if st["mfma_frac"] < 0.37:
-        if copy_tbs < 4.3 and st["mfma_frac"] >= 0.33:
+    # (round 6, second half: 0.4195-0.4233 with the driver's arguments on five boxes -- launch boundaries, DESIGN.md 3.4 -- so the
+    # bar moves to 0.39, as VERDICT r05 asked once the step was past 0.42; a slow-HBM box is expected at ~0.37)
+    if st["mfma_frac"] < 0.39:
+        if copy_tbs < 4.3 and st["mfma_frac"] >= 0.34:
             pytest.xfail("slow-HBM box (device-to-device copy %.2f TB/s < 4.3): C2 step at %.1f %% of the fp32 MFMA peak; "
-                         "the build's bar is 37 %% on a box whose copy runs at speed" % (copy_tbs, 100 * st["mfma_frac"]))
-        raise AssertionError("C2 step below 37 %% of the fp32 MFMA peak (copy %.2f TB/s): %s" % (copy_tbs, diag))
+                         "the build's bar is 39 %% on a box whose copy runs at speed" % (copy_tbs, 100 * st["mfma_frac"]))
+        raise AssertionError("C2 step below 39 %% of the fp32 MFMA peak (copy %.2f TB/s): %s" % (copy_tbs, diag))
