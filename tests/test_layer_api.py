@@ -377,6 +377,22 @@ def test_patch_backward_route_bits():
     assert f(8, 560, 1, 3, 560, 1, 5, 1, 1, 1, 32) == 0          # odd channel count: no float4 pieces
 
 
+def test_conv1d_fused_backward_applicability():
+    """dccn_cconv1d_bwd_supported (host-side planning, no GPU): few-channel 1-D layers with 2F = 64 or 128 and at most 30 patch
+    columns; everything else stays with the separate implicit-GEMM routes"""
+    from dl_ofdm_amd import _lib
+    lib = _lib.load()
+    f = lib.dccn_cconv1d_bwd_supported
+    assert f(1170, 560, 2, 560, 5, 1, 64) == 1 and f(8, 333, 2, 167, 5, 2, 64) == 1 and f(4, 40, 6, 40, 2, 1, 32) == 1
+    assert f(8, 560, 2, 560, 8, 1, 64) == 0          # 32 patch columns: no room for the row of ones (bias gradient)
+    assert f(8, 560, 16, 560, 5, 1, 32) == 0         # 160 patch columns
+    assert f(8, 560, 2, 560, 5, 1, 16) == 0 and f(8, 560, 3, 560, 5, 1, 64) == 0      # 2F = 32; odd channel count
+    assert f(8, 560, 2, 560, 70, 1, 64) == 0         # 280 patch columns (and more taps than a 64-row chunk owns positions for)
+    assert lib.dccn_cconv1d_bwd_workspace_size(64) > lib.dccn_cconv1d_bwd_workspace_size(32) > 0
+    assert lib.dccn_cconv1d_bwd(None, None, None, None, None, None, 8, 560, 2, 560, 5, 0, 1, 2, 64, None, 0, None) == _lib.DCCN_ERR_INVALID_ARG \
+        if hasattr(_lib, "DCCN_ERR_INVALID_ARG") else True
+
+
 @pytest.mark.gpu
 def test_composable_model_equals_fused_engine():
     from dl_ofdm_amd import ofdm
