@@ -389,8 +389,7 @@ def test_conv1d_fused_backward_applicability():
     assert f(8, 560, 2, 560, 5, 1, 16) == 0 and f(8, 560, 3, 560, 5, 1, 64) == 0      # 2F = 32; odd channel count
     assert f(8, 560, 2, 560, 70, 1, 64) == 0         # 280 patch columns (and more taps than a 64-row chunk owns positions for)
     assert lib.dccn_cconv1d_bwd_workspace_size(64) > lib.dccn_cconv1d_bwd_workspace_size(32) > 0
-    assert lib.dccn_cconv1d_bwd(None, None, None, None, None, None, 8, 560, 2, 560, 5, 0, 1, 2, 64, None, 0, None) == _lib.DCCN_ERR_INVALID_ARG \
-        if hasattr(_lib, "DCCN_ERR_INVALID_ARG") else True
+    assert lib.dccn_cconv1d_bwd(None, None, None, None, None, None, 8, 560, 2, 560, 5, 0, 1, 2, 64, None, 0, None) < 0      # null operands: refused
 
 
 @pytest.mark.gpu
